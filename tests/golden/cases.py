@@ -1,0 +1,25 @@
+"""Case list shared by make_golden.py (runs the REFERENCE) and the tests (run the oracle / HIP path)."""
+
+SEED_WEIGHTS = 1234
+SEED_NP = 7            # np.random.seed() before every Model construction (feature-ring init noise)
+HEADS_BINARY = ["alexa", "hey_mycroft", "hey_jarvis"]
+CLIPS = ["alexa_test", "hey_mycroft_test", "hey_jane"]
+
+# (case id, heads, clip, predict_clip kwargs)
+CLIP_CASES = [
+    ("c1280", HEADS_BINARY, "alexa_test", dict(chunk_size=1280)),
+    ("c1280m", HEADS_BINARY, "hey_mycroft_test", dict(chunk_size=1280)),
+    ("c1280j", HEADS_BINARY, "hey_jane", dict(chunk_size=1280)),
+    ("c2560", HEADS_BINARY, "alexa_test", dict(chunk_size=2560)),
+    ("c1024", HEADS_BINARY, "alexa_test", dict(chunk_size=1024)),
+    ("c2048", HEADS_BINARY, "alexa_test", dict(chunk_size=2048)),
+    ("c400", HEADS_BINARY, "hey_mycroft_test", dict(chunk_size=400)),
+    ("c3000", HEADS_BINARY, "hey_mycroft_test", dict(chunk_size=3000)),
+    ("c5120np", HEADS_BINARY, "hey_jane", dict(chunk_size=5120, padding=0)),
+    ("patience", HEADS_BINARY, "hey_jane",
+     dict(chunk_size=1280, patience={"alexa": 2, "hey_jarvis": 3}, threshold={"alexa": 0.4, "hey_jarvis": 0.45})),
+    ("debounce", HEADS_BINARY, "hey_jane",
+     dict(chunk_size=1280, debounce_time=0.4, threshold={"alexa": 0.4, "hey_mycroft": 0.5, "hey_jarvis": 0.45})),
+    ("timer", ["timer"], "hey_mycroft_test", dict(chunk_size=1280)),
+    ("timer2560", ["timer"], "hey_mycroft_test", dict(chunk_size=2560)),
+]

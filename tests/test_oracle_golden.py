@@ -1,0 +1,89 @@
+"""The oracle's restatement of the reference's streaming logic vs vectors produced by the REFERENCE's
+own code (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oww_oracle as O
+from openwakeword_amd import weights as W
+
+TIMER_MAP = {"timer": {"1": "1_minute_timer", "2": "5_minute_timer", "3": "10_minute_timer",
+                       "4": "20_minute_timer", "5": "30_minute_timer", "6": "1_hour_timer"}}
+
+
+def build(head_names):
+    emb = W.synthetic_embedding(cases.SEED_WEIGHTS)
+    heads = {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in head_names}
+    np.random.seed(cases.SEED_NP)
+    return O.OracleModel(heads, emb, class_mapping=TIMER_MAP)
+
+
+@pytest.mark.parametrize("case", cases.CLIP_CASES, ids=[c[0] for c in cases.CLIP_CASES])
+def test_streaming_restatement_matches_reference(golden, case):
+    cid, head_names, clip, kw = case
+    mdl = build(head_names)
+    preds = mdl.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(golden[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    want = golden[f"{cid}/scores"]
+    assert got.shape == want.shape
+    # identical stage math + identical control flow -> identical numbers (BLAS batching aside)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(mdl.preprocessor.features, golden[f"{cid}/features"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(mdl.preprocessor.mel_rows[-16:], golden[f"{cid}/mel_tail"], rtol=0, atol=1e-5)
+
+
+def test_reset_then_second_clip(golden):
+    mdl = build(cases.HEADS_BINARY)
+    assert mdl.preprocessor.features.shape == (41, 96)            # SURVEY §3.3 structural pin
+    np.testing.assert_allclose(mdl.preprocessor.features, golden["init/feature_buffer"], atol=2e-5)
+    mdl.predict_clip(golden["pcm/alexa_test"], chunk_size=1280)
+    np.random.seed(cases.SEED_NP + 1)
+    mdl.reset()
+    preds = mdl.predict_clip(golden["pcm/hey_mycroft_test"], chunk_size=1280)
+    labels = list(golden["c1280/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    np.testing.assert_allclose(got, golden["reset/scores"], atol=2e-6)
+
+
+def test_structural_pins(golden):
+    # notebooks/converting_google_speech_embedding_model.ipynb:859 ; docs/models/alexa.md:26-29 ; timers.md:24-27
+    assert O.cnn_param_count() == 332_088
+    assert W.embedding_param_count(W.synthetic_embedding()) == 332_088
+    assert W.head_param_count(W.synthetic_head("alexa")) == 102_849
+    assert W.head_param_count(W.synthetic_head("timer")) == 435_335
+    # SURVEY Appendix A self-consistency values of the mel recipe
+    fb = O.mel_filterbank()
+    assert (fb > 0).sum() == 229
+    nz = np.nonzero(fb.sum(axis=1))[0]
+    assert (nz[0], nz[-1]) == (2, 121)
+    assert abs(fb.sum() - 1.023993) < 1e-5 and abs(fb.max() - 0.014234) < 1e-6
+    assert abs((O.hann_window_padded() ** 2).sum() - 150.0) < 1e-9
+    np.testing.assert_array_equal(fb, W.mel_filterbank())           # product table == oracle table
+    # 5 rows on the first call, 8 afterwards
+    assert O.n_mel_frames(1280) == 5 and O.n_mel_frames(1760) == 8 and O.n_mel_frames(1280 * 2 + 480) == 16
+
+
+def test_stage_regression_vectors(golden):
+    x = golden["stage/mel_in"].astype(np.float32)[None]
+    np.testing.assert_allclose(O.mel_stage(x)[0, 0], golden["stage/mel_out"], atol=1e-4)
+    # all-zero audio -> -100 dB everywhere -> mel value -8 after x/10+2 (Appendix A step 6)
+    z = O.mel_transform(O.mel_stage(np.zeros((1, 1760), np.float32)))
+    assert np.allclose(z, -8.0, atol=1e-5)
+    emb = W.synthetic_embedding(cases.SEED_WEIGHTS)
+    win = (golden["stage/mel_out"][:76] / 10 + 2).astype(np.float32)
+    e = O.embedding_stage(win[None, :, :, None], emb).reshape(96)
+    np.testing.assert_allclose(e, golden["stage/embed_out"], atol=2e-5)
+
+
+def test_cnn_is_time_fully_convolutional():
+    """SURVEY §8a-E probe: a (76+8K)-row strip gives the K+1 per-window outputs -> the incremental
+    (streaming) evaluation used on the GPU is exact."""
+    emb = W.synthetic_embedding(cases.SEED_WEIGHTS)
+    r = np.random.default_rng(0)
+    strip = r.normal(10, 1.5, (1, 76 + 8 * 3, 32, 1))
+    full = O.embedding_stage(strip, emb, np.float64)[0, :, 0, :]
+    assert full.shape == (4, 96)
+    for k in range(4):
+        one = O.embedding_stage(strip[:, 8 * k: 8 * k + 76], emb, np.float64).reshape(96)
+        np.testing.assert_allclose(full[k], one, atol=1e-12)
