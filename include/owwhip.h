@@ -1,0 +1,131 @@
+/*
+ * owwhip.h -- C ABI of libowwhip.so: the MI355X (gfx950) streaming wake-word path.
+ *
+ * This is the drop-in boundary for the ONE hot path of dscripka/openWakeWord:
+ *   int16 PCM 16 kHz -> log-mel -> speech-embedding CNN -> wake-word heads -> post-processing.
+ * The reference crosses this boundary through three onnxruntime / LiteRT closures
+ *   melspec_model_predict        openwakeword/utils.py:87  (122-136 for tflite)
+ *   embedding_model_predict      openwakeword/utils.py:93  (147-161)
+ *   model_prediction_function[]  openwakeword/model.py:137-138, 158-159 (116-119, 174-175)
+ * and keeps all per-stream state in Python objects (utils.py:163-170, model.py:198).  Here the state
+ * of S concurrent streams lives in HBM and one call advances every stream by one 80 ms step.
+ *
+ * Conventions: plain C, opaque handle, every function returns 0 on success and a negative OWW_E*
+ * code on failure (message via oww_last_error()); nothing throws across the ABI.  One handle = one
+ * GPU; calls on one handle must be serialised by the caller (the reference object is single-threaded
+ * too).  "dev" pointers are HIP device pointers valid on the handle's device; "host" pointers are
+ * ordinary host memory.  All float data is IEEE fp32, row-major, C order.
+ */
+#ifndef OWWHIP_H
+#define OWWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OWW_ABI_VERSION 1
+
+#define OWW_OK            0
+#define OWW_EINVAL       -1   /* bad argument */
+#define OWW_EHIP         -2   /* HIP runtime error */
+#define OWW_ESTATE       -3   /* call out of order (e.g. step before weights committed) */
+#define OWW_ENOMEM       -4
+
+#define OWW_CHUNK        1280 /* samples per 80 ms step          (utils.py:417-434) */
+#define OWW_MEL_BINS       32 /* melspectrogram.onnx output bins (utils.py:271)     */
+#define OWW_MEL_PER_CHUNK   8 /* new mel rows per step                 */
+#define OWW_WINDOW         76 /* mel rows per embedding window   (utils.py:225,440) */
+#define OWW_EMB_DIM        96 /* embedding_model.onnx output     (utils.py:323)     */
+#define OWW_SCORE_RING     30 /* prediction_buffer maxlen        (model.py:198)     */
+#define OWW_MAX_HEADS      16
+#define OWW_MAX_LABELS     32
+
+typedef struct oww_ctx oww_ctx;
+
+typedef struct oww_config {
+    int32_t device;        /* HIP device ordinal */
+    int32_t n_streams;     /* S: concurrent audio streams owned by this handle */
+    int32_t max_chunks;    /* largest n_chunks a single oww_step may carry (>=1) */
+    int32_t feature_ring;  /* rows of the per-stream feature ring; 0 = max head T (>=16) */
+    int32_t use_mfma;      /* 1 = MFMA kernels (default path), 0 = plain-VALU kernels of the same dataflow */
+    int32_t debug_layers;  /* 1 = keep per-layer CNN outputs of the last step for oww_debug_read */
+    void*   stream;        /* hipStream_t to launch on; NULL = a stream owned by the handle */
+} oww_config;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+int  oww_abi_version(void);
+const char* oww_last_error(void);
+int  oww_create(const oww_config* cfg, oww_ctx** out);
+int  oww_destroy(oww_ctx* h);
+
+/* ---- weights (replace the .onnx/.tflite files of openwakeword/__init__.py:8-51) ----------------
+ * Host blobs, copied.  Layouts:
+ *  mel   : float hann[400]; int32 start[32]; float taps[32][16]          (window + sparse mel filterbank)
+ *  embed : for each of the 20 conv layers in graph order: float w[kh][kw][cin][cout] (Keras HWIO),
+ *          then for layers 0..18: float scale[cout]; float shift[cout]   (inference BatchNorm folded)
+ *  head  : int32 hdr[8] = {kind(0 binary,1 gated,2 multiclass), T, hidden, n_out, has_layernorm,0,0,0}
+ *          then per net (1 net; 2 for gated): w1[T*96][hidden] b1[hidden] (ln1_g ln1_b [hidden] if
+ *          has_layernorm) w2[hidden][hidden] b2 (ln2_g ln2_b) w3[hidden][n_out] b3[n_out]
+ */
+int  oww_load_mel(oww_ctx* h, const void* blob, size_t nbytes);
+int  oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes);
+int  oww_add_head(oww_ctx* h, const void* blob, size_t nbytes);     /* returns head index >= 0 */
+int  oww_commit(oww_ctx* h);          /* pack + upload, allocate state, derive reset state; then reset all */
+int  oww_n_labels(const oww_ctx* h);  /* total score columns = sum of n_out over heads */
+
+/* ---- per-stream state (AudioFeatures.reset utils.py:172-178 + Model.reset model.py:226-230) -----
+ * stream_ids == NULL resets every stream.  init_features (host, [feature_ring][96], oldest row first)
+ * seeds the feature ring the way the reference seeds it with embeddings of random audio
+ * (utils.py:169); NULL = zeros. */
+int  oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* init_features);
+
+/* ---- post-processing options of Model.predict (model.py:340-359); arrays of oww_n_labels() -------
+ * patience[i] <= 0 and debounce_frames <= 0 disable the respective rule for label i. */
+int  oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold, int32_t debounce_frames);
+
+/* ---- the hot loop: one Model.predict per stream (model.py:232-386) --------------------------------
+ * pcm: int16 [S][n_chunks*1280], stream-major.  scores: fp32 [S][n_labels] or NULL.
+ * *_on_device: 0 = host pointer (copied on the handle's stream), 1 = device pointer.
+ * n_chunks > 1 reproduces the reference's multi-chunk call: one mel pass over the whole span
+ * (single top_db clamp), one embedding + head evaluation per chunk, max over chunks (model.py:287-298).
+ * Asynchronous on the handle's stream unless scores is a host pointer. */
+int  oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks,
+              float* scores, int scores_on_device);
+int  oww_sync(oww_ctx* h);
+const float* oww_scores_dev(const oww_ctx* h);     /* device [S][n_labels], valid until the next step */
+
+/* ---- stage-level entry points (the reference's per-stage closures; used for parity tests and for
+ *      AudioFeatures._get_melspectrogram / embed_clips style callers).  Host pointers. ---------------
+ * oww_mel: int16 [B][n] -> dB values [B][F][32], F=(n-512)/160+1, clamp floor shared over the call
+ *          exactly like melspec_model_predict (utils.py:87,202).  Requires B <= n_streams.
+ * oww_embed: mel rows [B][rows][32] (rows = 76 + 8*(n_out-1)) -> embeddings [B][n_out][96]; the
+ *          windows are rows[8i : 8i+76] (utils.py:229-236).  Runs the same incremental kernels on
+ *          scratch state and CLOBBERS the streaming state of streams [0,B): reset afterwards.
+ * oww_head: features [B][T][96] -> raw outputs [B][n_out] of head `head` (model.py:137-138). */
+int  oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db);
+int  oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float* out);
+int  oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out);
+
+/* ---- introspection ------------------------------------------------------------------------------ */
+/* AudioFeatures.get_features (utils.py:454-460): last T rows of stream sid's feature ring, oldest first */
+int  oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out);
+/* newest 8*n_chunks transformed mel rows (x/10+2) of stream sid from the last step */
+int  oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows);
+/* per-layer CNN outputs (new rows only, dense [rows][F][C]) of stream sid from the last chunk processed;
+ * layer 0..19; needs cfg.debug_layers.  Returns the number of floats written. */
+int  oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t cap);
+/* kernel timing: records hipEvents around every kernel of subsequent oww_step calls when enabled;
+ * oww_kernel_times fills ms[i] with the accumulated time and n[i] with the launch count of kernel
+ * class i (0 mel,1 stageA,2 stageB,3 stageC,4 stageD,5 stageE,6 heads,7 postproc) and clears them. */
+int  oww_enable_timing(oww_ctx* h, int on);
+int  oww_kernel_times(oww_ctx* h, double ms[8], int64_t n[8]);
+/* capture the n_chunks==1 device-to-device step into a hipGraph and replay it on later steps */
+int  oww_use_graph(oww_ctx* h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OWWHIP_H */

@@ -1,0 +1,38 @@
+"""Build libowwhip.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch extension machinery:
+the library is a plain C-ABI shared object (include/owwhip.h) loaded through ctypes."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "owwhip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "owwhip_kernels.h"), os.path.join(ROOT, "include", "owwhip.h")]
+LIB = os.path.join(HERE, "libowwhip.so")
+
+
+def lib_path() -> str:
+    return LIB
+
+
+def is_fresh() -> bool:
+    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and is_fresh():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC,
+           "-I" + os.path.join(ROOT, "include"), "-o", LIB + ".tmp", "-Wall", "-Wno-unused-function"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,79 @@
+"""ctypes binding of libowwhip.so (C ABI in include/owwhip.h).  Fails loudly when the library is
+missing -- there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+_lib = None
+
+
+class OwwError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_streams", C.c_int32), ("max_chunks", C.c_int32),
+                ("feature_ring", C.c_int32), ("use_mfma", C.c_int32), ("debug_layers", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+# every symbol include/owwhip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "oww_abi_version": (C.c_int, []),
+    "oww_last_error": (C.c_char_p, []),
+    "oww_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "oww_destroy": (C.c_int, [_P]),
+    "oww_load_mel": (C.c_int, [_P, _P, C.c_size_t]),
+    "oww_load_embedding": (C.c_int, [_P, _P, C.c_size_t]),
+    "oww_add_head": (C.c_int, [_P, _P, C.c_size_t]),
+    "oww_commit": (C.c_int, [_P]),
+    "oww_n_labels": (C.c_int, [_P]),
+    "oww_reset": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "oww_set_postproc": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "oww_step": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P, C.c_int]),
+    "oww_sync": (C.c_int, [_P]),
+    "oww_scores_dev": (_P, [_P]),
+    "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "oww_embed": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "oww_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
+    "oww_get_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "oww_get_mel": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
+    "oww_debug_read": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "oww_enable_timing": (C.c_int, [_P, C.c_int]),
+    "oww_kernel_times": (C.c_int, [_P, _P, _P]),
+    "oww_use_graph": (C.c_int, [_P, C.c_int]),
+}
+
+
+def load():
+    """dlopen libowwhip.so once.  torch is imported first when available so that the HIP runtime
+    torch bundles (soname libamdhip64.so.7) is the one and only runtime in the process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.lib_path()
+    if not os.path.exists(path):
+        raise OwwError(f"{path} is missing: build it with `python -m openwakeword_amd._build` "
+                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    if lib.oww_abi_version() != 1:
+        raise OwwError("libowwhip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise OwwError(f"libowwhip error {rc}: {load().oww_last_error().decode(errors='replace')}")
+    return rc

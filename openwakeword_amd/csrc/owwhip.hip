@@ -1,0 +1,893 @@
+// owwhip.hip -- host side of libowwhip.so: context, weight packing, kernel launches, C ABI.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC owwhip.hip -I../../include -o libowwhip.so
+// Interface contract and the reference call sites each entry replaces: include/owwhip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "owwhip.h"
+#include "owwhip_kernels.h"
+
+using namespace owk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) return fail(OWW_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+struct LayerDef { int kh, kw, cin, cout; };
+const LayerDef kLayers[20] = {
+    {3, 3, 1, 24},
+    {1, 3, 24, 24}, {3, 1, 24, 24},
+    {1, 3, 24, 48}, {3, 1, 48, 48}, {1, 3, 48, 48}, {3, 1, 48, 48},
+    {1, 3, 48, 72}, {3, 1, 72, 72}, {1, 3, 72, 72}, {3, 1, 72, 72},
+    {1, 3, 72, 96}, {3, 1, 96, 96}, {1, 3, 96, 96}, {3, 1, 96, 96},
+    {1, 3, 96, 96}, {3, 1, 96, 96}, {1, 3, 96, 96}, {3, 1, 96, 96},
+    {3, 1, 96, 96},
+};
+// new rows x F x C of every layer's output per step (debug layout)
+const int kLayerOut[20][3] = {
+    {8, 32, 24}, {8, 32, 24}, {8, 32, 24},
+    {4, 16, 48}, {4, 16, 48}, {4, 16, 48}, {4, 16, 48},
+    {4, 8, 72}, {4, 8, 72}, {4, 8, 72}, {4, 8, 72},
+    {2, 4, 96}, {2, 4, 96}, {2, 4, 96}, {2, 4, 96},
+    {2, 2, 96}, {2, 2, 96}, {2, 2, 96}, {2, 2, 96},
+    {1, 1, 96},
+};
+
+// pack [ntaps][cin][cout] for conv_mfma / heads64: out[(ct*KS + s)*64 + lane]
+void pack_mfma(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
+    const int nct = (cout + 15) / 16, ks = ntaps * cin / 4;
+    out.assign((size_t)nct * ks * 64, 0.f);
+    for (int ct = 0; ct < nct; ++ct)
+        for (int tap = 0; tap < ntaps; ++tap)
+            for (int cb = 0; cb < cin; cb += 8)
+                for (int q = 0; q < 2; ++q) {
+                    const int s = (tap * cin + cb) / 4 + q;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 15, j = lane >> 4;
+                        const int co = ct * 16 + i, ci = cb + 2 * j + q;
+                        out[((size_t)ct * ks + s) * 64 + lane] = co < cout ? w[((size_t)tap * cin + ci) * cout + co] : 0.f;
+                    }
+                }
+}
+
+struct HostBuf {                      // host image of the device weight buffer (256-byte aligned pieces)
+    std::vector<float> data;
+    size_t add(const float* p, size_t n) {
+        const size_t off = (data.size() + 63) / 64 * 64;
+        data.resize(off + n);
+        if (p) memcpy(data.data() + off, p, n * sizeof(float));
+        return off;
+    }
+    size_t add(const std::vector<float>& v) { return add(v.data(), v.size()); }
+};
+
+struct NetHost {
+    int hidden, n_out, has_ln, T, final_act, head, role, out_col;
+    const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // into the owning head blob
+};
+struct HeadHost {
+    int kind, T, hidden, n_out, has_ln;
+    std::vector<float> blob;
+    int out_col;
+};
+struct FastGroup {
+    int T, NH, n_nets;
+    std::vector<int> nets;            // indices into all nets
+    NetDesc* d_nets = nullptr;
+    const float* d_w1pk = nullptr;
+    const float* d_b1cat = nullptr;
+};
+
+constexpr int N_STATE = 11;
+// per-stream floats of every state array: hist_mel, hist2, B:b,d  C:b,d  D:b,d  E:b,d  hist19
+const int kStateLen[N_STATE] = {64, 1536, 1536, 1536, 1152, 1152, 768, 768, 384, 384, 192};
+constexpr int DBG_FLOATS = 3 * 6144 + 4 * 3072 + 4 * 2304 + 4 * 768 + 4 * 384 + 96;
+
+struct EventRec { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct oww_ctx {
+    oww_config cfg{};
+    int S = 0, Spad = 0, kmax = 1, TR = 16, NL = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false, committed = false, mfma = true;
+    // host side weights as loaded
+    std::vector<float> mel_blob, emb_blob;
+    std::vector<HeadHost> heads;
+    std::vector<NetHost> nets;
+    std::vector<std::pair<int, int>> head_nets;      // [begin,end) into nets per head
+    // device weights
+    float* d_w = nullptr;
+    const float *d_hann = nullptr, *d_taps = nullptr;
+    const int* d_mstart = nullptr;
+    const float* d_conv[20] = {};     // layer 0: natural [9][24]; 1..19: packed (mfma) or natural (valu)
+    const float* d_scale[20] = {};
+    const float* d_shift[20] = {};
+    NetDesc* d_allnets = nullptr;
+    std::vector<FastGroup> groups;
+    std::vector<int> generic_nets;    // indices into nets (with verifier right after its primary)
+    NetDesc* d_generic = nullptr;
+    int generic_hmax = 0;
+    float* d_scratch = nullptr;
+    size_t scratch_streams = 0;
+    // state
+    float* d_state[N_STATE] = {};
+    float* d_tmpl[N_STATE] = {};
+    float *d_xA = nullptr, *d_xB = nullptr, *d_xC = nullptr, *d_xD = nullptr;
+    float *d_mel = nullptr, *d_feat = nullptr, *d_emb = nullptr, *d_raw = nullptr, *d_scores = nullptr, *d_ring = nullptr;
+    float* d_featinit = nullptr;
+    float* d_dbg = nullptr;
+    uint32_t *d_nfeat = nullptr, *d_npred = nullptr;
+    int16_t *d_tail = nullptr, *d_pcm = nullptr;
+    int* d_ids = nullptr;
+    int ids_cap = 0;
+    int *d_patience = nullptr;
+    float* d_threshold = nullptr;
+    int debounce_frames = 0;
+    // timing
+    bool timing = false;
+    std::vector<EventRec> ev;
+    size_t ev_used = 0;
+    double t_ms[8] = {};
+    int64_t t_n[8] = {};
+    // graph
+    bool want_graph = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+};
+
+namespace {
+
+int flush_events(oww_ctx* h) {
+    if (!h->ev_used) return 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[i].a, h->ev[i].b));
+        h->t_ms[h->ev[i].cls] += ms;
+        h->t_n[h->ev[i].cls] += 1;
+    }
+    h->ev_used = 0;
+    return 0;
+}
+
+struct Timed {          // RAII: records a start event now and a stop event at scope exit
+    oww_ctx* h;
+    EventRec* r = nullptr;
+    Timed(oww_ctx* h_, int cls) : h(h_) {
+        if (!h->timing) return;
+        if (h->ev_used == h->ev.size()) {
+            if (h->ev.size() >= 8192) { flush_events(h); }
+            else {
+                EventRec e{};
+                if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+                h->ev.push_back(e);
+            }
+        }
+        r = &h->ev[h->ev_used++];
+        r->cls = cls;
+        (void)hipEventRecord(r->a, h->stream);
+    }
+    ~Timed() { if (r) (void)hipEventRecord(r->b, h->stream); }
+};
+
+template <class K>
+int set_lds(K kernel, int bytes) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+// ---- CNN over the first n_active streams, mel rows at d_mel + s*mel_stride + mel_off ----------------
+template <bool MFMA>
+int run_cnn_t(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
+    hipStream_t st = h->stream;
+    const bool dbg = h->d_dbg != nullptr;
+    int off = 0;
+    int dbg_off[20];
+    for (int l = 0; l < 20; ++l) { dbg_off[l] = off; off += kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2]; }
+    {
+        StageAParams p{};
+        p.mel = h->d_mel; p.mel_stride = mel_stride; p.mel_off = mel_off;
+        p.hist_mel = h->d_state[0]; p.hist2 = h->d_state[1];
+        p.w0 = h->d_conv[0]; p.w1 = h->d_conv[1]; p.w2 = h->d_conv[2];
+        for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
+        p.xout = h->d_xA; p.dbg = dbg ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+        Timed t(h, 1);
+        hipLaunchKernelGGL(stageA_kernel<MFMA>, dim3(n_active), dim3(CfgA::NT), CfgA::LDS_BYTES, st, p);
+    }
+    auto fill = [&](StageParams& p, const float* xin, float* xout, int first_layer, int sb, int sd) {
+        p.xin = xin; p.xout = xout; p.hist_b = h->d_state[sb]; p.hist_d = h->d_state[sd];
+        for (int i = 0; i < 4; ++i) {
+            p.w[i] = h->d_conv[first_layer + i]; p.scale[i] = h->d_scale[first_layer + i];
+            p.shift[i] = h->d_shift[first_layer + i]; p.dbg_off[i] = dbg_off[first_layer + i];
+        }
+        p.dbg = dbg ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+    };
+    {
+        StageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3);
+        Timed t(h, 2);
+        hipLaunchKernelGGL((stage_kernel<CfgB, MFMA, false>), dim3((n_active + CfgB::B - 1) / CfgB::B), dim3(CfgB::NT), CfgB::LDS_BYTES, st, p);
+    }
+    {
+        StageParams p{}; fill(p, h->d_xB, h->d_xC, 7, 4, 5);
+        Timed t(h, 3);
+        hipLaunchKernelGGL((stage_kernel<CfgC, MFMA, false>), dim3((n_active + CfgC::B - 1) / CfgC::B), dim3(CfgC::NT), CfgC::LDS_BYTES, st, p);
+    }
+    {
+        StageParams p{}; fill(p, h->d_xC, h->d_xD, 11, 6, 7);
+        Timed t(h, 4);
+        hipLaunchKernelGGL((stage_kernel<CfgD, MFMA, false>), dim3((n_active + CfgD::B - 1) / CfgD::B), dim3(CfgD::NT), CfgD::LDS_BYTES, st, p);
+    }
+    {
+        StageParams p{}; fill(p, h->d_xD, nullptr, 15, 8, 9);
+        p.hist19 = h->d_state[10]; p.w19 = h->d_conv[19]; p.feat = h->d_feat; p.emb = h->d_emb; p.nfeat = h->d_nfeat; p.TR = h->TR;
+        p.dbg_off[4] = dbg_off[19];
+        Timed t(h, 5);
+        hipLaunchKernelGGL((stage_kernel<CfgE, MFMA, true>), dim3((n_active + CfgE::B - 1) / CfgE::B), dim3(CfgE::NT), CfgE::LDS_BYTES, st, p);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int run_cnn(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
+    // grids cover whole workgroups of streams: round up to the largest per-workgroup stream count
+    n_active = std::min(h->Spad, (n_active + 7) / 8 * 8);
+    return h->mfma ? run_cnn_t<true>(h, n_active, mel_stride, mel_off) : run_cnn_t<false>(h, n_active, mel_stride, mel_off);
+}
+
+int ensure_scratch(oww_ctx* h, size_t streams) {
+    if (streams <= h->scratch_streams) return 0;
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    h->d_scratch = nullptr; h->scratch_streams = 0;
+    const size_t n = streams * std::max<size_t>(1, h->nets.size()) * 2 * (size_t)std::max(h->generic_hmax, 1);
+    HIPCHK(hipMalloc(&h->d_scratch, n * sizeof(float)));
+    h->scratch_streams = streams;
+    return 0;
+}
+
+int heads_lds_bytes(int NH) { return (HD_SB * 100 + 2 * HD_SB * (NH + 4) + HD_SB * HD_MAXNETS) * 4; }
+
+// heads over streams [0,n_active): ring mode (ext == nullptr) or external features
+int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, int only_head, float* raw_out, int force_generic) {
+    hipStream_t st = h->stream;
+    Timed t(h, 6);
+    HeadParams base{};
+    base.feat = ext ? ext : h->d_feat; base.ext = ext ? 1 : 0; base.TR = h->TR; base.nfeat = h->d_nfeat;
+    base.raw = raw_out; base.NL = h->NL; base.S = n_active; base.accumulate_max = accumulate_max ? 1 : 0;
+    const bool fast_ok = h->mfma && !force_generic;
+    if (fast_ok) {
+        for (auto& g : h->groups) {
+            if (only_head >= 0) {
+                bool has = false;
+                for (int ni : g.nets) has |= h->nets[ni].head == only_head;
+                if (!has) continue;
+            }
+            HeadParams p = base;
+            p.nets = g.d_nets; p.n_nets = g.n_nets; p.T = g.T; p.NH = g.NH; p.w1pk = g.d_w1pk; p.b1cat = g.d_b1cat;
+            hipLaunchKernelGGL(heads64_kernel, dim3((n_active + HD_SB - 1) / HD_SB), dim3(HD_NT), heads_lds_bytes(g.NH), st, p);
+        }
+    }
+    // generic kernel: nets that have no fast group, or everything when the fast path is off
+    if (!fast_ok) {
+        if (int rc = ensure_scratch(h, (size_t)std::max(n_active, h->Spad))) return rc;
+        HeadParams p = base;
+        p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
+        int nb = 0, ne = (int)h->nets.size();
+        if (only_head >= 0) { nb = h->head_nets[only_head].first; ne = h->head_nets[only_head].second; }
+        hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + 63) / 64), dim3(64), 0, st, p, nb, ne, h->d_scratch, h->generic_hmax);
+    } else if (!h->generic_nets.empty()) {
+        if (int rc = ensure_scratch(h, (size_t)std::max(n_active, h->Spad))) return rc;
+        for (size_t hi = 0; hi < h->heads.size(); ++hi) {
+            if (only_head >= 0 && (int)hi != only_head) continue;
+            const int nb = h->head_nets[hi].first, ne = h->head_nets[hi].second;
+            if (std::find(h->generic_nets.begin(), h->generic_nets.end(), nb) == h->generic_nets.end()) continue;
+            HeadParams p = base;
+            p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
+            hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + 63) / 64), dim3(64), 0, st, p, nb, ne, h->d_scratch, h->generic_hmax);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_mel(oww_ctx* h, const int16_t* d_pcm, int n_streams, int n_samples, int n_frames, int streaming, float* out, float* smax) {
+    MelParams p{};
+    p.pcm = d_pcm; p.n_samples = n_samples; p.n_frames = n_frames; p.streaming = streaming;
+    p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.out = out; p.smax = smax;
+    p.hann = h->d_hann; p.mel_start = h->d_mstart; p.mel_taps = h->d_taps; p.S = n_streams;
+    const int grid = std::min(n_streams, 256 * 8);
+    Timed t(h, 0);
+    hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(MEL_NT), 0, h->stream, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int do_reset(oww_ctx* h, const int* d_ids, int n, const float* d_featinit) {
+    ResetParams p{};
+    p.ids = d_ids; p.n = n; p.n_arrays = N_STATE;
+    for (int a = 0; a < N_STATE; ++a) { p.dst[a] = h->d_state[a]; p.tmpl[a] = h->d_tmpl[a]; p.len[a] = kStateLen[a]; }
+    p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.npred = h->d_npred;
+    p.ring = h->d_ring; p.ring_len = h->NL * OWW_SCORE_RING;
+    p.feat = h->d_feat; p.feat_len = h->TR * OWW_EMB_DIM; p.feat_init = d_featinit;
+    hipLaunchKernelGGL(reset_kernel, dim3(n), dim3(256), 0, h->stream, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <class T>
+int dalloc(T** p, size_t n, bool zero = true) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+void free_all(oww_ctx* h) {
+    auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    fr(h->d_w); fr(h->d_allnets); fr(h->d_generic); fr(h->d_scratch);
+    for (auto& g : h->groups) fr(g.d_nets);
+    for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
+    fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
+    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail);
+    fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold);
+    for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    h->ev.clear();
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+}
+
+// one chunk of the streaming step on device-resident mel rows
+int step_chunk(oww_ctx* h, int k, int c) {
+    if (int rc = run_cnn(h, h->Spad, 8 * k * 32, c * 8 * 32)) return rc;
+    if (int rc = run_heads(h, h->Spad, c > 0, nullptr, -1, h->d_raw, 0)) return rc;
+    hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+    return 0;
+}
+
+int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
+    if (int rc = launch_mel(h, d_pcm, h->S, OWW_CHUNK * k, 8 * k, 1, h->d_mel, nullptr)) return rc;
+    for (int c = 0; c < k; ++c)
+        if (int rc = step_chunk(h, k, c)) return rc;
+    PostParams pp{};
+    pp.raw = h->d_raw; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred;
+    pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
+    pp.NL = h->NL; pp.S = h->Spad;
+    {
+        Timed t(h, 7);
+        hipLaunchKernelGGL(postproc_kernel, dim3((h->Spad + 127) / 128), dim3(128), 0, h->stream, pp);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int oww_abi_version(void) { return OWW_ABI_VERSION; }
+const char* oww_last_error(void) { return g_err.c_str(); }
+
+int oww_create(const oww_config* cfg, oww_ctx** out) {
+    if (!cfg || !out) return fail(OWW_EINVAL, "oww_create: null argument");
+    if (cfg->n_streams < 1) return fail(OWW_EINVAL, "oww_create: n_streams must be >= 1");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(OWW_EINVAL, "oww_create: device %d of %d", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+    oww_ctx* h = new (std::nothrow) oww_ctx();
+    if (!h) return fail(OWW_ENOMEM, "oww_create: out of host memory");
+    h->cfg = *cfg;
+    h->S = cfg->n_streams;
+    h->Spad = (h->S + 31) / 32 * 32;
+    h->kmax = std::max(1, cfg->max_chunks);
+    h->mfma = cfg->use_mfma != 0;
+    if (cfg->stream) h->stream = reinterpret_cast<hipStream_t>(cfg->stream);
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(OWW_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    *out = h;
+    return OWW_OK;
+}
+
+int oww_destroy(oww_ctx* h) {
+    if (!h) return OWW_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return OWW_OK;
+}
+
+int oww_load_mel(oww_ctx* h, const void* blob, size_t nbytes) {
+    if (!h || !blob) return fail(OWW_EINVAL, "oww_load_mel: null argument");
+    if (h->committed) return fail(OWW_ESTATE, "weights already committed");
+    const size_t want = (400 + 32 + 32 * 16) * 4;
+    if (nbytes != want) return fail(OWW_EINVAL, "oww_load_mel: blob is %zu bytes, expected %zu", nbytes, want);
+    h->mel_blob.assign((const float*)blob, (const float*)blob + want / 4);
+    return OWW_OK;
+}
+
+int oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes) {
+    if (!h || !blob) return fail(OWW_EINVAL, "oww_load_embedding: null argument");
+    if (h->committed) return fail(OWW_ESTATE, "weights already committed");
+    size_t want = 0;
+    for (int l = 0; l < 20; ++l) {
+        want += (size_t)kLayers[l].kh * kLayers[l].kw * kLayers[l].cin * kLayers[l].cout;
+        if (l < 19) want += 2 * (size_t)kLayers[l].cout;
+    }
+    if (nbytes != want * 4) return fail(OWW_EINVAL, "oww_load_embedding: blob is %zu bytes, expected %zu", nbytes, want * 4);
+    h->emb_blob.assign((const float*)blob, (const float*)blob + want);
+    return OWW_OK;
+}
+
+int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
+    if (!h || !blob || nbytes < 32) return fail(OWW_EINVAL, "oww_add_head: bad argument");
+    if (h->committed) return fail(OWW_ESTATE, "weights already committed");
+    if ((int)h->heads.size() >= OWW_MAX_HEADS) return fail(OWW_EINVAL, "too many heads");
+    const int32_t* hdr = (const int32_t*)blob;
+    HeadHost hh{};
+    hh.kind = hdr[0]; hh.T = hdr[1]; hh.hidden = hdr[2]; hh.n_out = hdr[3]; hh.has_ln = hdr[4];
+    if (hh.kind < 0 || hh.kind > 2 || hh.T < 1 || hh.T > 120 || hh.hidden < 1 || hh.hidden > 512 || hh.n_out < 1 || hh.n_out > 8)
+        return fail(OWW_EINVAL, "oww_add_head: bad header kind=%d T=%d hidden=%d n_out=%d", hh.kind, hh.T, hh.hidden, hh.n_out);
+    const size_t in = (size_t)hh.T * 96, H = hh.hidden, O = hh.n_out;
+    const size_t per_net = in * H + H + (hh.has_ln ? 2 * H : 0) + H * H + H + (hh.has_ln ? 2 * H : 0) + H * O + O;
+    const size_t n_nets = hh.kind == 1 ? 2 : 1;
+    if (nbytes != 32 + per_net * n_nets * 4)
+        return fail(OWW_EINVAL, "oww_add_head: blob is %zu bytes, expected %zu", nbytes, 32 + per_net * n_nets * 4);
+    hh.blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
+    h->heads.push_back(std::move(hh));
+    return (int)h->heads.size() - 1;
+}
+
+int oww_n_labels(const oww_ctx* h) { return h ? h->NL : 0; }
+
+int oww_commit(oww_ctx* h) {
+    if (!h) return fail(OWW_EINVAL, "null handle");
+    if (h->committed) return fail(OWW_ESTATE, "already committed");
+    if (h->mel_blob.empty() || h->emb_blob.empty()) return fail(OWW_ESTATE, "mel and embedding weights must be loaded before commit");
+    HIPCHK(hipSetDevice(h->cfg.device));
+
+    // ---- nets ----
+    h->nets.clear(); h->head_nets.clear();
+    int col = 0, maxT = 16, hmax = 1;
+    for (size_t hi = 0; hi < h->heads.size(); ++hi) {
+        HeadHost& hh = h->heads[hi];
+        hh.out_col = col;
+        const size_t in = (size_t)hh.T * 96, H = hh.hidden, O = hh.n_out;
+        const float* q = hh.blob.data();
+        const int begin = (int)h->nets.size();
+        for (int r = 0; r < (hh.kind == 1 ? 2 : 1); ++r) {
+            NetHost n{};
+            n.hidden = hh.hidden; n.n_out = hh.n_out; n.has_ln = hh.has_ln; n.T = hh.T;
+            n.final_act = hh.kind == 2 ? 1 : 0; n.head = (int)hi; n.role = r; n.out_col = col;
+            n.w1 = q; q += in * H; n.b1 = q; q += H;
+            if (hh.has_ln) { n.ln1g = q; q += H; n.ln1b = q; q += H; }
+            n.w2 = q; q += H * H; n.b2 = q; q += H;
+            if (hh.has_ln) { n.ln2g = q; q += H; n.ln2b = q; q += H; }
+            n.w3 = q; q += H * O; n.b3 = q; q += O;
+            h->nets.push_back(n);
+        }
+        h->head_nets.push_back({begin, (int)h->nets.size()});
+        col += hh.n_out;
+        maxT = std::max(maxT, hh.T);
+        hmax = std::max(hmax, hh.hidden);
+    }
+    h->NL = col;
+    if (h->NL > OWW_MAX_LABELS) return fail(OWW_EINVAL, "too many labels (%d)", h->NL);
+    h->TR = h->cfg.feature_ring > 0 ? std::max(h->cfg.feature_ring, maxT) : maxT;
+    h->generic_hmax = hmax;
+
+    // ---- device weight image ----
+    HostBuf hb;
+    const size_t o_hann = hb.add(h->mel_blob.data(), 400);
+    const size_t o_start = hb.add(h->mel_blob.data() + 400, 32);          // int32 bit patterns
+    const size_t o_taps = hb.add(h->mel_blob.data() + 432, 512);
+    size_t o_conv[20], o_scale[20] = {}, o_shift[20] = {};
+    {
+        const float* q = h->emb_blob.data();
+        std::vector<float> pk;
+        for (int l = 0; l < 20; ++l) {
+            const LayerDef& L = kLayers[l];
+            const size_t nw = (size_t)L.kh * L.kw * L.cin * L.cout;
+            if (l == 0 || !h->mfma) o_conv[l] = hb.add(q, nw);
+            else { pack_mfma(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
+            q += nw;
+            if (l < 19) { o_scale[l] = hb.add(q, L.cout); q += L.cout; o_shift[l] = hb.add(q, L.cout); q += L.cout; }
+        }
+    }
+    // heads: natural arrays for every net (+ packed w2 for hidden==64), fast groups
+    struct NetOff { size_t w1, b1, ln1g, ln1b, w2, b2, ln2g, ln2b, w3, b3, w2pk; };
+    std::vector<NetOff> noff(h->nets.size());
+    for (size_t ni = 0; ni < h->nets.size(); ++ni) {
+        const NetHost& n = h->nets[ni];
+        const size_t in = (size_t)n.T * 96, H = n.hidden, O = n.n_out;
+        NetOff& o = noff[ni];
+        o.w1 = hb.add(n.w1, in * H); o.b1 = hb.add(n.b1, H);
+        o.ln1g = n.has_ln ? hb.add(n.ln1g, H) : 0; o.ln1b = n.has_ln ? hb.add(n.ln1b, H) : 0;
+        o.w2 = hb.add(n.w2, H * H); o.b2 = hb.add(n.b2, H);
+        o.ln2g = n.has_ln ? hb.add(n.ln2g, H) : 0; o.ln2b = n.has_ln ? hb.add(n.ln2b, H) : 0;
+        o.w3 = hb.add(n.w3, H * O); o.b3 = hb.add(n.b3, O);
+        o.w2pk = 0;
+        if (n.hidden == 64) { std::vector<float> pk; pack_mfma(n.w2, 1, 64, 64, pk); o.w2pk = hb.add(pk); }
+    }
+    // grouping: heads whose nets are all (hidden 64, n_out 1, sigmoid) share a fast group per T (<= 8 nets each)
+    h->groups.clear(); h->generic_nets.clear();
+    struct GOff { size_t w1pk, b1cat; };
+    std::vector<GOff> goff;
+    for (size_t hi = 0; hi < h->heads.size(); ++hi) {
+        const auto [nb, ne] = h->head_nets[hi];
+        bool fast = h->mfma;
+        for (int ni = nb; ni < ne; ++ni) fast = fast && h->nets[ni].hidden == 64 && h->nets[ni].n_out == 1 && h->nets[ni].final_act == 0;
+        if (!fast) { for (int ni = nb; ni < ne; ++ni) h->generic_nets.push_back(ni); continue; }
+        FastGroup* g = nullptr;
+        for (auto& gg : h->groups) if (gg.T == h->nets[nb].T && gg.n_nets + (ne - nb) <= HD_MAXNETS) { g = &gg; break; }
+        if (!g) { h->groups.push_back(FastGroup{}); g = &h->groups.back(); g->T = h->nets[nb].T; g->n_nets = 0; }
+        for (int ni = nb; ni < ne; ++ni) { g->nets.push_back(ni); g->n_nets++; }
+    }
+    for (auto& g : h->groups) {
+        g.NH = 64 * g.n_nets;
+        const size_t K = (size_t)g.T * 96;
+        std::vector<float> wcat(K * g.NH), bcat(g.NH), pk;
+        for (int gi = 0; gi < g.n_nets; ++gi) {
+            const NetHost& n = h->nets[g.nets[gi]];
+            for (size_t k = 0; k < K; ++k) memcpy(&wcat[k * g.NH + 64 * gi], n.w1 + k * 64, 64 * sizeof(float));
+            memcpy(&bcat[64 * gi], n.b1, 64 * sizeof(float));
+        }
+        pack_mfma(wcat.data(), g.T, 96, g.NH, pk);
+        goff.push_back({hb.add(pk), hb.add(bcat)});
+    }
+    HIPCHK(hipMalloc(&h->d_w, hb.data.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->d_hann = h->d_w + o_hann; h->d_mstart = reinterpret_cast<const int*>(h->d_w + o_start); h->d_taps = h->d_w + o_taps;
+    for (int l = 0; l < 20; ++l) {
+        h->d_conv[l] = h->d_w + o_conv[l];
+        h->d_scale[l] = l < 19 ? h->d_w + o_scale[l] : nullptr;
+        h->d_shift[l] = l < 19 ? h->d_w + o_shift[l] : nullptr;
+    }
+    auto make_desc = [&](int ni, int hid_off) {
+        const NetHost& n = h->nets[ni];
+        const NetOff& o = noff[ni];
+        NetDesc d{};
+        d.hidden = n.hidden; d.n_out = n.n_out; d.has_ln = n.has_ln; d.final_act = n.final_act; d.T = n.T;
+        d.head = n.head; d.role = n.role; d.out_col = n.out_col; d.hid_off = hid_off;
+        d.w1 = h->d_w + o.w1; d.b1 = h->d_w + o.b1;
+        d.ln1g = n.has_ln ? h->d_w + o.ln1g : nullptr; d.ln1b = n.has_ln ? h->d_w + o.ln1b : nullptr;
+        d.w2 = h->d_w + o.w2; d.b2 = h->d_w + o.b2;
+        d.ln2g = n.has_ln ? h->d_w + o.ln2g : nullptr; d.ln2b = n.has_ln ? h->d_w + o.ln2b : nullptr;
+        d.w3 = h->d_w + o.w3; d.b3 = h->d_w + o.b3;
+        d.w2pk = n.hidden == 64 ? h->d_w + o.w2pk : nullptr;
+        return d;
+    };
+    if (!h->nets.empty()) {
+        std::vector<NetDesc> all;
+        for (size_t ni = 0; ni < h->nets.size(); ++ni) all.push_back(make_desc((int)ni, 0));
+        HIPCHK(hipMalloc(&h->d_allnets, all.size() * sizeof(NetDesc)));
+        HIPCHK(hipMemcpy(h->d_allnets, all.data(), all.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
+    }
+    for (size_t gi = 0; gi < h->groups.size(); ++gi) {
+        FastGroup& g = h->groups[gi];
+        std::vector<NetDesc> ds;
+        for (int i = 0; i < g.n_nets; ++i) ds.push_back(make_desc(g.nets[i], 64 * i));
+        HIPCHK(hipMalloc(&g.d_nets, ds.size() * sizeof(NetDesc)));
+        HIPCHK(hipMemcpy(g.d_nets, ds.data(), ds.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
+        g.d_w1pk = h->d_w + goff[gi].w1pk; g.d_b1cat = h->d_w + goff[gi].b1cat;
+        if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
+    }
+
+    // ---- state ----
+    const size_t SP = h->Spad;
+    for (int a = 0; a < N_STATE; ++a) {
+        if (int rc = dalloc(&h->d_state[a], SP * kStateLen[a])) return rc;
+        if (int rc = dalloc(&h->d_tmpl[a], (size_t)kStateLen[a])) return rc;
+    }
+    if (int rc = dalloc(&h->d_xA, SP * 1536)) return rc;
+    if (int rc = dalloc(&h->d_xB, SP * 1536)) return rc;
+    if (int rc = dalloc(&h->d_xC, SP * 576)) return rc;
+    if (int rc = dalloc(&h->d_xD, SP * 384)) return rc;
+    if (int rc = dalloc(&h->d_mel, SP * 8 * h->kmax * 32)) return rc;
+    if (int rc = dalloc(&h->d_feat, SP * h->TR * 96)) return rc;
+    if (int rc = dalloc(&h->d_emb, SP * 96)) return rc;
+    if (int rc = dalloc(&h->d_raw, SP * std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(&h->d_scores, SP * std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(&h->d_ring, SP * std::max(h->NL, 1) * OWW_SCORE_RING)) return rc;
+    if (int rc = dalloc(&h->d_featinit, (size_t)h->TR * 96)) return rc;
+    if (int rc = dalloc(&h->d_nfeat, SP)) return rc;
+    if (int rc = dalloc(&h->d_npred, SP)) return rc;
+    if (int rc = dalloc(&h->d_tail, SP * 480)) return rc;
+    if (int rc = dalloc(&h->d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax)) return rc;
+    if (int rc = dalloc(&h->d_patience, (size_t)std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(&h->d_threshold, (size_t)std::max(h->NL, 1))) return rc;
+    {
+        std::vector<float> nanv(std::max(h->NL, 1), NAN);
+        HIPCHK(hipMemcpy(h->d_threshold, nanv.data(), nanv.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (h->cfg.debug_layers) if (int rc = dalloc(&h->d_dbg, SP * DBG_FLOATS)) return rc;
+    if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
+
+    if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stageA_kernel<false>, CfgA::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgB, true, false>, CfgB::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgB, false, false>, CfgB::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgC, true, false>, CfgC::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgC, false, false>, CfgC::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgD, true, false>, CfgD::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgD, false, false>, CfgD::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgE, true, true>, CfgE::LDS_BYTES)) return rc;
+    if (int rc = set_lds(stage_kernel<CfgE, false, true>, CfgE::LDS_BYTES)) return rc;
+
+    // ---- reset state = what an all-ones mel history leaves behind (utils.py:165 melspectrogram_buffer =
+    //      ones((76,32))): run the incremental CNN on ones rows until the zero start is flushed out ----
+    {
+        const int warm = std::min<int>(32, (int)SP);
+        hipLaunchKernelGGL(fill_kernel, dim3((warm * 256 + 255) / 256), dim3(256), 0, h->stream, h->d_mel, (size_t)warm * 256, 1.0f);
+        float* saved_dbg = h->d_dbg; h->d_dbg = nullptr;
+        for (int it = 0; it < 12; ++it)
+            if (int rc = run_cnn(h, warm, 256, 0)) return rc;
+        h->d_dbg = saved_dbg;
+        for (int a = 0; a < N_STATE; ++a)
+            HIPCHK(hipMemcpyAsync(h->d_tmpl[a], h->d_state[a], kStateLen[a] * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_mel, 0, SP * 8 * h->kmax * 32 * sizeof(float), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_emb, 0, SP * 96 * sizeof(float), h->stream));
+        if (int rc = do_reset(h, nullptr, (int)SP, nullptr)) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->committed = true;
+    return OWW_OK;
+}
+
+int oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* init_features) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_reset: handle not committed");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const float* d_init = nullptr;
+    if (init_features) {
+        HIPCHK(hipMemcpyAsync(h->d_featinit, init_features, (size_t)h->TR * 96 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        d_init = h->d_featinit;
+    }
+    if (!stream_ids) {
+        if (int rc = do_reset(h, nullptr, h->Spad, d_init)) return rc;
+    } else {
+        if (n < 1) return OWW_OK;
+        for (int i = 0; i < n; ++i)
+            if (stream_ids[i] < 0 || stream_ids[i] >= h->S) return fail(OWW_EINVAL, "oww_reset: stream id %d out of range", stream_ids[i]);
+        if (n > h->ids_cap) {
+            if (h->d_ids) (void)hipFree(h->d_ids);
+            h->d_ids = nullptr; h->ids_cap = 0;
+            HIPCHK(hipMalloc(&h->d_ids, (size_t)n * sizeof(int)));
+            h->ids_cap = n;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_ids, stream_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (int rc = do_reset(h, h->d_ids, n, d_init)) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));     // host buffers may be reused by the caller
+    return OWW_OK;
+}
+
+int oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold, int32_t debounce_frames) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_set_postproc: handle not committed");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::vector<int> pat(std::max(h->NL, 1), 0);
+    std::vector<float> thr(std::max(h->NL, 1), NAN);
+    if (patience) for (int i = 0; i < h->NL; ++i) pat[i] = patience[i];
+    if (threshold) for (int i = 0; i < h->NL; ++i) thr[i] = threshold[i];
+    HIPCHK(hipMemcpyAsync(h->d_patience, pat.data(), pat.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_threshold, thr.data(), thr.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->debounce_frames = debounce_frames;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // baked-in scalar changed
+    return OWW_OK;
+}
+
+int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks, float* scores, int scores_on_device) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step: handle not committed");
+    if (!pcm) return fail(OWW_EINVAL, "oww_step: pcm is null");
+    if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_step: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t n_pcm = (size_t)h->S * OWW_CHUNK * n_chunks;
+    const bool graphable = h->want_graph && n_chunks == 1 && !h->timing;
+    const int16_t* d_pcm = pcm;
+    if (!pcm_on_device || graphable) {
+        HIPCHK(hipMemcpyAsync(h->d_pcm, pcm, n_pcm * sizeof(int16_t), pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        d_pcm = h->d_pcm;
+    }
+    if (graphable) {
+        if (!h->graph_exec) {
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = launch_step(h, h->d_pcm, 1);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(h->stream, &g);
+            if (rc) return rc;
+            if (e != hipSuccess) return fail(OWW_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            if (h->graph) (void)hipGraphDestroy(h->graph);
+            h->graph = g;
+            HIPCHK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+        }
+        HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+    } else {
+        if (int rc = launch_step(h, d_pcm, n_chunks)) return rc;
+    }
+    if (scores) {
+        const size_t nb = (size_t)h->S * h->NL * sizeof(float);
+        if (nb) HIPCHK(hipMemcpyAsync(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        if (!scores_on_device) HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return OWW_OK;
+}
+
+int oww_sync(oww_ctx* h) {
+    if (!h) return fail(OWW_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OWW_OK;
+}
+
+const float* oww_scores_dev(const oww_ctx* h) { return h ? h->d_scores : nullptr; }
+
+int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_mel: handle not committed");
+    if (!pcm || !out_db || B < 1 || n < 512) return fail(OWW_EINVAL, "oww_mel: bad argument (B=%d n=%d)", B, n);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int F = (n - 512) / 160 + 1;
+    int16_t* d_in = nullptr; float* d_out = nullptr; float* d_max = nullptr;
+    HIPCHK(hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)));
+    HIPCHK(hipMalloc(&d_out, (size_t)B * F * 32 * sizeof(float)));
+    HIPCHK(hipMalloc(&d_max, (size_t)B * sizeof(float)));
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: H2D failed"); break; }
+        if ((rc = launch_mel(h, d_in, B, n, F, 0, d_out, d_max))) break;
+        std::vector<float> mx(B);
+        if (hipMemcpyAsync(mx.data(), d_max, B * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
+        float gmax = -INFINITY;                       // one clamp floor for the whole call (ipynb cell 15: log_spec.max())
+        for (float v : mx) gmax = std::max(gmax, v);
+        const size_t tot = (size_t)B * F * 32;
+        hipLaunchKernelGGL(clamp_db_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, d_out, tot, gmax - 80.0f);
+        if (hipMemcpyAsync(out_db, d_out, tot * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
+    } while (0);
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_max);
+    return rc;
+}
+
+int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float* out) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_embed: handle not committed");
+    if (!mel_rows || !out || B < 1 || B > h->Spad || rows < 76 || (rows - 76) % 8) return fail(OWW_EINVAL, "oww_embed: bad argument (B=%d rows=%d, need B<=%d)", B, rows, h->Spad);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int n_out = (rows - 76) / 8 + 1;
+    const int n_steps = (rows + 4) / 8;                 // 4 lead-in rows + rows, 8 per step
+    std::vector<float> slab((size_t)B * 256), emb((size_t)B * 96);
+    for (int it = 0; it < n_steps; ++it) {
+        for (int b = 0; b < B; ++b)
+            for (int r = 0; r < 8; ++r) {
+                const int src = it * 8 + r - 4;
+                float* d = &slab[((size_t)b * 8 + r) * 32];
+                if (src < 0) memset(d, 0, 32 * sizeof(float));
+                else memcpy(d, mel_rows + ((size_t)b * rows + src) * 32, 32 * sizeof(float));
+            }
+        HIPCHK(hipMemcpyAsync(h->d_mel, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (int rc = run_cnn(h, B, 256, 0)) return rc;
+        hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+        if (it >= 9) {
+            HIPCHK(hipMemcpyAsync(emb.data(), h->d_emb, emb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int b = 0; b < B; ++b) memcpy(out + ((size_t)b * n_out + (it - 9)) * 96, &emb[(size_t)b * 96], 96 * sizeof(float));
+        } else {
+            HIPCHK(hipStreamSynchronize(h->stream));  // slab is reused next iteration
+        }
+    }
+    return OWW_OK;
+}
+
+int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_head: handle not committed");
+    if (head < 0 || head >= (int)h->heads.size() || !features || !out || B < 1) return fail(OWW_EINVAL, "oww_head: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const HeadHost& hh = h->heads[head];
+    const size_t nf = (size_t)B * hh.T * 96;
+    float* d_f = nullptr; float* d_raw = nullptr;
+    HIPCHK(hipMalloc(&d_f, nf * sizeof(float)));
+    HIPCHK(hipMalloc(&d_raw, (size_t)B * h->NL * sizeof(float)));
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(d_f, features, nf * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: H2D failed"); break; }
+        if (hipMemsetAsync(d_raw, 0, (size_t)B * h->NL * sizeof(float), h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: memset failed"); break; }
+        if ((rc = run_heads(h, B, false, d_f, head, d_raw, 0))) break;
+        std::vector<float> raw((size_t)B * h->NL);
+        if (hipMemcpyAsync(raw.data(), d_raw, raw.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: D2H failed"); break; }
+        for (int b = 0; b < B; ++b)
+            for (int o = 0; o < hh.n_out; ++o) out[(size_t)b * hh.n_out + o] = raw[(size_t)b * h->NL + hh.out_col + o];
+    } while (0);
+    (void)hipFree(d_f); (void)hipFree(d_raw);
+    return rc;
+}
+
+int oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_features: handle not committed");
+    if (sid < 0 || sid >= h->S || T < 1 || T > h->TR || !out) return fail(OWW_EINVAL, "oww_get_features: bad argument (sid=%d T=%d ring=%d)", sid, T, h->TR);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::vector<float> ring((size_t)h->TR * 96);
+    uint32_t cnt = 0;
+    HIPCHK(hipMemcpyAsync(ring.data(), h->d_feat + (size_t)sid * h->TR * 96, ring.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&cnt, h->d_nfeat + sid, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // after the step's advance the newest row sits at slot (cnt-1) % TR; oldest-first order of the last T rows
+    for (int t = 0; t < T; ++t) {
+        const uint32_t slot = (cnt + (uint32_t)(2 * h->TR - T + t)) % (uint32_t)h->TR;
+        memcpy(out + (size_t)t * 96, &ring[(size_t)slot * 96], 96 * sizeof(float));
+    }
+    return OWW_OK;
+}
+
+int oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_mel: handle not committed");
+    if (sid < 0 || sid >= h->S || !out || n_rows < 1 || n_rows > 8 * h->kmax) return fail(OWW_EINVAL, "oww_get_mel: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(out, h->d_mel + (size_t)sid * n_rows * 32, (size_t)n_rows * 32 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OWW_OK;
+}
+
+int oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t cap) {
+    if (!h || !h->committed || !h->d_dbg) return fail(OWW_ESTATE, "oww_debug_read: needs a committed handle created with debug_layers=1");
+    if (sid < 0 || sid >= h->S || layer < 0 || layer > 19 || !out) return fail(OWW_EINVAL, "oww_debug_read: bad argument");
+    int off = 0;
+    for (int l = 0; l < layer; ++l) off += kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2];
+    const int n = kLayerOut[layer][0] * kLayerOut[layer][1] * kLayerOut[layer][2];
+    if (cap < n) return fail(OWW_EINVAL, "oww_debug_read: need room for %d floats", n);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(out, h->d_dbg + (size_t)sid * DBG_FLOATS + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return n;
+}
+
+int oww_enable_timing(oww_ctx* h, int on) {
+    if (!h) return fail(OWW_EINVAL, "null handle");
+    if (!on && h->timing) { if (int rc = flush_events(h)) return rc; }
+    h->timing = on != 0;
+    return OWW_OK;
+}
+
+int oww_kernel_times(oww_ctx* h, double ms[8], int64_t n[8]) {
+    if (!h || !ms || !n) return fail(OWW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc = flush_events(h)) return rc;
+    for (int i = 0; i < 8; ++i) { ms[i] = h->t_ms[i]; n[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
+    return OWW_OK;
+}
+
+int oww_use_graph(oww_ctx* h, int on) {
+    if (!h) return fail(OWW_EINVAL, "null handle");
+    h->want_graph = on != 0;
+    if (!on && h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    return OWW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,976 @@
+// owwhip_kernels.h -- gfx950 device code of the streaming wake-word path (included by owwhip.hip only).
+//
+// Dataflow per 80 ms step, all S streams at once:
+//   mel_kernel      int16 PCM (+480-sample tail) -> 8 new log-mel rows           (HBM bound, radix-8 FFT)
+//   stageA_kernel   mel rows -> conv0(3x3) conv1(1x3) conv2(3x1) pool2x2         (fp32 MFMA)
+//   stage_kernel<B> 4 convs + pool, three instances (48 / 72 / 96 channels)      (fp32 MFMA)
+//   stage_kernel<E> 4 convs + pool + conv19 -> 96-d embedding -> feature ring    (fp32 MFMA)
+//   heads64_kernel  16x96 features -> Linear/LN/ReLU x2 -> Linear -> sigmoid      (fp32 MFMA)
+//   postproc_kernel first-5 zeroing, patience / debounce, score ring
+//
+// The embedding CNN is evaluated INCREMENTALLY: every time-axis op is 'valid' and the product of the
+// time strides (2*1*2*1*2) equals the window hop (8 mel rows), so a step only computes the rows that are
+// new (8,8,8 | 4,4,4,4 | 4,4,4,4 | 2,2,2,2 | 2,2,2,2 | 1) and keeps the last two input rows of every 3x1
+// (and the 3x3) convolution as per-stream state (9,472 floats).  Reference semantics being replaced:
+// /root/reference/openwakeword/utils.py:409-452 (full 76-row window re-evaluated through
+// embedding_model.onnx every step) -- same outputs up to fp32 summation order.
+//
+// MFMA formulation of a conv layer (v_mfma_f32_16x16x4_f32, exact fp32):
+//   D[cout 16][position 16] += A[cout][k 4] * B[k][position],  k = (tap, cin)
+//   A = weights, pre-packed on the host so that one coalesced dword load per lane per k-step fills the
+//       operand register; a wave keeps the whole K x 16 slab of its cout tile in VGPRs (<= 72 regs)
+//   B = activations read from LDS with ds_read_b64 (two k-steps per read); channel stride C+4 floats
+//       makes the 32-lane read groups conflict free (stride == 4*odd mod 64 banks)
+//   D lane layout: lane&15 = position, (lane>>4)*4+reg = cout  -> one ds_write_b128 per lane epilogue
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace owk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float leaky_clamp(float x) {
+    // max(max(0.2x, x), -0.4)  (converting_google_speech_embedding_model.ipynb cell 18)
+    return fmaxf(fmaxf(0.2f * x, x), -0.4f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic conv layer, LDS -> LDS
+//   TIME=false : 1x3 conv along mel axis.  in  layout P[b][R][F+2][CIN+4]   (cols 0 and F+1 are zeros)
+//                                           out layout Q[b][R+2][F][COUT+4]  rows 2.. (rows 0,1 = history)
+//   TIME=true  : 3x1 conv along time axis.  in  layout Q[b][R+2][F][CIN+4]
+//                                           out layout P[b][R][F+2][COUT+4]  cols 1..F
+// ------------------------------------------------------------------------------------------------
+template <int R, int F, bool TIME, int CPI, int CPO>
+__device__ __forceinline__ void pos_addr(int p, int& rd, int& wr) {
+    const int f = p % F;
+    const int r = (p / F) % R;
+    const int b = p / (F * R);
+    if (TIME) {
+        rd = ((b * (R + 2) + r) * F + f) * CPI;
+        wr = ((b * R + r) * (F + 2) + f + 1) * CPO;
+    } else {
+        rd = ((b * R + r) * (F + 2) + f) * CPI;
+        wr = ((b * (R + 2) + r + 2) * F + f) * CPO;
+    }
+}
+
+template <int CIN, int COUT, int R, int F, int B, bool TIME, int NW, bool BN_ACT>
+__device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
+                                          const float* __restrict__ wpk, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, int tid) {
+    constexpr int CPI = CIN + 4, CPO = COUT + 4;
+    constexpr int NCT = (COUT + 15) / 16;
+    constexpr int PSPLIT = NW / NCT;
+    static_assert(PSPLIT >= 1, "need at least one wave per cout tile");
+    static_assert(CIN % 8 == 0, "k-blocks of 8 channels");
+    constexpr int NP = B * R * F;
+    constexpr int NPT = (NP + 15) / 16;
+    constexpr int KS = 3 * CIN / 4;
+    constexpr int TAPSTRIDE = TIME ? F * CPI : CPI;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave >= NCT * PSPLIT) return;
+    const int ct = wave % NCT, part = wave / NCT;
+    const int pl = lane & 15, j = lane >> 4;
+
+    float wreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[s] = wpk[(ct * KS + s) * 64 + lane];
+
+    const int c0 = ct * 16 + j * 4;
+    const bool cvalid = c0 < COUT;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (BN_ACT && cvalid) {
+        sc = *reinterpret_cast<const f32x4*>(scale + c0);
+        sh = *reinterpret_cast<const f32x4*>(shift + c0);
+    }
+
+    for (int t0 = part; t0 < NPT; t0 += 2 * PSPLIT) {
+        const int t1 = t0 + PSPLIT;
+        const int p0 = t0 * 16 + pl, p1 = t1 * 16 + pl;
+        const bool v0ok = p0 < NP, v1ok = (t1 < NPT) && (p1 < NP);
+        int rd0, wr0, rd1, wr1;
+        pos_addr<R, F, TIME, CPI, CPO>(v0ok ? p0 : NP - 1, rd0, wr0);
+        pos_addr<R, F, TIME, CPI, CPO>(v1ok ? p1 : NP - 1, rd1, wr1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+            for (int cb = 0; cb < CIN; cb += 8) {
+                const float2 x0 = *reinterpret_cast<const float2*>(in + rd0 + tap * TAPSTRIDE + cb + 2 * j);
+                const float2 x1 = *reinterpret_cast<const float2*>(in + rd1 + tap * TAPSTRIDE + cb + 2 * j);
+                const int s = (tap * CIN + cb) / 4;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], x0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], x1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], x0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], x1.y, acc1, 0, 0, 0);
+            }
+        }
+        if (cvalid) {
+            if (BN_ACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0[e] = leaky_clamp(acc0[e] * sc[e] + sh[e]);
+                    acc1[e] = leaky_clamp(acc1[e] * sc[e] + sh[e]);
+                }
+            }
+            if (v0ok) *reinterpret_cast<f32x4*>(out + wr0 + c0) = acc0;
+            if (v1ok) *reinterpret_cast<f32x4*>(out + wr1 + c0) = acc1;
+        }
+    }
+}
+
+// plain-VALU version of the same layer (same LDS layouts; weights in natural [tap][cin][cout] order)
+template <int CIN, int COUT, int R, int F, int B, bool TIME, int NW, bool BN_ACT>
+__device__ __forceinline__ void conv_valu(const float* __restrict__ in, float* __restrict__ out,
+                                          const float* __restrict__ wraw, const float* __restrict__ scale,
+                                          const float* __restrict__ shift, int tid) {
+    constexpr int CPI = CIN + 4, CPO = COUT + 4;
+    constexpr int NP = B * R * F;
+    constexpr int TAPSTRIDE = TIME ? F * CPI : CPI;
+    for (int idx = tid; idx < NP * COUT; idx += NW * 64) {
+        const int p = idx / COUT, c = idx - p * COUT;
+        int rd, wr;
+        pos_addr<R, F, TIME, CPI, CPO>(p, rd, wr);
+        float acc = 0.f;
+        for (int tap = 0; tap < 3; ++tap)
+            for (int ci = 0; ci < CIN; ++ci)
+                acc = fmaf(in[rd + tap * TAPSTRIDE + ci], wraw[(tap * CIN + ci) * COUT + c], acc);
+        out[wr + c] = BN_ACT ? leaky_clamp(acc * scale[c] + shift[c]) : acc;
+    }
+}
+
+template <bool MFMA, int CIN, int COUT, int R, int F, int B, bool TIME, int NW, bool BN_ACT>
+__device__ __forceinline__ void conv_layer(const float* in, float* out, const float* w, const float* scale,
+                                           const float* shift, int tid) {
+    if (MFMA) conv_mfma<CIN, COUT, R, F, B, TIME, NW, BN_ACT>(in, out, w, scale, shift, tid);
+    else      conv_valu<CIN, COUT, R, F, B, TIME, NW, BN_ACT>(in, out, w, scale, shift, tid);
+}
+
+// dense global [B][ROWS][F][C] <-> LDS helpers -----------------------------------------------------
+// copy global dense rows into an LDS buffer laid out [b][BROWS][FW][CP] at (row0 + row, f0 + f)
+template <int B, int ROWS, int F, int C, int BROWS, int FW, int CP, int NT>
+__device__ __forceinline__ void g2l(const float* __restrict__ g, float* __restrict__ l, int row0, int f0, int tid) {
+    constexpr int N4 = B * ROWS * F * C / 4;
+    for (int i = tid; i < N4; i += NT) {
+        const int e = i * 4;
+        const int c = e % C;
+        const int pos = e / C;
+        const int f = pos % F;
+        const int rb = pos / F;
+        const int row = rb % ROWS, b = rb / ROWS;
+        const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+        *reinterpret_cast<f32x4*>(l + ((b * BROWS + row0 + row) * FW + f0 + f) * CP + c) = v;
+    }
+}
+template <int B, int ROWS, int F, int C, int BROWS, int FW, int CP, int NT>
+__device__ __forceinline__ void l2g(const float* __restrict__ l, float* __restrict__ g, int row0, int f0, int tid) {
+    constexpr int N4 = B * ROWS * F * C / 4;
+    for (int i = tid; i < N4; i += NT) {
+        const int e = i * 4;
+        const int c = e % C;
+        const int pos = e / C;
+        const int f = pos % F;
+        const int rb = pos / F;
+        const int row = rb % ROWS, b = rb / ROWS;
+        reinterpret_cast<f32x4*>(g)[i] =
+            *reinterpret_cast<const f32x4*>(l + ((b * BROWS + row0 + row) * FW + f0 + f) * CP + c);
+    }
+}
+// debug copy: LDS [b][BROWS][FW][CP] rows row0.. -> per-stream dense blocks g[(s0+b)*stride + off + ...]
+template <int B, int ROWS, int F, int C, int BROWS, int FW, int CP, int NT>
+__device__ __forceinline__ void l2dbg(const float* __restrict__ l, float* __restrict__ dbg, size_t stride, int off,
+                                      int s0, int row0, int f0, int tid) {
+    constexpr int N = B * ROWS * F * C;
+    for (int i = tid; i < N; i += NT) {
+        const int c = i % C;
+        const int pos = i / C;
+        const int f = pos % F;
+        const int rb = pos / F;
+        const int row = rb % ROWS, b = rb / ROWS;
+        dbg[(size_t)(s0 + b) * stride + off + (row * F + f) * C + c] =
+            l[((b * BROWS + row0 + row) * FW + f0 + f) * CP + c];
+    }
+}
+// zero the two padding columns (f=0 and f=F+1) of a P buffer [b*R rows][F+2][CP] for channels < C
+template <int BR, int F, int C, int CP, int NT>
+__device__ __forceinline__ void zero_pads(float* __restrict__ P, int tid) {
+    for (int i = tid; i < BR * 2 * C; i += NT) {
+        const int c = i % C;
+        const int t = i / C;
+        const int side = t & 1, row = t >> 1;
+        P[(row * (F + 2) + (side ? F + 1 : 0)) * CP + c] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage B / C / D / E
+// ------------------------------------------------------------------------------------------------
+template <int CIN_, int C_, int R_, int F_, int PT_, int PF_, int B_, int NW_>
+struct StageCfg {
+    static constexpr int CIN = CIN_, C = C_, R = R_, F = F_, PT = PT_, PF = PF_, B = B_, NW = NW_;
+    static constexpr int CP = C + 4;
+    static constexpr int P_FLOATS = B * R * (F + 2) * CP;
+    static constexpr int Q_FLOATS = B * (R + 2) * F * CP;
+    static constexpr int LDS_BYTES = (P_FLOATS + Q_FLOATS) * 4;
+    static constexpr int NT = NW * 64;
+};
+using CfgB = StageCfg<24, 48, 4, 16, 1, 2, 2, 6>;
+using CfgC = StageCfg<48, 72, 4, 8, 2, 2, 2, 5>;
+using CfgD = StageCfg<72, 96, 2, 4, 1, 2, 4, 6>;
+using CfgE = StageCfg<96, 96, 2, 2, 2, 2, 8, 6>;
+
+struct StageParams {
+    const float* xin;      // [S][R][F][CIN]
+    float* xout;           // [S][R/PT][F/PF][C]           (unused by the last stage)
+    float* hist_b;         // [S][2][F][C]  input history of the 1st 3x1 conv
+    float* hist_d;         // [S][2][F][C]  input history of the 2nd 3x1 conv
+    const float* w[4];     // MFMA-packed or natural weights of the four convs
+    const float* scale[4];
+    const float* shift[4];
+    // last stage only
+    float* hist19;         // [S][2][96]
+    const float* w19;
+    float* feat;           // [S][TR][96] feature ring
+    float* emb;            // [S][96]     newest embedding (dense copy)
+    const uint32_t* nfeat; // [S] embeddings appended since reset
+    int TR;
+    // debug
+    float* dbg;            // [S][dbg_stride] or null
+    size_t dbg_stride;
+    int dbg_off[5];
+};
+
+template <class C, bool MFMA, bool LAST>
+__global__ __launch_bounds__(C::NT) void stage_kernel(StageParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CIN = C::CIN, CC = C::C, R = C::R, F = C::F, B = C::B, NT = C::NT, NW = C::NW;
+    constexpr int CPI = CIN + 4, CP = C::CP;
+    float* P = smem;
+    float* Q = smem + C::P_FLOATS;
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * B;
+
+    // phase 0: stage input (CIN layout) + history of conv b
+    zero_pads<B * R, F, CIN, CPI, NT>(P, tid);
+    g2l<B, R, F, CIN, R, F + 2, CPI, NT>(p.xin + (size_t)s0 * R * F * CIN, P, 0, 1, tid);
+    g2l<B, 2, F, CC, R + 2, F, CP, NT>(p.hist_b + (size_t)s0 * 2 * F * CC, Q, 0, 0, tid);
+    __syncthreads();
+    // conv a: 1x3 CIN -> C
+    conv_layer<MFMA, CIN, CC, R, F, B, false, NW, true>(P, Q, p.w[0], p.scale[0], p.shift[0], tid);
+    __syncthreads();
+    // new history of conv b = last two rows of its input; conv b: 3x1
+    l2g<B, 2, F, CC, R + 2, F, CP, NT>(Q, p.hist_b + (size_t)s0 * 2 * F * CC, R, 0, tid);
+    if (p.dbg) l2dbg<B, R, F, CC, R + 2, F, CP, NT>(Q, p.dbg, p.dbg_stride, p.dbg_off[0], s0, 2, 0, tid);
+    zero_pads<B * R, F, CC, CP, NT>(P, tid);
+    conv_layer<MFMA, CC, CC, R, F, B, true, NW, true>(Q, P, p.w[1], p.scale[1], p.shift[1], tid);
+    __syncthreads();
+    // conv c: 1x3
+    g2l<B, 2, F, CC, R + 2, F, CP, NT>(p.hist_d + (size_t)s0 * 2 * F * CC, Q, 0, 0, tid);
+    if (p.dbg) l2dbg<B, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[1], s0, 0, 1, tid);
+    conv_layer<MFMA, CC, CC, R, F, B, false, NW, true>(P, Q, p.w[2], p.scale[2], p.shift[2], tid);
+    __syncthreads();
+    // conv d: 3x1
+    l2g<B, 2, F, CC, R + 2, F, CP, NT>(Q, p.hist_d + (size_t)s0 * 2 * F * CC, R, 0, tid);
+    if (p.dbg) l2dbg<B, R, F, CC, R + 2, F, CP, NT>(Q, p.dbg, p.dbg_stride, p.dbg_off[2], s0, 2, 0, tid);
+    conv_layer<MFMA, CC, CC, R, F, B, true, NW, true>(Q, P, p.w[3], p.scale[3], p.shift[3], tid);
+    __syncthreads();
+    if (p.dbg) l2dbg<B, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[3], s0, 0, 1, tid);
+
+    // max pool PT x PF
+    constexpr int RO = R / C::PT, FO = F / C::PF;
+    if (!LAST) {
+        float* xo = p.xout + (size_t)s0 * RO * FO * CC;
+        for (int i = tid; i < B * RO * FO * CC; i += NT) {
+            const int c = i % CC;
+            const int pos = i / CC;
+            const int fo = pos % FO;
+            const int t = pos / FO;
+            const int ro = t % RO, b = t / RO;
+            float m = -INFINITY;
+#pragma unroll
+            for (int dt = 0; dt < C::PT; ++dt)
+#pragma unroll
+                for (int df = 0; df < C::PF; ++df)
+                    m = fmaxf(m, P[((b * R + ro * C::PT + dt) * (F + 2) + fo * C::PF + df + 1) * CP + c]);
+            xo[i] = m;
+        }
+    } else {
+        // RO == FO == 1: pooled row feeds conv19 (3x1, 96->96, no BN/activation) over [hist19(2) ; pooled]
+        static_assert(!LAST || (RO == 1 && FO == 1), "last stage pools to one position");
+        // Q19 layout [b][3][1][CP] in Q (free: conv d finished reading it before the last barrier)
+        for (int i = tid; i < B * CC; i += NT) {
+            const int c = i % CC, b = i / CC;
+            float m = -INFINITY;
+#pragma unroll
+            for (int dt = 0; dt < C::PT; ++dt)
+#pragma unroll
+                for (int df = 0; df < C::PF; ++df)
+                    m = fmaxf(m, P[((b * R + dt) * (F + 2) + df + 1) * CP + c]);
+            Q[(b * 3 + 2) * CP + c] = m;
+        }
+        g2l<B, 2, 1, CC, 3, 1, CP, NT>(p.hist19 + (size_t)s0 * 2 * CC, Q, 0, 0, tid);
+        __syncthreads();
+        // P19 layout [b][1][3][CP] in P (pool finished reading P before the barrier above)
+        conv_layer<MFMA, CC, CC, 1, 1, B, true, NW, false>(Q, P, p.w19, nullptr, nullptr, tid);
+        l2g<B, 2, 1, CC, 3, 1, CP, NT>(Q, p.hist19 + (size_t)s0 * 2 * CC, 1, 0, tid);
+        __syncthreads();
+        for (int i = tid; i < B * CC; i += NT) {
+            const int c = i % CC, b = i / CC;
+            const float v = P[(b * 3 + 1) * CP + c];
+            const int s = s0 + b;
+            const uint32_t slot = p.nfeat[s] % (uint32_t)p.TR;
+            p.feat[((size_t)s * p.TR + slot) * CC + c] = v;
+            p.emb[(size_t)s * CC + c] = v;
+            if (p.dbg) p.dbg[(size_t)s * p.dbg_stride + p.dbg_off[4] + c] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage A: mel rows -> conv0 (3x3, 1->24, ReLU, BN, act) -> conv1 (1x3) -> conv2 (3x1) -> pool 2x2
+// one stream per workgroup, 8 waves
+// ------------------------------------------------------------------------------------------------
+struct StageAParams {
+    const float* mel;      // [S][mel_stride] transformed mel rows of this call; chunk rows start at mel_off
+    int mel_stride, mel_off;
+    float* hist_mel;       // [S][2][32]
+    float* hist2;          // [S][2][32][24]
+    const float* w0;       // [9][24]
+    const float* w1;       // packed / natural
+    const float* w2;
+    const float* scale[3];
+    const float* shift[3];
+    float* xout;           // [S][4][16][24]
+    float* dbg;
+    size_t dbg_stride;
+    int dbg_off[3];
+};
+struct CfgA {
+    static constexpr int NW = 8, NT = 512, R = 8, F = 32, C = 24, CP = 28;
+    static constexpr int M_FLOATS = 352;                       // [10][34] padded to a 16-byte multiple
+    static constexpr int P_FLOATS = R * (F + 2) * CP;          // 7616
+    static constexpr int Q_FLOATS = (R + 2) * F * CP;          // 8960
+    static constexpr int LDS_BYTES = (M_FLOATS + P_FLOATS + Q_FLOATS) * 4;
+};
+
+template <bool MFMA>
+__global__ __launch_bounds__(CfgA::NT) void stageA_kernel(StageAParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 8, F = 32, CC = 24, CP = 28, NT = CfgA::NT, NW = CfgA::NW;
+    float* M = smem;                       // [10][34]
+    float* P = smem + CfgA::M_FLOATS;      // [8][34][28]
+    float* Q = P + CfgA::P_FLOATS;         // [10][32][28]
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x;
+
+    // phase 0
+    for (int i = tid; i < 10 * 34; i += NT) {
+        const int row = i / 34, col = i % 34;
+        float v = 0.f;
+        if (col >= 1 && col <= 32) {
+            v = (row < 2) ? p.hist_mel[(size_t)s * 64 + row * 32 + col - 1]
+                          : p.mel[(size_t)s * p.mel_stride + p.mel_off + (row - 2) * 32 + col - 1];
+        }
+        M[i] = v;
+    }
+    zero_pads<R, F, CC, CP, NT>(P, tid);
+    g2l<1, 2, F, CC, R + 2, F, CP, NT>(p.hist2 + (size_t)s * 2 * F * CC, Q, 0, 0, tid);
+    __syncthreads();
+    // conv0: 3x3 valid in time, zero padded in mel; ReLU; BN; activation (plain VALU: K = 9)
+    {
+        const float* __restrict__ w0 = p.w0;
+        const float* __restrict__ sc = p.scale[0];
+        const float* __restrict__ sh = p.shift[0];
+        for (int idx = tid; idx < R * F * CC; idx += NT) {
+            const int c = idx % CC;
+            const int pos = idx / CC;
+            const int f = pos % F, r = pos / F;
+            float acc = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df)
+                    acc = fmaf(M[(r + dt) * 34 + f + df], w0[(dt * 3 + df) * CC + c], acc);
+            acc = fmaxf(acc, 0.f);
+            P[(r * (F + 2) + f + 1) * CP + c] = leaky_clamp(acc * sc[c] + sh[c]);
+        }
+        if (tid < 64) p.hist_mel[(size_t)s * 64 + tid] = M[(8 + tid / 32) * 34 + 1 + (tid % 32)];
+    }
+    __syncthreads();
+    if (p.dbg) l2dbg<1, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[0], s, 0, 1, tid);
+    conv_layer<MFMA, CC, CC, R, F, 1, false, NW, true>(P, Q, p.w1, p.scale[1], p.shift[1], tid);
+    __syncthreads();
+    l2g<1, 2, F, CC, R + 2, F, CP, NT>(Q, p.hist2 + (size_t)s * 2 * F * CC, R, 0, tid);
+    if (p.dbg) l2dbg<1, R, F, CC, R + 2, F, CP, NT>(Q, p.dbg, p.dbg_stride, p.dbg_off[1], s, 2, 0, tid);
+    conv_layer<MFMA, CC, CC, R, F, 1, true, NW, true>(Q, P, p.w2, p.scale[2], p.shift[2], tid);
+    __syncthreads();
+    if (p.dbg) l2dbg<1, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[2], s, 0, 1, tid);
+    float* xo = p.xout + (size_t)s * 4 * 16 * CC;
+    for (int i = tid; i < 4 * 16 * CC; i += NT) {
+        const int c = i % CC;
+        const int pos = i / CC;
+        const int fo = pos % 16, ro = pos / 16;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+                m = fmaxf(m, P[((ro * 2 + dt) * (F + 2) + fo * 2 + df + 1) * CP + c]);
+        xo[i] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mel front end: one workgroup (4 waves) per stream-step; wave w turns frames 2w and 2w+1 of an
+// 8-frame group into ONE 512-point complex FFT (z = frame_a + i*frame_b), radix-8 x 3 with two LDS
+// transposes, then splits the two real spectra, |.|^2 for bins 2..121, sparse mel (<=16 taps),
+// 10*log10, clamp at (max over the call) - 80 dB, x/10 + 2.
+// Replaces melspectrogram.onnx + utils.py:180-208,387-401 (SURVEY Appendix A is the recipe).
+// ------------------------------------------------------------------------------------------------
+struct MelParams {
+    const int16_t* pcm;     // [S][n_samples]
+    int n_samples;          // samples per stream in this call
+    int n_frames;           // frames to produce per stream
+    int streaming;          // 1: virtual buffer = tail(480) ++ pcm, first-call masking, tail update, x/10+2
+                            // 0: clip mode: frames straight from pcm, raw dB out, per-stream max to `smax`
+    int16_t* tail;          // [S][480]
+    const uint32_t* nfeat;  // [S]
+    float* out;             // [S][n_frames][32]
+    float* smax;            // [S] (clip mode)
+    const float* hann;      // [400]
+    const int* mel_start;   // [32]
+    const float* mel_taps;  // [32][16]
+    int S;
+};
+
+__device__ __forceinline__ void dft8(float* re, float* im) {
+    // forward 8-point DFT, natural order in and out
+    const float h = 0.70710678118654752440f;
+    float a0r = re[0] + re[4], a0i = im[0] + im[4], a1r = re[0] - re[4], a1i = im[0] - im[4];
+    float a2r = re[2] + re[6], a2i = im[2] + im[6], t3r = re[2] - re[6], t3i = im[2] - im[6];
+    float a3r = t3i, a3i = -t3r;                                   // * (-i)
+    float b0r = re[1] + re[5], b0i = im[1] + im[5], b1r = re[1] - re[5], b1i = im[1] - im[5];
+    float b2r = re[3] + re[7], b2i = im[3] + im[7], u3r = re[3] - re[7], u3i = im[3] - im[7];
+    float b3r = u3i, b3i = -u3r;                                   // * (-i)
+    float E0r = a0r + a2r, E0i = a0i + a2i, E2r = a0r - a2r, E2i = a0i - a2i;
+    float E1r = a1r + a3r, E1i = a1i + a3i, E3r = a1r - a3r, E3i = a1i - a3i;
+    float O0r = b0r + b2r, O0i = b0i + b2i, O2r = b0r - b2r, O2i = b0i - b2i;
+    float O1r = b1r + b3r, O1i = b1i + b3i, O3r = b1r - b3r, O3i = b1i - b3i;
+    // twiddles W8^k: 1, (1-i)/sqrt2, -i, (-1-i)/sqrt2
+    float T1r = h * (O1r + O1i), T1i = h * (O1i - O1r);
+    float T2r = O2i, T2i = -O2r;
+    float T3r = h * (O3i - O3r), T3i = -h * (O3r + O3i);
+    re[0] = E0r + O0r; im[0] = E0i + O0i; re[4] = E0r - O0r; im[4] = E0i - O0i;
+    re[1] = E1r + T1r; im[1] = E1i + T1i; re[5] = E1r - T1r; im[5] = E1i - T1i;
+    re[2] = E2r + T2r; im[2] = E2i + T2i; re[6] = E2r - T2r; im[6] = E2i - T2i;
+    re[3] = E3r + T3r; im[3] = E3i + T3i; re[7] = E3r - T3r; im[7] = E3i - T3i;
+}
+
+constexpr int MEL_NT = 256;
+constexpr int MEL_XBUF = 1760 + 512;    // samples of one 8-frame group (+ slack so partial groups read zeros)
+constexpr int MEL_PBINS = 120;          // FFT bins 2..121 are the only ones the filterbank touches
+
+__global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
+    __shared__ float s_x[MEL_XBUF];
+    __shared__ float s_hann[400];
+    __shared__ float s_re[4][576];
+    __shared__ float s_im[4][576];
+    __shared__ float s_pow[8][MEL_PBINS + 8];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    for (int i = tid; i < 400; i += MEL_NT) s_hann[i] = p.hann[i];
+    // per-lane twiddles (registers, computed once per workgroup lifetime)
+    float tw1r[8], tw1i[8], tw2r[8], tw2i[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sincospif(-(float)(lane * k) / 256.f, &tw1i[k], &tw1r[k]);          // exp(-2 pi i lane k / 512)
+        sincospif(-(float)((lane & 7) * k) / 32.f, &tw2i[k], &tw2r[k]);     // exp(-2 pi i m0 k / 64)
+    }
+    // mel filter of this thread's output bin
+    const int mbin = tid & 31, fr = tid >> 5;
+    const int mstart = p.mel_start[mbin] - 2;
+    float taps[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) taps[t] = p.mel_taps[mbin * 16 + t];
+    const int n_groups = (p.n_frames + 7) / 8;
+    const int hist = p.streaming ? 480 : 0;
+
+    for (int s = blockIdx.x; s < p.S; s += gridDim.x) {
+        const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
+        const bool first = p.streaming && (p.nfeat[s] == 0);
+        float vmax = -INFINITY;
+        float last_db = 0.f;
+        for (int g = 0; g < n_groups; ++g) {
+            __syncthreads();                     // previous group's readers of s_x / s_pow are done
+            // ---- load the group's samples: virtual index c0 + i, c = [tail(hist) ; pcm]
+            const int c0 = g * 1280;
+            for (int i = tid * 8; i < MEL_XBUF; i += MEL_NT * 8) {
+                const int c = c0 + i;
+                float v[8];
+                if (c + 8 <= hist) {
+                    const int4 raw = *reinterpret_cast<const int4*>(p.tail + (size_t)s * 480 + c);
+                    const int16_t* h = reinterpret_cast<const int16_t*>(&raw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+                } else if (c >= hist && c - hist + 8 <= p.n_samples &&
+                           ((reinterpret_cast<uintptr_t>(pcm + (c - hist)) & 15) == 0)) {
+                    const int4 raw = *reinterpret_cast<const int4*>(pcm + (c - hist));
+                    const int16_t* h = reinterpret_cast<const int16_t*>(&raw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int cc = c + e;
+                        float x = 0.f;
+                        if (cc < hist) x = (float)p.tail[(size_t)s * 480 + cc];
+                        else if (cc - hist < p.n_samples) x = (float)pcm[cc - hist];
+                        v[e] = x;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_x[i + e] = v[e];
+            }
+            __syncthreads();
+            // ---- one complex FFT per wave: frames fa = 2*wave, fb = fa + 1 of this group
+            float re[8], im[8];
+            {
+                const int oa = 160 * (2 * wave), ob = oa + 160;
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) {
+                    const int n = 64 * n2 + lane;
+                    const bool in = (n >= 56) && (n < 456);
+                    const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
+                    re[n2] = w * s_x[oa + n];
+                    im[n2] = w * s_x[ob + n];
+                }
+            }
+            dft8(re, im);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const float r = re[k] * tw1r[k] - im[k] * tw1i[k];
+                im[k] = re[k] * tw1i[k] + im[k] * tw1r[k];
+                re[k] = r;
+            }
+            float* xr = s_re[wave];
+            float* xi = s_im[wave];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { xr[k * 72 + lane] = re[k]; xi[k * 72 + lane] = im[k]; }
+            __syncthreads();
+            {
+                const int q = lane >> 3, m0 = lane & 7;
+#pragma unroll
+                for (int m1 = 0; m1 < 8; ++m1) { re[m1] = xr[q * 72 + m1 * 8 + m0]; im[m1] = xi[q * 72 + m1 * 8 + m0]; }
+            }
+            dft8(re, im);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const float r = re[k] * tw2r[k] - im[k] * tw2i[k];
+                im[k] = re[k] * tw2i[k] + im[k] * tw2r[k];
+                re[k] = r;
+            }
+            __syncthreads();
+            {
+                const int q = lane >> 3, m0 = lane & 7;
+#pragma unroll
+                for (int k1 = 0; k1 < 8; ++k1) { xr[(q * 8 + k1) * 9 + m0] = re[k1]; xi[(q * 8 + k1) * 9 + m0] = im[k1]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m0 = 0; m0 < 8; ++m0) { re[m0] = xr[lane * 9 + m0]; im[m0] = xi[lane * 9 + m0]; }
+            dft8(re, im);
+            __syncthreads();
+            {
+                // lane = k0*8 + k1 holds Z[k0 + 8*k1 + 64*k2], k2 = 0..7; only k<128 and k>=384 are needed
+                const int kb = (lane >> 3) + 8 * (lane & 7);
+                xr[kb] = re[0];        xi[kb] = im[0];
+                xr[kb + 64] = re[1];   xi[kb + 64] = im[1];
+                xr[kb + 384] = re[6];  xi[kb + 384] = im[6];
+                xr[kb + 448] = re[7];  xi[kb + 448] = im[7];
+            }
+            __syncthreads();
+            for (int i = lane; i < MEL_PBINS; i += 64) {
+                const int k = i + 2;
+                const float zr = xr[k], zi = xi[k], yr = xr[512 - k], yi = xi[512 - k];
+                const float ar = zr + yr, ai = zi - yi;        // 2*A[k]
+                const float br = zi + yi, bi = zr - yr;        // 2*|B[k]| components
+                s_pow[2 * wave][i] = 0.25f * (ar * ar + ai * ai);
+                s_pow[2 * wave + 1][i] = 0.25f * (br * br + bi * bi);
+            }
+            __syncthreads();
+            // ---- mel + log: thread (fr, mbin)
+            const int frame = g * 8 + fr;
+            if (frame < p.n_frames) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = fmaf(s_pow[fr][mstart + t], taps[t], acc);
+                float db = 10.0f * logf(fmaxf(acc, 1e-10f)) / 2.302585092994046f;
+                const bool masked = first && frame < 3;
+                if (!masked) vmax = fmaxf(vmax, db);
+                if (masked) db = INFINITY;                 // marker: becomes 1.0 below
+                last_db = db;
+                if (n_groups > 1 || !p.streaming) p.out[((size_t)s * p.n_frames + frame) * 32 + mbin] = db;
+            }
+        }
+        // ---- block max over the whole call
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        __syncthreads();
+        if (lane == 0) s_red[wave] = vmax;
+        __syncthreads();
+        vmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        if (p.streaming) {
+            const float floor_db = vmax - 80.0f;
+            for (int g = 0; g < n_groups; ++g) {
+                const int frame = g * 8 + fr;
+                if (frame >= p.n_frames) break;
+                float* o = p.out + ((size_t)s * p.n_frames + frame) * 32 + mbin;
+                const float db = (n_groups > 1) ? *o : last_db;
+                *o = (db == INFINITY) ? 1.0f : fmaxf(db, floor_db) / 10.0f + 2.0f;
+            }
+            // new 480-sample tail = last 480 samples of [tail ; pcm]
+            for (int i = tid; i < 480; i += MEL_NT) {
+                const int src = p.n_samples - 480 + i;
+                p.tail[(size_t)s * 480 + i] = (src >= 0) ? pcm[src] : p.tail[(size_t)s * 480 + p.n_samples + i];
+            }
+        } else if (tid == 0) {
+            p.smax[s] = vmax;
+        }
+    }
+}
+
+__global__ void clamp_db_kernel(float* x, size_t n, float floor_db) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], floor_db);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wake-word heads (model.py:299-302; architecture train.py:56-83)
+// ------------------------------------------------------------------------------------------------
+struct NetDesc {
+    int hidden, n_out, has_ln, final_act;   // final_act: 0 sigmoid, 1 relu+softmax
+    int T;
+    int head, role;                          // role 0 = primary net, 1 = gate verifier (hey_jarvis style)
+    int out_col;                             // first score column of the owning head
+    int hid_off;                             // column offset inside the group's hidden matrix (fast path)
+    const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // natural layouts
+    const float *w2pk;                       // MFMA-packed [hidden/16][hidden/4][64] (fast path)
+};
+
+struct HeadParams {
+    const float* feat;      // ring [S][TR][96]  or external [B][T][96] when ext != 0
+    int ext;
+    int TR;
+    const uint32_t* nfeat;
+    const NetDesc* nets;    // device array
+    int n_nets;
+    int T;                  // common T of the group (fast path)
+    int NH;                 // total hidden columns of the group (fast path)
+    const float* w1pk;      // [NH/16][T*24][64]   (fast path)
+    const float* b1cat;     // [NH]
+    float* raw;             // [S][NL]
+    int NL;
+    int S;
+    int accumulate_max;     // 1: raw = max(raw, new)  (multi-chunk calls, model.py:298)
+};
+
+__device__ __forceinline__ const float* feat_row(const HeadParams& p, int s, int T, int t) {
+    if (p.ext) return p.feat + ((size_t)s * T + t) * 96;
+    const uint32_t slot = (p.nfeat[s] + (uint32_t)(2 * p.TR - T + 1 + t)) % (uint32_t)p.TR;
+    return p.feat + ((size_t)s * p.TR + slot) * 96;
+}
+
+__device__ __forceinline__ void store_raw(const HeadParams& p, int s, int col, float v) {
+    float* o = p.raw + (size_t)s * p.NL + col;
+    *o = p.accumulate_max ? fmaxf(*o, v) : v;
+}
+
+// generic (any T / hidden / n_out / LN / softmax): one thread per (stream, head); slow, fully general
+__global__ void heads_generic_kernel(HeadParams p, int net_begin, int net_end, float* scratch /*[S][n_nets][2*HMAX]*/,
+                                     int HMAX) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.S) return;
+    for (int ni = net_begin; ni < net_end; ++ni) {
+        const NetDesc& n = p.nets[ni];
+        if (n.role != 0) continue;
+        float result[8];
+        float gate_score = 0.f;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                if (ni + 1 >= net_end) break;
+                if (p.nets[ni + 1].role != 1 || p.nets[ni + 1].head != n.head) break;
+            }
+            const NetDesc& m = p.nets[ni + pass];
+            float* h1 = scratch + ((size_t)s * p.n_nets + ni) * 2 * HMAX;
+            float* h2 = h1 + HMAX;
+            const int H = m.hidden, T = m.T;
+            for (int o = 0; o < H; ++o) h1[o] = m.b1[o];
+            for (int t = 0; t < T; ++t) {
+                const float* x = feat_row(p, s, T, t);
+                for (int c = 0; c < 96; ++c) {
+                    const float xv = x[c];
+                    const float* w = m.w1 + (size_t)(t * 96 + c) * H;
+                    for (int o = 0; o < H; ++o) h1[o] = fmaf(xv, w[o], h1[o]);
+                }
+            }
+            for (int layer = 0; layer < 2; ++layer) {
+                float* h = layer ? h2 : h1;
+                if (layer) {
+                    for (int o = 0; o < H; ++o) {
+                        float a = m.b2[o];
+                        for (int i = 0; i < H; ++i) a = fmaf(h1[i], m.w2[i * H + o], a);
+                        h2[o] = a;
+                    }
+                }
+                if (m.has_ln) {
+                    const float* g = layer ? m.ln2g : m.ln1g;
+                    const float* b = layer ? m.ln2b : m.ln1b;
+                    float mu = 0.f;
+                    for (int o = 0; o < H; ++o) mu += h[o];
+                    mu /= (float)H;
+                    float var = 0.f;
+                    for (int o = 0; o < H; ++o) { const float d = h[o] - mu; var = fmaf(d, d, var); }
+                    var /= (float)H;
+                    const float rs = 1.0f / sqrtf(var + 1e-5f);
+                    for (int o = 0; o < H; ++o) h[o] = (h[o] - mu) * rs * g[o] + b[o];
+                }
+                for (int o = 0; o < H; ++o) h[o] = fmaxf(h[o], 0.f);
+            }
+            float z[8];
+            for (int o = 0; o < m.n_out; ++o) {
+                float a = m.b3[o];
+                for (int i = 0; i < H; ++i) a = fmaf(h2[i], m.w3[i * m.n_out + o], a);
+                z[o] = a;
+            }
+            if (m.final_act == 1) {
+                float mx = -INFINITY, sum = 0.f;
+                for (int o = 0; o < m.n_out; ++o) { z[o] = fmaxf(z[o], 0.f); mx = fmaxf(mx, z[o]); }
+                for (int o = 0; o < m.n_out; ++o) { z[o] = expf(z[o] - mx); sum += z[o]; }
+                for (int o = 0; o < m.n_out; ++o) z[o] /= sum;
+            } else {
+                for (int o = 0; o < m.n_out; ++o) z[o] = 1.0f / (1.0f + expf(-z[o]));
+            }
+            if (pass == 0) { for (int o = 0; o < m.n_out; ++o) result[o] = z[o]; gate_score = z[0]; }
+            else if (gate_score > 0.5f) { for (int o = 0; o < m.n_out; ++o) result[o] = z[o]; }
+        }
+        for (int o = 0; o < n.n_out; ++o) store_raw(p, s, n.out_col + o, result[o]);
+    }
+}
+
+// fast path: every net of the group has hidden == 64, n_out == 1, sigmoid, the same T.
+constexpr int HD_SB = 32;          // streams per workgroup
+constexpr int HD_NW = 8;
+constexpr int HD_NT = HD_NW * 64;
+constexpr int HD_MAXNETS = 8;
+
+__global__ __launch_bounds__(HD_NT) void heads64_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NH = p.NH, HS = NH + 4;             // hidden row stride in LDS
+    float* X = smem;                               // [SB][100]
+    float* H1 = X + HD_SB * 100;                   // [SB][HS]
+    float* H2 = H1 + HD_SB * HS;                   // [SB][HS]
+    float* SC = H2 + HD_SB * HS;                   // [SB][MAXNETS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pl = lane & 15, j = lane >> 4;
+    const int s0 = blockIdx.x * HD_SB;
+    const int NCT = NH / 16;
+    const int T = p.T;
+    const int KST = T * 24;                        // k-steps of the first layer
+
+    // ---- layer 1: D[hidden][stream] over K = T*96, staged one ring row (96 k) at a time
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();
+        for (int i = tid; i < HD_SB * 24; i += HD_NT) {
+            const int b = i / 24, c4 = i % 24;
+            int s = s0 + b;
+            if (s >= p.S) s = p.S - 1;
+            *reinterpret_cast<f32x4*>(X + b * 100 + c4 * 4) = *reinterpret_cast<const f32x4*>(feat_row(p, s, T, t) + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ct = wave + a * HD_NW;
+            if (ct < NCT) {
+                const float* wp = p.w1pk + ((size_t)ct * KST + t * 24) * 64 + lane;
+#pragma unroll
+                for (int cb = 0; cb < 96; cb += 8) {
+                    const float2 x0 = *reinterpret_cast<const float2*>(X + pl * 100 + cb + 2 * j);
+                    const float2 x1 = *reinterpret_cast<const float2*>(X + (16 + pl) * 100 + cb + 2 * j);
+                    const float w0 = wp[(cb / 4) * 64], w1 = wp[(cb / 4 + 1) * 64];
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, x0.x, acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, x1.x, acc[a][1], 0, 0, 0);
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, x0.y, acc[a][0], 0, 0, 0);
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, x1.y, acc[a][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int ct = wave + a * HD_NW;
+        if (ct < NCT) {
+            const int c0 = ct * 16 + j * 4;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1cat + c0);
+            *reinterpret_cast<f32x4*>(H1 + pl * HS + c0) = acc[a][0] + bias;
+            *reinterpret_cast<f32x4*>(H1 + (16 + pl) * HS + c0) = acc[a][1] + bias;
+        }
+    }
+    __syncthreads();
+    // ---- LayerNorm + ReLU, one thread per (stream, net)
+    const int n_nets = p.n_nets;
+    for (int layer = 0; layer < 2; ++layer) {
+        float* H = layer ? H2 : H1;
+        if (tid < HD_SB * n_nets) {
+            const int b = tid % HD_SB, ni = tid / HD_SB;
+            const NetDesc& n = p.nets[ni];
+            float* h = H + b * HS + n.hid_off;
+            if (n.has_ln) {
+                const float* g = layer ? n.ln2g : n.ln1g;
+                const float* be = layer ? n.ln2b : n.ln1b;
+                float mu = 0.f;
+                for (int o = 0; o < 64; ++o) mu += h[o];
+                mu /= 64.f;
+                float var = 0.f;
+                for (int o = 0; o < 64; ++o) { const float d = h[o] - mu; var = fmaf(d, d, var); }
+                var /= 64.f;
+                const float rs = 1.0f / sqrtf(var + 1e-5f);
+                for (int o = 0; o < 64; ++o) h[o] = fmaxf((h[o] - mu) * rs * g[o] + be[o], 0.f);
+            } else {
+                for (int o = 0; o < 64; ++o) h[o] = fmaxf(h[o], 0.f);
+            }
+            if (layer == 1) {
+                float z = n.b3[0];
+                for (int i = 0; i < 64; ++i) z = fmaf(h[i], n.w3[i], z);
+                SC[b * HD_MAXNETS + ni] = 1.0f / (1.0f + expf(-z));
+            }
+        }
+        __syncthreads();
+        if (layer == 0) {
+            // ---- layer 2 (64x64 per net) on MFMA: combos (net, cout tile) spread over the waves
+            for (int combo = wave; combo < n_nets * 4; combo += HD_NW) {
+                const int ni = combo >> 2, ct = combo & 3;
+                const NetDesc& n = p.nets[ni];
+                const float* wp = n.w2pk + (size_t)ct * 16 * 64 + lane;
+                const float* hb = H1 + n.hid_off;
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int cb = 0; cb < 64; cb += 8) {
+                    const float2 x0 = *reinterpret_cast<const float2*>(hb + pl * HS + cb + 2 * j);
+                    const float2 x1 = *reinterpret_cast<const float2*>(hb + (16 + pl) * HS + cb + 2 * j);
+                    const float w0 = wp[(cb / 4) * 64], w1 = wp[(cb / 4 + 1) * 64];
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, x0.x, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, x1.x, a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, x0.y, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, x1.y, a1, 0, 0, 0);
+                }
+                const int c0 = ct * 16 + j * 4;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(n.b2 + c0);
+                *reinterpret_cast<f32x4*>(H2 + pl * HS + n.hid_off + c0) = a0 + bias;
+                *reinterpret_cast<f32x4*>(H2 + (16 + pl) * HS + n.hid_off + c0) = a1 + bias;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- gating + store
+    if (tid < HD_SB * n_nets) {
+        const int b = tid % HD_SB, ni = tid / HD_SB;
+        const NetDesc& n = p.nets[ni];
+        const int s = s0 + b;
+        if (n.role == 0 && s < p.S) {
+            float sc = SC[b * HD_MAXNETS + ni];
+            if (ni + 1 < n_nets && p.nets[ni + 1].role == 1 && p.nets[ni + 1].head == n.head && sc > 0.5f)
+                sc = SC[b * HD_MAXNETS + ni + 1];
+            store_raw(p, s, n.out_col, sc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// post-processing (model.py:330-363): one thread per stream
+// ------------------------------------------------------------------------------------------------
+struct PostParams {
+    const float* raw;        // [S][NL]
+    float* scores;           // [S][NL]
+    float* ring;             // [S][NL][30]
+    uint32_t* npred;         // [S]
+    const int* patience;     // [NL]
+    const float* threshold;  // [NL]  (NaN = no threshold for this label)
+    int debounce_frames;
+    int NL, S;
+};
+
+__global__ void postproc_kernel(PostParams p) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.S) return;
+    const uint32_t cnt = p.npred[s];
+    const int have = cnt < 30u ? (int)cnt : 30;
+    for (int l = 0; l < p.NL; ++l) {
+        float sc = p.raw[(size_t)s * p.NL + l];
+        float* ring = p.ring + ((size_t)s * p.NL + l) * 30;
+        if (cnt < 5u) sc = 0.0f;                                            // model.py:331-333
+        if (sc != 0.0f) {
+            const int pat = p.patience[l];
+            const float thr = p.threshold[l];
+            if (pat > 0) {                                                  // model.py:349-352
+                const int look = pat < have ? pat : have;
+                int n_ok = 0;
+                for (int i = 1; i <= look; ++i) n_ok += ring[(cnt - i) % 30u] >= thr ? 1 : 0;
+                if (n_ok < pat) sc = 0.0f;
+            } else if (p.debounce_frames > 0 && thr == thr) {               // model.py:353-359
+                const int look = p.debounce_frames < have ? p.debounce_frames : have;
+                int n_hit = 0;
+                for (int i = 1; i <= look; ++i) n_hit += ring[(cnt - i) % 30u] >= thr ? 1 : 0;
+                if (sc >= thr && n_hit > 0) sc = 0.0f;
+            }
+        }
+        ring[cnt % 30u] = sc;                                               // model.py:362-363
+        p.scores[(size_t)s * p.NL + l] = sc;
+    }
+    p.npred[s] = cnt + 1u;
+}
+
+__global__ void advance_kernel(uint32_t* nfeat, int S) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) nfeat[s] += 1u;
+}
+
+__global__ void fill_kernel(float* x, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+
+// reset: copy per-layer templates into the listed streams' state
+struct ResetParams {
+    const int* ids;          // device list or null (all)
+    int n;
+    int n_arrays;
+    float* dst[16];
+    const float* tmpl[16];
+    int len[16];             // floats per stream
+    int16_t* tail;
+    uint32_t* nfeat;
+    uint32_t* npred;
+    float* ring;  int ring_len;      // score ring floats per stream
+    float* feat;  int feat_len;      // feature ring floats per stream
+    const float* feat_init;          // [feat_len] or null (zeros)
+};
+
+__global__ void reset_kernel(ResetParams p) {
+    const int k = blockIdx.x;
+    const int s = p.ids ? p.ids[k] : k;
+    for (int a = 0; a < p.n_arrays; ++a)
+        for (int i = threadIdx.x; i < p.len[a]; i += blockDim.x) p.dst[a][(size_t)s * p.len[a] + i] = p.tmpl[a][i];
+    for (int i = threadIdx.x; i < 480; i += blockDim.x) p.tail[(size_t)s * 480 + i] = 0;
+    for (int i = threadIdx.x; i < p.ring_len; i += blockDim.x) p.ring[(size_t)s * p.ring_len + i] = 0.f;
+    for (int i = threadIdx.x; i < p.feat_len; i += blockDim.x)
+        p.feat[(size_t)s * p.feat_len + i] = p.feat_init ? p.feat_init[i] : 0.f;
+    if (threadIdx.x == 0) { p.nfeat[s] = 0u; p.npred[s] = 0u; }
+}
+
+}  // namespace owk

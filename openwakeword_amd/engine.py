@@ -1,0 +1,232 @@
+"""
+StreamEngine: S concurrent audio streams advanced one 80 ms frame per call on one MI355X.
+
+This is the batched form of the reference's per-object hot loop
+(`openwakeword.Model.predict`, /root/reference/openwakeword/model.py:232-386, which drives
+`utils.AudioFeatures.__call__`, utils.py:409-463): the reference keeps one Python object per stream and
+calls onnxruntime 2+H times per frame; here every stream's state lives in HBM and one `step()` runs the
+mel / embedding / head / post-processing kernels of libowwhip.so over all of them.
+
+Thin by design: blob packing + ctypes calls.  All arithmetic happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib, weights as W
+
+CHUNK = 1280
+EMB_DIM = 96
+_KIND = {"binary": 0, "gated": 1, "multiclass": 2}
+# rows x mel-width x channels that each CNN layer produces per 80 ms step (incremental form)
+LAYER_NEW_SHAPES = ([(8, 32, 24)] * 3 + [(4, 16, 48)] * 4 + [(4, 8, 72)] * 4 + [(2, 4, 96)] * 4 +
+                    [(2, 2, 96)] * 4 + [(1, 1, 96)])
+KERNEL_CLASSES = ["mel", "stageA", "stageB", "stageC", "stageD", "stageE", "heads", "postproc"]
+
+
+def pack_mel_blob() -> np.ndarray:
+    start, taps, lo, hi = W.mel_sparse_taps()
+    assert lo == 2 and hi == 121, "the mel kernel keeps FFT bins 2..121 only"
+    return np.concatenate([W.hann_window().view(np.uint8), start.astype(np.int32).view(np.uint8),
+                           taps.astype(np.float32).ravel().view(np.uint8)])
+
+
+def pack_embedding_blob(emb: dict) -> np.ndarray:
+    parts = []
+    for li, w in enumerate(emb["conv"]):
+        kh, kw, ci, co, _ = W.CNN_TOPOLOGY[li]
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        if w.shape != (kh, kw, ci, co):
+            raise ValueError(f"conv {li}: expected HWIO {(kh, kw, ci, co)}, got {w.shape}")
+        parts.append(w.ravel())
+        if li < len(emb["conv"]) - 1:
+            scale, shift = W.bn_scale_shift(emb["bn"][li])
+            parts += [scale, shift]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def pack_head_blob(head: dict) -> np.ndarray:
+    T, H, O = int(head["T"]), int(head["hidden"]), int(head["n_out"])
+    has_ln = head["net"].get("ln1") is not None
+    hdr = np.array([_KIND[head["kind"]], T, H, O, int(has_ln), 0, 0, 0], dtype=np.int32)
+    parts = [hdr.view(np.float32)]
+    nets = [head["net"]] + ([head["net2"]] if head["kind"] == "gated" else [])
+    for net in nets:
+        if net["w1"].shape != (T * EMB_DIM, H) or net["w2"].shape != (H, H) or net["w3"].shape != (H, O):
+            raise ValueError("head weight shapes do not match its header")
+        parts += [net["w1"].ravel(), net["b1"]]
+        if has_ln:
+            parts += list(net["ln1"])
+        parts += [net["w2"].ravel(), net["b2"]]
+        if has_ln:
+            parts += list(net["ln2"])
+        parts += [net["w3"].ravel(), net["b3"]]
+    return np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in parts])
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class StreamEngine:
+    """One GPU, S streams.  `heads` maps model name -> head dict (see weights.synthetic_head)."""
+
+    def __init__(self, n_streams: int, heads: Dict[str, dict], embedding: Optional[dict] = None,
+                 device: int = 0, max_chunks: int = 1, use_mfma: bool = True, debug_layers: bool = False,
+                 feature_ring: int = 0, hip_stream: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.n_streams = int(n_streams)
+        self.max_chunks = int(max_chunks)
+        self.head_names = list(heads.keys())
+        self.heads = heads
+        cfg = _lib.Config(int(device), self.n_streams, self.max_chunks, int(feature_ring), int(bool(use_mfma)),
+                          int(bool(debug_layers)), C.c_void_p(hip_stream) if hip_stream else None)
+        _lib.check(self._lib.oww_create(C.byref(cfg), C.byref(self._h)))
+        try:
+            blob = pack_mel_blob()
+            _lib.check(self._lib.oww_load_mel(self._h, _ptr(blob), blob.nbytes))
+            blob = pack_embedding_blob(embedding if embedding is not None else W.synthetic_embedding())
+            _lib.check(self._lib.oww_load_embedding(self._h, _ptr(blob), blob.nbytes))
+            self.head_cols = {}
+            col = 0
+            for name, head in heads.items():
+                blob = pack_head_blob(head)
+                _lib.check(self._lib.oww_add_head(self._h, _ptr(blob), blob.nbytes))
+                self.head_cols[name] = (col, col + int(head["n_out"]))
+                col += int(head["n_out"])
+            _lib.check(self._lib.oww_commit(self._h))
+        except Exception:
+            self.close()
+            raise
+        self.n_labels = self._lib.oww_n_labels(self._h)
+        self.feature_ring = max([16] + [int(h["T"]) for h in heads.values()] + [int(feature_ring)])
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.oww_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state
+    def reset(self, stream_ids: Optional[Sequence[int]] = None, init_features: Optional[np.ndarray] = None):
+        ids = None
+        n = 0
+        if stream_ids is not None:
+            ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+            n = ids.size
+        feat = None
+        if init_features is not None:
+            feat = np.ascontiguousarray(init_features, dtype=np.float32)
+            if feat.shape != (self.feature_ring, EMB_DIM):
+                raise ValueError(f"init_features must be [{self.feature_ring}, 96] (oldest row first), got {feat.shape}")
+        _lib.check(self._lib.oww_reset(self._h, _ptr(ids), n, _ptr(feat)))
+
+    def set_postproc(self, patience: Optional[Sequence[int]] = None, threshold: Optional[Sequence[float]] = None,
+                     debounce_frames: int = 0):
+        pat = None if patience is None else np.ascontiguousarray(patience, dtype=np.int32)
+        thr = None if threshold is None else np.ascontiguousarray(threshold, dtype=np.float32)
+        for a in (pat, thr):
+            if a is not None and a.size != self.n_labels:
+                raise ValueError(f"need one value per label ({self.n_labels})")
+        _lib.check(self._lib.oww_set_postproc(self._h, _ptr(pat), _ptr(thr), int(debounce_frames)))
+
+    # ---- hot loop
+    def step(self, pcm: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """pcm int16 [S, 1280*k] (host) -> scores fp32 [S, n_labels] (host, blocking)."""
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype != np.int16:
+            raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {pcm.dtype} data.")
+        if pcm.ndim != 2 or pcm.shape[0] != self.n_streams or pcm.shape[1] % CHUNK or pcm.shape[1] == 0:
+            raise ValueError(f"pcm must be [n_streams={self.n_streams}, 1280*k], got {pcm.shape}")
+        k = pcm.shape[1] // CHUNK
+        if out is None:
+            out = np.empty((self.n_streams, self.n_labels), dtype=np.float32)
+        _lib.check(self._lib.oww_step(self._h, _ptr(pcm), 0, k, _ptr(out), 0))
+        return out
+
+    def step_device(self, pcm_dev_ptr: int, n_chunks: int = 1, scores_dev_ptr: int = 0):
+        """Asynchronous step on device pointers (e.g. torch tensors' data_ptr())."""
+        _lib.check(self._lib.oww_step(self._h, C.c_void_p(pcm_dev_ptr), 1, int(n_chunks),
+                                      C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None, 1))
+
+    def sync(self):
+        _lib.check(self._lib.oww_sync(self._h))
+
+    @property
+    def scores_dev_ptr(self) -> int:
+        return int(self._lib.oww_scores_dev(self._h) or 0)
+
+    # ---- stage-level entry points (the reference's per-stage closures)
+    def mel(self, pcm: np.ndarray) -> np.ndarray:
+        """melspec_model_predict (utils.py:87): int16 [B, n] -> dB [B, F, 32]."""
+        pcm = np.ascontiguousarray(np.atleast_2d(pcm))
+        if pcm.dtype != np.int16:
+            raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {pcm.dtype} data.")
+        B, n = pcm.shape
+        out = np.empty((B, (n - 512) // 160 + 1, 32), dtype=np.float32)
+        _lib.check(self._lib.oww_mel(self._h, _ptr(pcm), B, n, _ptr(out)))
+        return out
+
+    def embed(self, mel_rows: np.ndarray) -> np.ndarray:
+        """embedding_model_predict over sliding windows (utils.py:229-236): [B, 76+8j, 32] -> [B, j+1, 96].
+        Clobbers the streaming state of streams [0, B)."""
+        m = np.ascontiguousarray(mel_rows, dtype=np.float32)
+        if m.ndim == 2:
+            m = m[None]
+        B, rows, _ = m.shape
+        out = np.empty((B, (rows - 76) // 8 + 1, EMB_DIM), dtype=np.float32)
+        _lib.check(self._lib.oww_embed(self._h, _ptr(m), B, rows, _ptr(out)))
+        return out
+
+    def head(self, head: Union[int, str], features: np.ndarray) -> np.ndarray:
+        """model_prediction_function[name] (model.py:137-138): [B, T, 96] -> [B, n_out]."""
+        idx = self.head_names.index(head) if isinstance(head, str) else int(head)
+        f = np.ascontiguousarray(features, dtype=np.float32)
+        if f.ndim == 2:
+            f = f[None]
+        hd = self.heads[self.head_names[idx]]
+        if f.shape[1:] != (hd["T"], EMB_DIM):
+            raise ValueError(f"features must be [B, {hd['T']}, 96], got {f.shape}")
+        out = np.empty((f.shape[0], hd["n_out"]), dtype=np.float32)
+        _lib.check(self._lib.oww_head(self._h, idx, _ptr(f), f.shape[0], _ptr(out)))
+        return out
+
+    # ---- introspection
+    def get_features(self, sid: int, T: int = 16) -> np.ndarray:
+        out = np.empty((T, EMB_DIM), dtype=np.float32)
+        _lib.check(self._lib.oww_get_features(self._h, int(sid), int(T), _ptr(out)))
+        return out
+
+    def get_mel(self, sid: int, n_rows: int = 8) -> np.ndarray:
+        out = np.empty((n_rows, 32), dtype=np.float32)
+        _lib.check(self._lib.oww_get_mel(self._h, int(sid), _ptr(out), int(n_rows)))
+        return out
+
+    def debug_layer(self, sid: int, layer: int) -> np.ndarray:
+        """New rows of CNN layer `layer` (0..19) for stream sid from the last chunk: [rows, F, C]."""
+        r, f, c = LAYER_NEW_SHAPES[layer]
+        out = np.empty(r * f * c, dtype=np.float32)
+        _lib.check(self._lib.oww_debug_read(self._h, int(sid), int(layer), _ptr(out), out.size))
+        return out.reshape(r, f, c)
+
+    def enable_timing(self, on: bool = True):
+        _lib.check(self._lib.oww_enable_timing(self._h, int(on)))
+
+    def kernel_times(self) -> Dict[str, Dict[str, float]]:
+        ms = (C.c_double * 8)()
+        n = (C.c_int64 * 8)()
+        _lib.check(self._lib.oww_kernel_times(self._h, ms, n))
+        return {KERNEL_CLASSES[i]: {"ms": ms[i], "launches": int(n[i])} for i in range(8)}
+
+    def use_graph(self, on: bool = True):
+        _lib.check(self._lib.oww_use_graph(self._h, int(on)))
