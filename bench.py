@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""
+bench.py -- throughput of the streaming wake-word hot path on N MI355X GPUs of one node.
+
+A "step" is one 80 ms frame (1280 new int16 samples) for EVERY stream of the job through
+mel -> incremental speech-embedding CNN -> wake-word heads -> post-processing, i.e. one
+`openwakeword.Model.predict` per stream (/root/reference/openwakeword/model.py:232-386).
+Metric (BASELINE.json): frames/sec = stream-steps completed per second, whole job.
+
+Workload: per GPU `--streams` concurrent streams (default 131072 = the per-GPU shard of BASELINE
+configs[3] "8 GPU, 1M streams, 3 heads"; configs[2] is --streams 65536, configs[1] is
+--streams 4096 --heads hey_jarvis), 3 heads (alexa, hey_mycroft, hey_jarvis), synthetic Gaussian PCM
+(RMS 3000) already resident in HBM, random-init weights of the reference's shapes (no model files exist
+offline).  Streams are sharded by contiguous range over ranks (weak scaling: fixed streams per GPU);
+the only collective is the per-step gather of fp32 scores [S, n_labels] to rank 0 over RCCL.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus 8 --steps 50 --warmup 10
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# executed algorithmic flops per stream-step of each CNN stage (2 x MACs of the incremental form)
+STAGE_FLOPS = {"stageA": 1_880_064, "stageB": 3_096_576, "stageC": 3_649_536, "stageD": 1_658_880, "stageE": 940_032}
+MEL_BYTES = 3584            # 2560 B new PCM + 1024 B mel rows per stream-step
+PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def head_flops(heads) -> int:
+    n = 0
+    for h in heads.values():
+        per = h["T"] * 96 * h["hidden"] + h["hidden"] * h["hidden"] + h["hidden"] * h["n_out"]
+        n += 2 * per * (2 if h["kind"] == "gated" else 1)
+    return n
+
+
+def cpu_baseline(emb, heads, budget_s: float = 15.0):
+    """The reference's per-frame algorithm (full 76-row window every frame) on the host cores:
+    torch-CPU port in oracle/ (checker code; never used by the product path)."""
+    import torch
+    from oracle.oww_oracle_torch import TorchCpuPort
+    from openwakeword_amd import weights as W
+    port = TorchCpuPort(emb, heads)
+    B = 64
+    pcm = W.synthetic_pcm(B, 1760, seed=7)
+    mel_ring = torch.full((B, 76, 32), 1.0)
+    feat = torch.zeros(B, max(h["T"] for h in heads.values()), 96)
+    port.frame(pcm, mel_ring, feat)                 # warm-up
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, mel_ring, feat = port.frame(pcm, mel_ring, feat)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 1), "unit": "frames/s", "cores": int(port.threads), "kind": "port",
+            "sample": f"{n} frames x {B} streams ({dt:.1f} s) of the reference algorithm (257-bin DFT mel, full 76x32 "
+                      f"window CNN, {len(heads)} heads) as a torch-CPU/oneDNN port (oracle/oww_oracle_torch.py); "
+                      "onnxruntime and the .onnx files are not available offline"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=131072, help="streams per GPU")
+    ap.add_argument("--heads", default="alexa,hey_mycroft,hey_jarvis")
+    ap.add_argument("--valu", action="store_true", help="plain-VALU kernels instead of MFMA (A/B only)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--pcm-pool", type=int, default=4, help="distinct PCM buffers cycled through")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from openwakeword_amd import weights as W
+    from openwakeword_amd.engine import StreamEngine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    S = args.streams
+    emb = W.synthetic_embedding(1234)
+    heads = {n: W.synthetic_head(n, 1234) for n in args.heads.split(",") if n}
+    # one side stream carries the engine's kernels AND the RCCL gather, so they are ordered without host syncs
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=not args.valu, hip_stream=stream.cuda_stream)
+    NL = eng.n_labels
+    eng.reset()
+    if args.graph:
+        eng.use_graph(True)
+
+    # synthetic PCM resident in HBM: Gaussian, RMS 3000, a different seed per rank (independent streams)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xA11CE + rank)
+    pool = [(torch.randn(S, 1280, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
+            for _ in range(max(1, args.pcm_pool))]
+    scores = torch.empty(S, NL, device=dev, dtype=torch.float32)
+    gathered = [torch.empty_like(scores) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def one_step(i):
+        eng.step_device(pool[i % len(pool)].data_ptr(), 1, scores.data_ptr())
+        if world > 1:
+            dist.gather(scores, gathered, dst=0)       # RCCL over xGMI: the path's only exchange
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    if not args.no_kernel_timing and not args.graph:
+        eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    ktimes = eng.kernel_times() if (not args.no_kernel_timing and not args.graph) else None
+    eng.enable_timing(False)
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item())
+
+    if rank == 0:
+        total_frames = S * world * args.steps
+        value = total_frames / dt_max
+        out = {
+            "metric": "frames/sec (80 ms frames through mel+embedding+3 wakeword heads), whole job",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), "
+                                   "80 ms frames, BASELINE configs[3] per-GPU shard" if S == 131072 else
+                                   f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
+                       "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
+                       "collective": "RCCL gather of scores per step" if world > 1 else "none",
+                       "kernels": "valu" if args.valu else "mfma", "graph": bool(args.graph), "weights": "synthetic seed 1234"},
+            "realtime_streams": round(value / 12.5, 1),
+            "frames_per_sec_per_gpu": round(value / world, 1),
+            "scores_valid": ok,
+        }
+        if ktimes:
+            per = {k: (v["ms"] / max(v["launches"], 1)) for k, v in ktimes.items()}
+            out["kernel_ms"] = {k: round(v, 4) for k, v in per.items()}
+            dom = max(STAGE_FLOPS, key=lambda k: per[k])
+            tf = STAGE_FLOPS[dom] * S / (per[dom] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                               "flops_per_launch": STAGE_FLOPS[dom] * S, "avg_ms": round(per[dom], 4)}
+            cnn_ms = sum(per[k] for k in STAGE_FLOPS)
+            cnn_tf = sum(STAGE_FLOPS.values()) * S / (cnn_ms * 1e-3) / 1e12
+            out["roofline_all"] = {
+                "cnn_all_stages": {"achieved": round(cnn_tf, 2), "unit": "TFLOP/s", "frac": round(cnn_tf / PEAK_FP32_TFLOPS, 4)},
+                **{k: {"achieved": round(STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                       "frac": round(STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)} for k in STAGE_FLOPS},
+                "heads": {"achieved": round(head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                          "frac": round(head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)},
+                "mel": {"bound": "hbm", "achieved": round(MEL_BYTES * S / (per["mel"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(MEL_BYTES * S / (per["mel"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+            }
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(emb, heads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
