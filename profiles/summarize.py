@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV: per-kernel average duration of the FULL-GRID launches only
+(oww_commit also launches each CNN kernel 12 times on a 32-stream grid to derive the reset state; those
+tiny launches are excluded so the averages are comparable with bench.py's hipEvent numbers).
+usage: summarize.py <kernel_trace.csv> [<counter_collection.csv> ...]"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "").replace("owk::", "")
+    for tag, s in (("StageCfg<24, 48", "stageB"), ("StageCfg<48, 72", "stageC"), ("StageCfg<72, 96", "stageD"), ("StageCfg<96, 96", "stageE")):
+        if tag in name:
+            return s + ("(valu)" if ", false, " in name.split(">")[1] else "")
+    return name.split("(")[0][:60]
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    by = defaultdict(list)
+    for r in rows:
+        by[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]), r))
+    print(f"{'kernel':32s} {'launches':>8s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'grid':>10s} {'wg':>5s} {'vgpr':>5s} {'lds_B':>7s}  (full-grid launches only)")
+    tot = 0.0
+    out = []
+    for k, v in by.items():
+        gmax = max(g for _, g, _ in v)
+        full = [d for d, g, _ in v if g == gmax]
+        r = [x for _, g, x in v if g == gmax][0]
+        out.append((sum(full), k, len(full), sum(full) / len(full) / 1e3, min(full) / 1e3, max(full) / 1e3, gmax, r))
+    for s, k, n, avg, mn, mx, g, r in sorted(out, reverse=True):
+        if not (k.startswith("stage") or k.startswith("mel") or k.startswith("heads") or k.startswith("postproc") or k.startswith("advance")):
+            continue
+        tot += s
+        print(f"{k:32s} {n:8d} {avg:10.1f} {mn:10.1f} {mx:10.1f} {g:10d} {r['Workgroup_Size_X']:>5s} {r['VGPR_Count']:>5s} {r['LDS_Block_Size']:>7s}")
+    print(f"total hot-path kernel time {tot / 1e6:.2f} ms")
+    for path in sys.argv[2:]:
+        rows = list(csv.DictReader(open(path)))
+        agg = defaultdict(lambda: defaultdict(list))
+        gmax = defaultdict(int)
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            gmax[k] = max(gmax[k], int(r["Grid_Size"]))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if int(r["Grid_Size"]) == gmax[k]:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print(f"\ncounters from {path} (mean per full-grid launch)")
+        for k in sorted(agg):
+            if k.startswith(("stage", "mel", "heads")):
+                print(f"  {k:20s} " + "  ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(agg[k].items())))
+
+
+if __name__ == "__main__":
+    main()
