@@ -117,6 +117,10 @@ int  oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows);
 /* per-layer CNN outputs (new rows only, dense [rows][F][C]) of stream sid from the last chunk processed;
  * layer 0..19; needs cfg.debug_layers.  Returns the number of floats written. */
 int  oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t cap);
+/* in-kernel phase stamps (shader clock) of one workgroup of each of the four generic CNN stage kernels
+ * from the last step: out[stage 0..3][wave 0..15][mark 0..15]; only when the environment variable
+ * OWW_PROF_BLOCK=<workgroup index> was set at oww_commit time.  Development aid. */
+int  oww_debug_profile(oww_ctx* h, int64_t* out, int32_t cap);
 /* kernel timing: records hipEvents around every kernel of subsequent oww_step calls when enabled;
  * oww_kernel_times fills ms[i] with the accumulated time and n[i] with the launch count of kernel
  * class i (0 mel,1 stageA,2 stageB,3 stageC,4 stageD,5 stageE,6 heads,7 postproc) and clears them. */

@@ -14,24 +14,27 @@ LIB = os.path.join(HERE, "libowwhip.so")
 
 
 def lib_path() -> str:
-    return LIB
+    """OWW_LIB selects an alternative build of the same library (kernel-variant A/B runs only)."""
+    return os.environ.get("OWW_LIB") or LIB
 
 
 def is_fresh() -> bool:
     return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and is_fresh():
+def build(force: bool = False, verbose: bool = False, out: str | None = None, defines: tuple = ()) -> str:
+    target = out or LIB
+    if not force and out is None and is_fresh():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC,
-           "-I" + os.path.join(ROOT, "include"), "-o", LIB + ".tmp", "-Wall", "-Wno-unused-function"]
+           "-I" + os.path.join(ROOT, "include"), "-o", target + ".tmp", "-Wall", "-Wno-unused-function"]
+    cmd += ["-D" + d for d in defines]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":

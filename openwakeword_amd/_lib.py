@@ -43,6 +43,7 @@ SYMBOLS = {
     "oww_get_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "oww_get_mel": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "oww_debug_read": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "oww_debug_profile": (C.c_int, [_P, _P, C.c_int32]),
     "oww_enable_timing": (C.c_int, [_P, C.c_int]),
     "oww_kernel_times": (C.c_int, [_P, _P, _P]),
     "oww_use_graph": (C.c_int, [_P, C.c_int]),

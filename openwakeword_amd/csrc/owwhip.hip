@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -141,6 +142,8 @@ struct oww_ctx {
     float *d_mel = nullptr, *d_feat = nullptr, *d_emb = nullptr, *d_raw = nullptr, *d_scores = nullptr, *d_ring = nullptr;
     float* d_featinit = nullptr;
     float* d_dbg = nullptr;
+    long long* d_prof = nullptr;     // [4 stages][16 waves][16 marks], allocated when OWW_PROF_BLOCK is set
+    int prof_block = -1;
     uint32_t *d_nfeat = nullptr, *d_npred = nullptr;
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
     int* d_ids = nullptr;
@@ -226,6 +229,8 @@ int run_cnn_t(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
             p.shift[i] = h->d_shift[first_layer + i]; p.dbg_off[i] = dbg_off[first_layer + i];
         }
         p.dbg = dbg ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+        p.prof = h->d_prof ? h->d_prof + (first_layer / 4) * 256 : nullptr;      // first_layer 3,7,11,15 -> slot 0..3
+        p.prof_block = h->prof_block;
     };
     {
         StageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3);
@@ -352,7 +357,7 @@ void free_all(oww_ctx* h) {
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
     fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail);
-    fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold);
+    fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold);
     for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->ev.clear();
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -516,8 +521,18 @@ int oww_commit(oww_ctx* h) {
         for (int l = 0; l < 20; ++l) {
             const LayerDef& L = kLayers[l];
             const size_t nw = (size_t)L.kh * L.kw * L.cin * L.cout;
-            if (l == 0 || !h->mfma) o_conv[l] = hb.add(q, nw);
-            else { pack_mfma(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
+            if (!h->mfma) o_conv[l] = hb.add(q, nw);
+            else if (l == 0) {
+                // conv0: K = 9 taps padded to 12 -> three k-steps; lane (i, j) of k-step s holds w[k = 4s+j][cout = 16ct+i]
+                pk.assign(2 * 3 * 64, 0.f);
+                for (int ct = 0; ct < 2; ++ct)
+                    for (int s = 0; s < 3; ++s)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int k = 4 * s + (lane >> 4), co = ct * 16 + (lane & 15);
+                            if (k < 9 && co < 24) pk[(ct * 3 + s) * 64 + lane] = q[k * 24 + co];
+                        }
+                o_conv[l] = hb.add(pk);
+            } else { pack_mfma(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
             q += nw;
             if (l < 19) { o_scale[l] = hb.add(q, L.cout); q += L.cout; o_shift[l] = hb.add(q, L.cout); q += L.cout; }
         }
@@ -629,6 +644,7 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(hipMemcpy(h->d_threshold, nanv.data(), nanv.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (h->cfg.debug_layers) if (int rc = dalloc(&h->d_dbg, SP * DBG_FLOATS)) return rc;
+    if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
     if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;
@@ -866,6 +882,15 @@ int oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t c
     HIPCHK(hipMemcpyAsync(out, h->d_dbg + (size_t)sid * DBG_FLOATS + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return n;
+}
+
+int oww_debug_profile(oww_ctx* h, int64_t* out, int32_t cap) {
+    if (!h || !h->committed || !h->d_prof) return fail(OWW_ESTATE, "oww_debug_profile: set OWW_PROF_BLOCK before creating the handle");
+    if (!out || cap < 4 * 256) return fail(OWW_EINVAL, "oww_debug_profile: need room for 1024 values");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d_prof, (size_t)4 * 256 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 4 * 256;
 }
 
 int oww_enable_timing(oww_ctx* h, int on) {

@@ -56,69 +56,168 @@ __device__ __forceinline__ void pos_addr(int p, int& rd, int& wr) {
     }
 }
 
-template <int CIN, int COUT, int R, int F, int B, bool TIME, int NW, bool BN_ACT>
-__device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
-                                          const float* __restrict__ wpk, const float* __restrict__ scale,
-                                          const float* __restrict__ shift, int tid) {
-    constexpr int CPI = CIN + 4, CPO = COUT + 4;
-    constexpr int NCT = (COUT + 15) / 16;
-    constexpr int PSPLIT = NW / NCT;
+#ifndef OWW_PF
+#define OWW_PF 1          // LDS operand reads run this many 8-channel k-blocks ahead of the MFMAs (1 = compiler's choice)
+#endif
+#ifndef OWW_SCHED
+#define OWW_SCHED 0       // pin the DS-read / MFMA interleave with sched_group_barrier
+#endif
+#ifndef OWW_PIN
+#define OWW_PIN 0         // 1: weights loaded early (before the barrier) and pinned in VGPRs; 0: compiler streams them
+#endif
+#ifndef OWW_SPLIT
+#define OWW_SPLIT 0       // 0: one cout tile per wave (NW = NCT*PSPLIT); 1: equal runs of (cout,position) tiles per wave
+#endif
+
+// Weights of the cout tile a wave is working on: K/4 MFMA operand registers per lane.
+template <int CIN, int COUT, int NPT, int NW>
+struct ConvW {
+    static constexpr int KS = 3 * CIN / 4;
+    static constexpr int NCT = (COUT + 15) / 16;
+    static constexpr int ITEMS = NCT * NPT;
+#if OWW_SPLIT
+    static constexpr int PER = (ITEMS + NW - 1) / NW;
+#else
+    static constexpr int PSPLIT = NW / NCT;
     static_assert(PSPLIT >= 1, "need at least one wave per cout tile");
-    static_assert(CIN % 8 == 0, "k-blocks of 8 channels");
-    constexpr int NP = B * R * F;
-    constexpr int NPT = (NP + 15) / 16;
-    constexpr int KS = 3 * CIN / 4;
-    constexpr int TAPSTRIDE = TIME ? F * CPI : CPI;
-    const int wave = tid >> 6, lane = tid & 63;
-    if (wave >= NCT * PSPLIT) return;
-    const int ct = wave % NCT, part = wave / NCT;
-    const int pl = lane & 15, j = lane >> 4;
-
-    float wreg[KS];
+#endif
+    float w[KS];
+    __device__ __forceinline__ static int first_ct(int wave) {
+#if OWW_SPLIT
+        return wave * PER < ITEMS ? (wave * PER) / NPT : -1;
+#else
+        return wave < NCT * PSPLIT ? wave % NCT : -1;
+#endif
+    }
+    // issue the loads of the wave's first cout tile early (before the barrier that precedes the layer)
+    __device__ __forceinline__ void load(const float* __restrict__ wpk, int tid) {
+#if OWW_PIN
+        asm volatile("" ::: "memory");      // do not hoist these loads above the previous layer's MFMA loop
+        const int wave = tid >> 6, lane = tid & 63;
+        const int ct = first_ct(wave);
+        if (ct < 0) return;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wreg[s] = wpk[(ct * KS + s) * 64 + lane];
+        for (int s = 0; s < KS; ++s) w[s] = wpk[(ct * KS + s) * 64 + lane];
+#endif
+    }
+};
 
+// MFMA body for one or two position tiles against the cout tile whose weights sit in W.w
+template <int CIN, int COUT, int R, int F, int B, bool TIME, bool BN_ACT, bool PAIR, class WT>
+__device__ __forceinline__ void conv_tiles(const float* __restrict__ in, float* __restrict__ out, WT& W, int ct, int t0, int t1,
+                                           const f32x4 sc, const f32x4 sh, int lane) {
+    constexpr int CPI = CIN + 4, CPO = COUT + 4;
+    constexpr int NP = B * R * F;
+    constexpr int TAPSTRIDE = TIME ? F * CPI : CPI;
+    const int pl = lane & 15, j = lane >> 4;
     const int c0 = ct * 16 + j * 4;
     const bool cvalid = c0 < COUT;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (BN_ACT && cvalid) {
-        sc = *reinterpret_cast<const f32x4*>(scale + c0);
-        sh = *reinterpret_cast<const f32x4*>(shift + c0);
+    const int p0 = t0 * 16 + pl, p1 = t1 * 16 + pl;
+    const bool v0ok = p0 < NP, v1ok = PAIR && (p1 < NP);
+    int rd0, wr0, rd1 = 0, wr1 = 0;
+    pos_addr<R, F, TIME, CPI, CPO>(v0ok ? p0 : NP - 1, rd0, wr0);
+    if (PAIR) pos_addr<R, F, TIME, CPI, CPO>(v1ok ? p1 : NP - 1, rd1, wr1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NKB = 3 * CIN / 8;           // k-blocks of 8 channels
+    constexpr int PF = OWW_PF < 1 ? 1 : OWW_PF;
+    auto kb_off = [&](int kb) { return (kb / (CIN / 8)) * TAPSTRIDE + (kb % (CIN / 8)) * 8 + 2 * j; };
+    float2 q0[PF], q1[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        q0[u] = *reinterpret_cast<const float2*>(in + rd0 + kb_off(u < NKB ? u : 0));
+        if (PAIR) q1[u] = *reinterpret_cast<const float2*>(in + rd1 + kb_off(u < NKB ? u : 0));
     }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const float2 x0 = q0[kb % PF];
+        float2 x1 = x0;
+        if (PAIR) x1 = q1[kb % PF];
+        if (kb + PF < NKB) {
+            q0[kb % PF] = *reinterpret_cast<const float2*>(in + rd0 + kb_off(kb + PF));
+            if (PAIR) q1[kb % PF] = *reinterpret_cast<const float2*>(in + rd1 + kb_off(kb + PF));
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w[2 * kb], x0.x, acc0, 0, 0, 0);
+        if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w[2 * kb], x1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w[2 * kb + 1], x0.y, acc0, 0, 0, 0);
+        if (PAIR) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w[2 * kb + 1], x1.y, acc1, 0, 0, 0);
+#if OWW_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, PAIR ? 2 : 1, 0);   // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 4 : 2, 0);   // MFMA
+#endif
+    }
+    if (cvalid) {
+        if (BN_ACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0[e] = leaky_clamp(acc0[e] * sc[e] + sh[e]);
+                if (PAIR) acc1[e] = leaky_clamp(acc1[e] * sc[e] + sh[e]);
+            }
+        }
+        if (v0ok) *reinterpret_cast<f32x4*>(out + wr0 + c0) = acc0;
+        if (v1ok) *reinterpret_cast<f32x4*>(out + wr1 + c0) = acc1;
+    }
+}
 
-    for (int t0 = part; t0 < NPT; t0 += 2 * PSPLIT) {
-        const int t1 = t0 + PSPLIT;
-        const int p0 = t0 * 16 + pl, p1 = t1 * 16 + pl;
-        const bool v0ok = p0 < NP, v1ok = (t1 < NPT) && (p1 < NP);
-        int rd0, wr0, rd1, wr1;
-        pos_addr<R, F, TIME, CPI, CPO>(v0ok ? p0 : NP - 1, rd0, wr0);
-        pos_addr<R, F, TIME, CPI, CPO>(v1ok ? p1 : NP - 1, rd1, wr1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+template <int CIN, int COUT, int R, int F, int B, bool TIME, int NW, bool BN_ACT>
+__device__ __forceinline__ void conv_mfma(const float* __restrict__ in, float* __restrict__ out,
+                                          const float* __restrict__ wpk,
+                                          ConvW<CIN, COUT, (B * R * F + 15) / 16, NW>& W,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, int tid) {
+    static_assert(CIN % 8 == 0, "k-blocks of 8 channels");
+    constexpr int NPT = (B * R * F + 15) / 16;
+    using WT = ConvW<CIN, COUT, NPT, NW>;
+    constexpr int KS = WT::KS;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int j = lane >> 4;
+    auto fetch = [&](int ct, bool preloaded) {
+        if (!(OWW_PIN && preloaded)) {
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-#pragma unroll
-            for (int cb = 0; cb < CIN; cb += 8) {
-                const float2 x0 = *reinterpret_cast<const float2*>(in + rd0 + tap * TAPSTRIDE + cb + 2 * j);
-                const float2 x1 = *reinterpret_cast<const float2*>(in + rd1 + tap * TAPSTRIDE + cb + 2 * j);
-                const int s = (tap * CIN + cb) / 4;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], x0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], x1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], x0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], x1.y, acc1, 0, 0, 0);
-            }
+            for (int s = 0; s < KS; ++s) W.w[s] = wpk[(ct * KS + s) * 64 + lane];
         }
-        if (cvalid) {
-            if (BN_ACT) {
+#if OWW_PIN
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc0[e] = leaky_clamp(acc0[e] * sc[e] + sh[e]);
-                    acc1[e] = leaky_clamp(acc1[e] * sc[e] + sh[e]);
-                }
-            }
-            if (v0ok) *reinterpret_cast<f32x4*>(out + wr0 + c0) = acc0;
-            if (v1ok) *reinterpret_cast<f32x4*>(out + wr1 + c0) = acc1;
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(W.w[s]));
+#endif
+    };
+    auto bn = [&](int ct, f32x4& sc, f32x4& sh) {
+        sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c0 = ct * 16 + j * 4;
+        if (BN_ACT && c0 < COUT) {
+            sc = *reinterpret_cast<const f32x4*>(scale + c0);
+            sh = *reinterpret_cast<const f32x4*>(shift + c0);
         }
+    };
+#if OWW_SPLIT
+    int i = wave * WT::PER;
+    const int iend = min(i + WT::PER, WT::ITEMS);
+    bool first = true;
+    while (i < iend) {
+        const int ct = i / NPT;
+        int t = i - ct * NPT;
+        const int tend = min(NPT, t + (iend - i));
+        i += tend - t;
+        fetch(ct, first);
+        first = false;
+        f32x4 sc, sh;
+        bn(ct, sc, sh);
+        for (; t + 1 < tend; t += 2)
+            conv_tiles<CIN, COUT, R, F, B, TIME, BN_ACT, true>(in, out, W, ct, t, t + 1, sc, sh, lane);
+        if (t < tend)
+            conv_tiles<CIN, COUT, R, F, B, TIME, BN_ACT, false>(in, out, W, ct, t, t, sc, sh, lane);
     }
+#else
+    constexpr int PSPLIT = WT::PSPLIT;
+    if (wave >= WT::NCT * PSPLIT) return;
+    const int ct = wave % WT::NCT, part = wave / WT::NCT;
+    fetch(ct, true);
+    f32x4 sc, sh;
+    bn(ct, sc, sh);
+    int t = part;
+    for (; t + PSPLIT < NPT; t += 2 * PSPLIT)
+        conv_tiles<CIN, COUT, R, F, B, TIME, BN_ACT, true>(in, out, W, ct, t, t + PSPLIT, sc, sh, lane);
+    if (t < NPT)
+        conv_tiles<CIN, COUT, R, F, B, TIME, BN_ACT, false>(in, out, W, ct, t, t, sc, sh, lane);
+#endif
 }
 
 // plain-VALU version of the same layer (same LDS layouts; weights in natural [tap][cin][cout] order)
@@ -142,9 +241,10 @@ __device__ __forceinline__ void conv_valu(const float* __restrict__ in, float* _
 }
 
 template <bool MFMA, int CIN, int COUT, int R, int F, int B, bool TIME, int NW, bool BN_ACT>
-__device__ __forceinline__ void conv_layer(const float* in, float* out, const float* w, const float* scale,
-                                           const float* shift, int tid) {
-    if (MFMA) conv_mfma<CIN, COUT, R, F, B, TIME, NW, BN_ACT>(in, out, w, scale, shift, tid);
+__device__ __forceinline__ void conv_layer(const float* in, float* out, const float* w,
+                                           ConvW<CIN, COUT, (B * R * F + 15) / 16, NW>& W,
+                                           const float* scale, const float* shift, int tid) {
+    if (MFMA) conv_mfma<CIN, COUT, R, F, B, TIME, NW, BN_ACT>(in, out, w, W, scale, shift, tid);
     else      conv_valu<CIN, COUT, R, F, B, TIME, NW, BN_ACT>(in, out, w, scale, shift, tid);
 }
 
@@ -216,10 +316,17 @@ struct StageCfg {
     static constexpr int LDS_BYTES = (P_FLOATS + Q_FLOATS) * 4;
     static constexpr int NT = NW * 64;
 };
+#if OWW_SPLIT
+using CfgB = StageCfg<24, 48, 4, 16, 1, 2, 2, 8>;
+using CfgC = StageCfg<48, 72, 4, 8, 2, 2, 2, 4>;
+using CfgD = StageCfg<72, 96, 2, 4, 1, 2, 4, 4>;
+using CfgE = StageCfg<96, 96, 2, 2, 2, 2, 8, 4>;
+#else
 using CfgB = StageCfg<24, 48, 4, 16, 1, 2, 2, 6>;
 using CfgC = StageCfg<48, 72, 4, 8, 2, 2, 2, 5>;
 using CfgD = StageCfg<72, 96, 2, 4, 1, 2, 4, 6>;
 using CfgE = StageCfg<96, 96, 2, 2, 2, 2, 8, 6>;
+#endif
 
 struct StageParams {
     const float* xin;      // [S][R][F][CIN]
@@ -240,7 +347,10 @@ struct StageParams {
     float* dbg;            // [S][dbg_stride] or null
     size_t dbg_stride;
     int dbg_off[5];
+    long long* prof;       // [16 waves][16 marks] shader-clock stamps of workgroup prof_block, or null
+    int prof_block;
 };
+#define OWW_MARK(k) do { if (p.prof && (int)blockIdx.x == p.prof_block && (tid & 63) == 0) p.prof[(tid >> 6) * 16 + (k)] = clock64(); } while (0)
 
 template <class C, bool MFMA, bool LAST>
 __global__ __launch_bounds__(C::NT) void stage_kernel(StageParams p) {
@@ -252,30 +362,71 @@ __global__ __launch_bounds__(C::NT) void stage_kernel(StageParams p) {
     const int tid = threadIdx.x;
     const int s0 = blockIdx.x * B;
 
+    constexpr int NPT = (B * R * F + 15) / 16;
+    ConvW<CIN, CC, NPT, NW> Wa;
+    ConvW<CC, CC, NPT, NW> Wb, Wc, Wd;
+    ConvW<CC, CC, (B + 15) / 16, NW> W19;
+    OWW_MARK(0);
+    if (MFMA) Wa.load(p.w[0], tid);
+    // history of conv d is needed two barriers from now: fetch it into registers right away
+    constexpr int HN4 = B * 2 * F * CC / 4;
+    constexpr int HPT = (HN4 + NT - 1) / NT;
+    f32x4 hd[HPT];
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        const int i = tid + u * NT;
+        if (i < HN4) hd[u] = reinterpret_cast<const f32x4*>(p.hist_d + (size_t)s0 * 2 * F * CC)[i];
+    }
     // phase 0: stage input (CIN layout) + history of conv b
     zero_pads<B * R, F, CIN, CPI, NT>(P, tid);
     g2l<B, R, F, CIN, R, F + 2, CPI, NT>(p.xin + (size_t)s0 * R * F * CIN, P, 0, 1, tid);
     g2l<B, 2, F, CC, R + 2, F, CP, NT>(p.hist_b + (size_t)s0 * 2 * F * CC, Q, 0, 0, tid);
+    OWW_MARK(1);
     __syncthreads();
+    OWW_MARK(2);
     // conv a: 1x3 CIN -> C
-    conv_layer<MFMA, CIN, CC, R, F, B, false, NW, true>(P, Q, p.w[0], p.scale[0], p.shift[0], tid);
+    conv_layer<MFMA, CIN, CC, R, F, B, false, NW, true>(P, Q, p.w[0], Wa, p.scale[0], p.shift[0], tid);
+    if (MFMA) Wb.load(p.w[1], tid);
+    OWW_MARK(3);
     __syncthreads();
+    OWW_MARK(4);
     // new history of conv b = last two rows of its input; conv b: 3x1
     l2g<B, 2, F, CC, R + 2, F, CP, NT>(Q, p.hist_b + (size_t)s0 * 2 * F * CC, R, 0, tid);
     if (p.dbg) l2dbg<B, R, F, CC, R + 2, F, CP, NT>(Q, p.dbg, p.dbg_stride, p.dbg_off[0], s0, 2, 0, tid);
     zero_pads<B * R, F, CC, CP, NT>(P, tid);
-    conv_layer<MFMA, CC, CC, R, F, B, true, NW, true>(Q, P, p.w[1], p.scale[1], p.shift[1], tid);
+    conv_layer<MFMA, CC, CC, R, F, B, true, NW, true>(Q, P, p.w[1], Wb, p.scale[1], p.shift[1], tid);
+    if (MFMA) Wc.load(p.w[2], tid);
+    OWW_MARK(5);
     __syncthreads();
-    // conv c: 1x3
-    g2l<B, 2, F, CC, R + 2, F, CP, NT>(p.hist_d + (size_t)s0 * 2 * F * CC, Q, 0, 0, tid);
+    OWW_MARK(6);
+    // conv c: 1x3 (its output rows 2.. of Q; rows 0,1 = prefetched history of conv d)
+#pragma unroll
+    for (int u = 0; u < HPT; ++u) {
+        const int i = tid + u * NT;
+        if (i < HN4) {
+            const int e = i * 4;
+            const int c = e % CC;
+            const int pos = e / CC;
+            const int f = pos % F;
+            const int rb = pos / F;
+            const int row = rb % 2, b = rb / 2;
+            *reinterpret_cast<f32x4*>(Q + ((b * (R + 2) + row) * F + f) * CP + c) = hd[u];
+        }
+    }
     if (p.dbg) l2dbg<B, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[1], s0, 0, 1, tid);
-    conv_layer<MFMA, CC, CC, R, F, B, false, NW, true>(P, Q, p.w[2], p.scale[2], p.shift[2], tid);
+    conv_layer<MFMA, CC, CC, R, F, B, false, NW, true>(P, Q, p.w[2], Wc, p.scale[2], p.shift[2], tid);
+    if (MFMA) Wd.load(p.w[3], tid);
+    OWW_MARK(7);
     __syncthreads();
+    OWW_MARK(8);
     // conv d: 3x1
     l2g<B, 2, F, CC, R + 2, F, CP, NT>(Q, p.hist_d + (size_t)s0 * 2 * F * CC, R, 0, tid);
     if (p.dbg) l2dbg<B, R, F, CC, R + 2, F, CP, NT>(Q, p.dbg, p.dbg_stride, p.dbg_off[2], s0, 2, 0, tid);
-    conv_layer<MFMA, CC, CC, R, F, B, true, NW, true>(Q, P, p.w[3], p.scale[3], p.shift[3], tid);
+    conv_layer<MFMA, CC, CC, R, F, B, true, NW, true>(Q, P, p.w[3], Wd, p.scale[3], p.shift[3], tid);
+    if (MFMA && LAST) W19.load(p.w19, tid);
+    OWW_MARK(9);
     __syncthreads();
+    OWW_MARK(10);
     if (p.dbg) l2dbg<B, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[3], s0, 0, 1, tid);
 
     // max pool PT x PF
@@ -313,7 +464,7 @@ __global__ __launch_bounds__(C::NT) void stage_kernel(StageParams p) {
         g2l<B, 2, 1, CC, 3, 1, CP, NT>(p.hist19 + (size_t)s0 * 2 * CC, Q, 0, 0, tid);
         __syncthreads();
         // P19 layout [b][1][3][CP] in P (pool finished reading P before the barrier above)
-        conv_layer<MFMA, CC, CC, 1, 1, B, true, NW, false>(Q, P, p.w19, nullptr, nullptr, tid);
+        conv_layer<MFMA, CC, CC, 1, 1, B, true, NW, false>(Q, P, p.w19, W19, nullptr, nullptr, tid);
         l2g<B, 2, 1, CC, 3, 1, CP, NT>(Q, p.hist19 + (size_t)s0 * 2 * CC, 1, 0, tid);
         __syncthreads();
         for (int i = tid; i < B * CC; i += NT) {
@@ -326,6 +477,7 @@ __global__ __launch_bounds__(C::NT) void stage_kernel(StageParams p) {
             if (p.dbg) p.dbg[(size_t)s * p.dbg_stride + p.dbg_off[4] + c] = v;
         }
     }
+    OWW_MARK(11);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -337,7 +489,7 @@ struct StageAParams {
     int mel_stride, mel_off;
     float* hist_mel;       // [S][2][32]
     float* hist2;          // [S][2][32][24]
-    const float* w0;       // [9][24]
+    const float* w0;       // natural [9][24] (VALU) or MFMA-packed [2][3][64] (K padded 9 -> 12)
     const float* w1;       // packed / natural
     const float* w2;
     const float* scale[3];
@@ -365,6 +517,14 @@ __global__ __launch_bounds__(CfgA::NT) void stageA_kernel(StageAParams p) {
     const int tid = threadIdx.x;
     const int s = blockIdx.x;
 
+    ConvW<CC, CC, 16, NW> W1, W2;
+    float w0r[3];
+    if (MFMA) {
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w0r[k] = p.w0[((wave & 1) * 3 + k) * 64 + lane];
+        W1.load(p.w1, tid);
+    }
     // phase 0
     for (int i = tid; i < 10 * 34; i += NT) {
         const int row = i / 34, col = i % 34;
@@ -378,8 +538,32 @@ __global__ __launch_bounds__(CfgA::NT) void stageA_kernel(StageAParams p) {
     zero_pads<R, F, CC, CP, NT>(P, tid);
     g2l<1, 2, F, CC, R + 2, F, CP, NT>(p.hist2 + (size_t)s * 2 * F * CC, Q, 0, 0, tid);
     __syncthreads();
-    // conv0: 3x3 valid in time, zero padded in mel; ReLU; BN; activation (plain VALU: K = 9)
-    {
+    // conv0: 3x3 valid in time, zero padded in mel; ReLU; BN; activation
+    if (MFMA) {
+        // K = 9 taps padded to 12: three k-steps of v_mfma_f32_16x16x4_f32, operand B gathered from the mel tile
+        const int wave = tid >> 6, lane = tid & 63;
+        const int ct = wave & 1, part = wave >> 1, pl = lane & 15, j = lane >> 4;
+        const int c0 = ct * 16 + j * 4;
+        const bool cvalid = c0 < CC;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (cvalid) { sc = *reinterpret_cast<const f32x4*>(p.scale[0] + c0); sh = *reinterpret_cast<const f32x4*>(p.shift[0] + c0); }
+        int koff[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int kk = min(4 * k + j, 8); koff[k] = (kk / 3) * 34 + (kk % 3); }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pidx = (part + 4 * it) * 16 + pl;
+            const int f = pidx % F, r = pidx / F;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0r[k], M[r * 34 + f + koff[k]], acc, 0, 0, 0);
+            if (cvalid) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = leaky_clamp(fmaxf(acc[e], 0.f) * sc[e] + sh[e]);
+                *reinterpret_cast<f32x4*>(P + (r * (F + 2) + f + 1) * CP + c0) = acc;
+            }
+        }
+    } else {
         const float* __restrict__ w0 = p.w0;
         const float* __restrict__ sc = p.scale[0];
         const float* __restrict__ sh = p.shift[0];
@@ -396,15 +580,16 @@ __global__ __launch_bounds__(CfgA::NT) void stageA_kernel(StageAParams p) {
             acc = fmaxf(acc, 0.f);
             P[(r * (F + 2) + f + 1) * CP + c] = leaky_clamp(acc * sc[c] + sh[c]);
         }
-        if (tid < 64) p.hist_mel[(size_t)s * 64 + tid] = M[(8 + tid / 32) * 34 + 1 + (tid % 32)];
     }
+    if (tid < 64) p.hist_mel[(size_t)s * 64 + tid] = M[(8 + tid / 32) * 34 + 1 + (tid % 32)];
     __syncthreads();
     if (p.dbg) l2dbg<1, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[0], s, 0, 1, tid);
-    conv_layer<MFMA, CC, CC, R, F, 1, false, NW, true>(P, Q, p.w1, p.scale[1], p.shift[1], tid);
+    conv_layer<MFMA, CC, CC, R, F, 1, false, NW, true>(P, Q, p.w1, W1, p.scale[1], p.shift[1], tid);
+    if (MFMA) W2.load(p.w2, tid);
     __syncthreads();
     l2g<1, 2, F, CC, R + 2, F, CP, NT>(Q, p.hist2 + (size_t)s * 2 * F * CC, R, 0, tid);
     if (p.dbg) l2dbg<1, R, F, CC, R + 2, F, CP, NT>(Q, p.dbg, p.dbg_stride, p.dbg_off[1], s, 2, 0, tid);
-    conv_layer<MFMA, CC, CC, R, F, 1, true, NW, true>(Q, P, p.w2, p.scale[2], p.shift[2], tid);
+    conv_layer<MFMA, CC, CC, R, F, 1, true, NW, true>(Q, P, p.w2, W2, p.scale[2], p.shift[2], tid);
     __syncthreads();
     if (p.dbg) l2dbg<1, R, F, CC, R, F + 2, CP, NT>(P, p.dbg, p.dbg_stride, p.dbg_off[2], s, 0, 1, tid);
     float* xo = p.xout + (size_t)s * 4 * 16 * CC;

@@ -219,6 +219,12 @@ class StreamEngine:
         _lib.check(self._lib.oww_debug_read(self._h, int(sid), int(layer), _ptr(out), out.size))
         return out.reshape(r, f, c)
 
+    def debug_profile(self) -> np.ndarray:
+        """Shader-clock phase stamps [stage B..E][wave][mark] of workgroup $OWW_PROF_BLOCK (development aid)."""
+        out = np.zeros((4, 16, 16), dtype=np.int64)
+        _lib.check(self._lib.oww_debug_profile(self._h, _ptr(out), out.size))
+        return out
+
     def enable_timing(self, on: bool = True):
         _lib.check(self._lib.oww_enable_timing(self._h, int(on)))
 
