@@ -100,12 +100,13 @@ def main():
     pool = [(torch.randn(S, 1280, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
             for _ in range(max(1, args.pcm_pool))]
     scores = torch.empty(S, NL, device=dev, dtype=torch.float32)
-    gathered = [torch.empty_like(scores) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from openwakeword_amd.shard import ScoreGather
+    gatherer = ScoreGather(S * world, NL, dev) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
 
     def one_step(i):
         eng.step_device(pool[i % len(pool)].data_ptr(), 1, scores.data_ptr())
         if world > 1:
-            dist.gather(scores, gathered, dst=0)       # RCCL over xGMI: the path's only exchange
+            gatherer.gather(scores)                    # RCCL over xGMI: the path's only exchange
 
     def fence():
         if world > 1:

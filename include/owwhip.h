@@ -96,6 +96,10 @@ int  oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunk
               float* scores, int scores_on_device);
 int  oww_sync(oww_ctx* h);
 const float* oww_scores_dev(const oww_ctx* h);     /* device [S][n_labels], valid until the next step */
+/* raw head outputs of the last step, BEFORE post-processing (what model_prediction_function returned,
+ * model.py:313-317; max over chunks for n_chunks > 1): host fp32 [S][n_labels].  Blocking.  Lets a host
+ * shim run the reference's own post-processing (Model.predict with short / unaligned calls). */
+int  oww_get_raw(oww_ctx* h, float* out);
 
 /* ---- stage-level entry points (the reference's per-stage closures; used for parity tests and for
  *      AudioFeatures._get_melspectrogram / embed_clips style callers).  Host pointers. ---------------

@@ -37,6 +37,7 @@ SYMBOLS = {
     "oww_step": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P, C.c_int]),
     "oww_sync": (C.c_int, [_P]),
     "oww_scores_dev": (_P, [_P]),
+    "oww_get_raw": (C.c_int, [_P, _P]),
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_embed": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),

@@ -765,6 +765,16 @@ int oww_sync(oww_ctx* h) {
 
 const float* oww_scores_dev(const oww_ctx* h) { return h ? h->d_scores : nullptr; }
 
+int oww_get_raw(oww_ctx* h, float* out) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_raw: handle not committed");
+    if (!out) return fail(OWW_EINVAL, "oww_get_raw: null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t nb = (size_t)h->S * h->NL * sizeof(float);
+    if (nb) HIPCHK(hipMemcpyAsync(out, h->d_raw, nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OWW_OK;
+}
+
 int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_mel: handle not committed");
     if (!pcm || !out_db || B < 1 || n < 512) return fail(OWW_EINVAL, "oww_mel: bad argument (B=%d n=%d)", B, n);

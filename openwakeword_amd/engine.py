@@ -154,6 +154,18 @@ class StreamEngine:
         _lib.check(self._lib.oww_step(self._h, _ptr(pcm), 0, k, _ptr(out), 0))
         return out
 
+    def step_raw(self, pcm: np.ndarray) -> np.ndarray:
+        """Like step(), but returns the head outputs before post-processing (model.py:313-317)."""
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype != np.int16:
+            raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {pcm.dtype} data.")
+        if pcm.ndim != 2 or pcm.shape[0] != self.n_streams or pcm.shape[1] % CHUNK or pcm.shape[1] == 0:
+            raise ValueError(f"pcm must be [n_streams={self.n_streams}, 1280*k], got {pcm.shape}")
+        _lib.check(self._lib.oww_step(self._h, _ptr(pcm), 0, pcm.shape[1] // CHUNK, None, 0))
+        out = np.empty((self.n_streams, self.n_labels), dtype=np.float32)
+        _lib.check(self._lib.oww_get_raw(self._h, _ptr(out)))
+        return out
+
     def step_device(self, pcm_dev_ptr: int, n_chunks: int = 1, scores_dev_ptr: int = 0):
         """Asynchronous step on device pointers (e.g. torch tensors' data_ptr())."""
         _lib.check(self._lib.oww_step(self._h, C.c_void_p(pcm_dev_ptr), 1, int(n_chunks),

@@ -1,0 +1,437 @@
+"""
+`Model` / `AudioFeatures`: the reference's Python surface for the streaming path, on the HIP library.
+
+Mirrors `openwakeword.Model` (/root/reference/openwakeword/model.py:32-426) and the streaming half of
+`openwakeword.utils.AudioFeatures` (utils.py:163-178, 387-463): same constructor keywords, `predict`,
+`predict_clip`, `reset`, `prediction_buffer`, `models`, `model_inputs`, `model_outputs`, `class_mapping`,
+`preprocessor.get_features`, same exceptions.  `inference_framework="hip"` is the value this package adds
+to the reference's `"onnx"` / `"tflite"` selector (model.py:46,112,133).
+
+One `Model` object = one audio stream, like the reference.  The arithmetic (mel, embedding CNN, heads) runs
+in libowwhip.so on the GPU through a 1-stream `StreamEngine`; this file only keeps the reference's
+host-side control flow: 1280-sample alignment with carry-over (utils.py:409-430), the "repeat the last
+prediction" rule for short calls (model.py:299-307), custom verifier hook (model.py:320-328), first-5
+zeroing / patience / debounce on the 30-deep `prediction_buffer` (model.py:330-363).  For many streams use
+`BatchedModel`, which keeps that post-processing on the device as well.
+
+There is no CPU fallback: constructing a Model without the HIP library or a GPU raises.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import wave
+from collections import defaultdict, deque
+from functools import partial
+from typing import DefaultDict, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import weights as W
+from .engine import CHUNK, EMB_DIM, StreamEngine
+
+# openwakeword/__init__.py:26-60 (names only; the files are release assets that are not in the checkout)
+MODELS = {name: {"model_path": os.path.join(os.path.dirname(os.path.abspath(__file__)), "resources", "models",
+                                            f"{name}_v0.1.onnx")}
+          for name in ("alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather")}
+FEATURE_MODELS = {k: {"model_path": os.path.join(os.path.dirname(os.path.abspath(__file__)), "resources", "models", f)}
+                  for k, f in (("embedding", "embedding_model.onnx"), ("melspectrogram", "melspectrogram.onnx"))}
+# openwakeword/__init__.py:62-71
+model_class_mappings = {
+    "timer": {"1": "1_minute_timer", "2": "5_minute_timer", "3": "10_minute_timer",
+              "4": "20_minute_timer", "5": "30_minute_timer", "6": "1_hour_timer"}
+}
+
+
+def get_pretrained_model_paths(inference_framework: str = "hip") -> List[str]:
+    return [MODELS[k]["model_path"] for k in MODELS]
+
+
+def _load_head(path_or_name: str, synthetic_seed: Optional[int]):
+    """Return (model name, head dict).  A path must be an .onnx file readable by onnx_ingest; a bare name is
+    looked up among the pretrained files, or generated when synthetic weights were asked for."""
+    if os.path.exists(path_or_name):
+        if path_or_name.endswith(".tflite"):
+            raise ValueError("The hip inference framework is selected, but tflite models were provided!")
+        from . import onnx_ingest
+        return os.path.splitext(os.path.basename(path_or_name))[0], onnx_ingest.load_head(path_or_name)
+    key = path_or_name.replace(" ", "_")
+    match = [p for p in get_pretrained_model_paths() if key in p.split(os.path.sep)[-1]]
+    if not match:
+        raise ValueError("Could not find pretrained model for model name '{}'".format(path_or_name))
+    if os.path.exists(match[0]):
+        from . import onnx_ingest
+        return path_or_name, onnx_ingest.load_head(match[0])
+    if synthetic_seed is None:
+        raise ValueError(f"Pretrained model file {match[0]} does not exist (the reference downloads it at run "
+                         "time, utils.py:625-673). Pass weights='synthetic' to use random-init weights of the "
+                         "same architecture, or give the path of an .onnx file.")
+    base = [k for k in MODELS if k in os.path.basename(match[0])][0]
+    return path_or_name, W.synthetic_head(base, synthetic_seed)
+
+
+class AudioFeatures:
+    """Streaming half of openwakeword.utils.AudioFeatures on one device stream.
+
+    `__call__(x)` buffers audio exactly like utils.py:409-452 and advances the device by whole 1280-sample
+    chunks; `get_features(n)` reads the device feature ring (utils.py:454-460)."""
+
+    feature_buffer_max_len = 120        # utils.py:170
+
+    def __init__(self, engine: StreamEngine, stream: int = 0):
+        self.engine = engine
+        self.sid = int(stream)
+        self._pending = np.empty(0, dtype=np.int16)     # samples appended to the raw buffer, not yet processed
+        self.accumulated_samples = 0
+        self.raw_data_remainder = np.empty(0, dtype=np.int16)
+        self.last_scores: Optional[np.ndarray] = None
+        self.reset()
+
+    def _get_embeddings(self, x: np.ndarray) -> np.ndarray:
+        """utils.py:210-241: mel of the whole clip, 76-row windows every 8 rows, one embedding each."""
+        spec = self.engine.mel(np.asarray(x, dtype=np.int16)[None])[0] / 10.0 + 2.0       # utils.py:180,206
+        n_win = (spec.shape[0] - 76) // 8 + 1
+        if n_win < 1:
+            return np.zeros((0, EMB_DIM), np.float32)
+        out = self.engine.embed(spec[None, : 76 + 8 * (n_win - 1)].astype(np.float32))[0]
+        return out
+
+    def reset(self):
+        """utils.py:172-178: the feature ring restarts from the embeddings of 4 s of random audio."""
+        self._pending = np.empty(0, dtype=np.int16)
+        self.accumulated_samples = 0
+        self.raw_data_remainder = np.empty(0, dtype=np.int16)
+        noise = np.random.randint(-1000, 1000, 16000 * 4).astype(np.int16)
+        feats = self._get_embeddings(noise)                       # [41, 96]; clobbers stream state -> reset below
+        ring = np.zeros((self.engine.feature_ring, EMB_DIM), np.float32)
+        n = min(len(feats), ring.shape[0])
+        ring[ring.shape[0] - n:] = feats[len(feats) - n:]
+        self._n_features = n
+        self.engine.reset([self.sid], ring)
+
+    def __call__(self, x: np.ndarray) -> int:
+        x = np.asarray(x)
+        if x.dtype != np.int16:                                     # utils.py:195-197 (lists are cast, 194)
+            raise ValueError("Input data must be 16-bit integers (i.e., 16-bit PCM audio)."
+                             f"You provided {x.dtype} data.")
+        processed = 0
+        if self.raw_data_remainder.shape[0] != 0:
+            x = np.concatenate((self.raw_data_remainder, x))
+            self.raw_data_remainder = np.empty(0, dtype=np.int16)
+        if self.accumulated_samples + x.shape[0] >= CHUNK:
+            remainder = (self.accumulated_samples + x.shape[0]) % CHUNK
+            if remainder != 0:
+                even = x[0:-remainder]
+                self._pending = np.concatenate((self._pending, even))
+                self.accumulated_samples += len(even)
+                self.raw_data_remainder = x[-remainder:]
+            else:
+                self._pending = np.concatenate((self._pending, x))
+                self.accumulated_samples += x.shape[0]
+        else:
+            self.accumulated_samples += x.shape[0]
+            self._pending = np.concatenate((self._pending, x))
+
+        if self.accumulated_samples >= CHUNK and self.accumulated_samples % CHUNK == 0:
+            k = self.accumulated_samples // CHUNK
+            if k > self.engine.max_chunks:
+                raise ValueError(f"a single call may carry at most {self.engine.max_chunks} x 1280 samples "
+                                 f"(max_chunks); got {self.accumulated_samples}")
+            self.last_scores = self.engine.step_raw(self._pending[None, :])[0]
+            self._n_features = min(self._n_features + k, self.feature_buffer_max_len)
+            self._pending = np.empty(0, dtype=np.int16)
+            processed = self.accumulated_samples
+            self.accumulated_samples = 0
+        return processed if processed != 0 else self.accumulated_samples
+
+    def get_features(self, n_feature_frames: int = 16, start_ndx: int = -1) -> np.ndarray:
+        have = min(self._n_features, self.engine.feature_ring)
+        buf = self.engine.get_features(self.sid, have)              # the reference's feature_buffer, oldest first
+        if start_ndx != -1:                                         # utils.py:455-458
+            end_ndx = start_ndx + int(n_feature_frames) if start_ndx + n_feature_frames != 0 else len(buf)
+            return buf[start_ndx:end_ndx, :][None, ].astype(np.float32)
+        return buf[int(-1 * n_feature_frames):, :][None, ].astype(np.float32)
+
+
+class Model:
+    """openwakeword.Model on the HIP library (one stream per object)."""
+
+    def __init__(self, wakeword_models: List[str] = [], class_mapping_dicts: List[dict] = [],
+                 enable_speex_noise_suppression: bool = False, vad_threshold: float = 0,
+                 custom_verifier_models: dict = {}, custom_verifier_threshold: float = 0.1,
+                 inference_framework: str = "hip", weights: Union[str, dict, None] = None, device: int = 0,
+                 max_chunks: int = 32, wakeword_model_paths: Optional[List[str]] = None, **kwargs):
+        if wakeword_model_paths is not None:            # deprecated alias (model.py:37)
+            wakeword_models = wakeword_model_paths
+        if inference_framework != "hip":
+            raise ValueError(f"openwakeword_amd only provides inference_framework='hip' (got '{inference_framework}'); "
+                             "use the reference package for 'onnx' / 'tflite'")
+        seed = None
+        embedding = None
+        given_heads: Dict[str, dict] = {}
+        if isinstance(weights, str):
+            if weights != "synthetic":
+                raise ValueError("weights must be 'synthetic', a dict {'embedding':..., 'heads':...} or None")
+            seed = 1234
+        elif isinstance(weights, dict):
+            embedding = weights.get("embedding")
+            given_heads = dict(weights.get("heads", {}))
+            seed = weights.get("seed")
+        wakeword_models = list(wakeword_models)
+        if wakeword_models == [] and given_heads:
+            wakeword_models = list(given_heads)
+        if wakeword_models == []:
+            wakeword_models = list(MODELS.keys())           # model.py:84-87: all pretrained models
+        heads: Dict[str, dict] = {}
+        for m in wakeword_models:
+            if m in given_heads:
+                heads[m] = given_heads[m]
+            else:
+                name, head = _load_head(m, seed)
+                heads[name] = head
+        if embedding is None:
+            if os.path.exists(FEATURE_MODELS["embedding"]["model_path"]):
+                from . import onnx_ingest
+                embedding = onnx_ingest.load_embedding(FEATURE_MODELS["embedding"]["model_path"])
+            elif seed is not None:
+                embedding = W.synthetic_embedding(seed)
+            else:
+                raise ValueError(f"{FEATURE_MODELS['embedding']['model_path']} does not exist; pass weights='synthetic' "
+                                 "for random-init weights of the same architecture")
+
+        self.models: Dict[str, dict] = heads
+        self.model_inputs = {n: int(h["T"]) for n, h in heads.items()}          # model.py:156
+        self.model_outputs = {n: int(h["n_out"]) for n, h in heads.items()}     # model.py:157
+        self.class_mapping: Dict[str, dict] = {}
+        for i, n in enumerate(heads):                                           # model.py:177-182
+            if class_mapping_dicts and i < len(class_mapping_dicts) and class_mapping_dicts[i].get(n, None):
+                self.class_mapping[n] = class_mapping_dicts[i]
+            elif model_class_mappings.get(n, None):
+                self.class_mapping[n] = model_class_mappings[n]
+            else:
+                self.class_mapping[n] = {str(j): str(j) for j in range(0, self.model_outputs[n])}
+
+        self.custom_verifier_models: Dict[str, object] = {}
+        self.custom_verifier_threshold = custom_verifier_threshold
+        if isinstance(custom_verifier_models, dict):
+            for n in heads:
+                if custom_verifier_models.get(n, False):
+                    self.custom_verifier_models[n] = pickle.load(open(custom_verifier_models[n], "rb"))
+            if len(self.custom_verifier_models.keys()) < len(custom_verifier_models.keys()):     # model.py:189-195
+                raise ValueError("Custom verifier models were provided, but some were not matched with a base model!"
+                                 " Make sure that the keys provided in the `custom_verifier_models` dictionary argument"
+                                 " exactly match that of the `.models` attribute of an instantiated openWakeWord Model object"
+                                 " that has the same base models but doesn't have custom verifier models.")
+
+        self.prediction_buffer: DefaultDict[str, deque] = defaultdict(partial(deque, maxlen=30))     # model.py:198
+        if enable_speex_noise_suppression:                                       # model.py:201-205 (host library)
+            from speexdsp_ns import NoiseSuppression
+            self.speex_ns = NoiseSuppression.create(160, 16000)
+        else:
+            self.speex_ns = None
+        self.vad_threshold = vad_threshold
+        if vad_threshold > 0:
+            raise ValueError("vad_threshold > 0 needs silero_vad.onnx, whose graph is not part of the reference "
+                             "checkout; the VAD gate is not available in this build (DESIGN.md, out of scope)")
+
+        self._engine = StreamEngine(1, heads, embedding, device=device, max_chunks=max_chunks,
+                                    feature_ring=AudioFeatures.feature_buffer_max_len)
+        self._cols = self._engine.head_cols
+        self.preprocessor = AudioFeatures(self._engine, 0)
+
+    def close(self):
+        self._engine.close()
+
+    # model.py:215-224
+    def get_parent_model_from_label(self, label):
+        parent_model = ""
+        for mdl in self.class_mapping.keys():
+            if label in self.class_mapping[mdl].values():
+                parent_model = mdl
+            elif label in self.class_mapping.keys() and label == mdl:
+                parent_model = mdl
+        return parent_model
+
+    # model.py:226-230
+    def reset(self):
+        self.prediction_buffer = defaultdict(partial(deque, maxlen=30))
+        self.preprocessor.reset()
+
+    def _suppress_noise_with_speex(self, x: np.ndarray, frame_size: int = 160):      # model.py:481-504
+        cleaned = [self.speex_ns.process(x[i:i + frame_size].tobytes()) for i in range(0, x.shape[0], frame_size)]
+        return np.frombuffer(b"".join(cleaned), np.int16)
+
+    # model.py:232-386
+    def predict(self, x: np.ndarray, patience: dict = {}, threshold: dict = {}, debounce_time: float = 0.0,
+                timing: bool = False):
+        if not isinstance(x, np.ndarray):
+            raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(x)}.")
+        import time
+        if timing:
+            timing_dict: Dict[str, Dict] = {"models": {}}
+            t0 = time.time()
+        n_prepared_samples = self.preprocessor(self._suppress_noise_with_speex(x) if self.speex_ns else x)
+        if timing:
+            # the device evaluates mel, embedding and every head in the same call
+            timing_dict["models"]["preprocessor"] = time.time() - t0
+
+        predictions = {}
+        raw = self.preprocessor.last_scores
+        for mdl in self.models.keys():
+            if timing:
+                t1 = time.time()
+            lo, hi = self._cols[mdl]
+            if n_prepared_samples >= 1280:
+                prediction = raw[lo:hi]             # multi-chunk calls: already the max over chunks (model.py:298)
+            else:                                    # model.py:299-307: not enough samples yet
+                if self.model_outputs[mdl] == 1:
+                    prediction = [self.prediction_buffer[mdl][-1]] if len(self.prediction_buffer[mdl]) > 0 else [0]
+                else:
+                    n_classes = max([int(i) for i in self.class_mapping[mdl].keys()])
+                    prediction = [0] * (n_classes + 1)
+            if self.model_outputs[mdl] == 1:
+                predictions[mdl] = prediction[0]
+            else:
+                for int_label, cls in self.class_mapping[mdl].items():
+                    predictions[cls] = prediction[int(int_label)]
+
+            if self.custom_verifier_models != {}:                                # model.py:320-328
+                for cls in predictions.keys():
+                    if predictions[cls] >= self.custom_verifier_threshold:
+                        parent_model = self.get_parent_model_from_label(cls)
+                        if self.custom_verifier_models.get(parent_model, False):
+                            predictions[cls] = self.custom_verifier_models[parent_model].predict_proba(
+                                self.preprocessor.get_features(self.model_inputs[mdl]))[0][-1]
+
+            for cls in predictions.keys():                                       # model.py:331-333
+                if len(self.prediction_buffer[cls]) < 5:
+                    predictions[cls] = 0.0
+            if timing:
+                timing_dict["models"][mdl] = time.time() - t1
+
+        if patience != {} or debounce_time > 0:                                  # model.py:340-359
+            if threshold == {}:
+                raise ValueError("Error! When using the `patience` argument, threshold "
+                                 "values must be provided via the `threshold` argument!")
+            if patience != {} and debounce_time > 0:
+                raise ValueError("Error! The `patience` and `debounce_time` arguments cannot be used together!")
+            for mdl in predictions.keys():
+                parent_model = self.get_parent_model_from_label(mdl)
+                if predictions[mdl] != 0.0:
+                    if parent_model in patience.keys():
+                        scores = np.array(self.prediction_buffer[mdl])[-patience[parent_model]:]
+                        if (scores >= threshold[parent_model]).sum() < patience[parent_model]:
+                            predictions[mdl] = 0.0
+                    elif debounce_time > 0:
+                        if parent_model in threshold.keys():
+                            n_frames = int(np.ceil(debounce_time / (n_prepared_samples / 16000)))
+                            recent_predictions = np.array(self.prediction_buffer[mdl])[-n_frames:]
+                            if predictions[mdl] >= threshold[parent_model] and \
+                               (recent_predictions >= threshold[parent_model]).sum() > 0:
+                                predictions[mdl] = 0.0
+
+        for mdl in predictions.keys():                                           # model.py:362-363
+            self.prediction_buffer[mdl].append(predictions[mdl])
+        return (predictions, timing_dict) if timing else predictions
+
+    # model.py:388-426
+    def predict_clip(self, clip: Union[str, np.ndarray], padding: int = 1, chunk_size=1280, **kwargs):
+        if isinstance(clip, str):
+            with wave.open(clip, mode="rb") as f:
+                data = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
+        elif isinstance(clip, np.ndarray):
+            data = clip
+        if padding:
+            data = np.concatenate((np.zeros(16000 * padding).astype(np.int16), data,
+                                   np.zeros(16000 * padding).astype(np.int16)))
+        predictions = []
+        for i in range(0, data.shape[0] - chunk_size, chunk_size):
+            predictions.append(self.predict(data[i:i + chunk_size], **kwargs))
+        return predictions
+
+    # model.py:428-479
+    def _get_positive_prediction_frames(self, file: str, threshold: float = 0.5, return_type: str = "features", **kwargs):
+        with wave.open(file, mode="rb") as f:
+            data = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
+        positive_data = defaultdict(list)
+        step_size = 1280
+        for i in range(0, data.shape[0] - step_size, step_size):
+            predictions = self.predict(data[i:i + step_size], **kwargs)
+            for lbl in predictions.keys():
+                if predictions[lbl] >= threshold:
+                    mdl = self.get_parent_model_from_label(lbl)
+                    if return_type == "features":
+                        positive_data[lbl].append(self.preprocessor.get_features(self.model_inputs[mdl]))
+                    if return_type == "audio":
+                        context = data[max(0, i - 16000 * 3):i + 16000]
+                        if len(context) == 16000 * 4:
+                            positive_data[lbl].append(context)
+        return {lbl: np.vstack(v) for lbl, v in positive_data.items()}
+
+
+class BatchedModel:
+    """S independent streams behind one object: `predict_batch(pcm[S, 1280*k])` -> fp32 scores [S, n_labels].
+
+    This is the many-stream form the reference lacks (one Python object per stream, utils.py:502-536 forks
+    processes for scale-out).  Post-processing (first-5 zeroing, patience, debounce, 30-deep score ring) runs
+    on the device per stream; `labels` names the score columns in `Model.predict`'s key order."""
+
+    def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict] = "synthetic",
+                 device: int = 0, max_chunks: int = 1, hip_stream: int = 0):
+        seed = 1234 if weights == "synthetic" else (weights.get("seed") if isinstance(weights, dict) else None)
+        given = dict(weights.get("heads", {})) if isinstance(weights, dict) else {}
+        heads = {}
+        for m in wakeword_models:
+            if m in given:
+                heads[m] = given[m]
+            else:
+                name, head = _load_head(m, seed)
+                heads[name] = head
+        emb = weights.get("embedding") if isinstance(weights, dict) else None
+        if emb is None:
+            emb = W.synthetic_embedding(seed if seed is not None else 1234)
+        self.engine = StreamEngine(n_streams, heads, emb, device=device, max_chunks=max_chunks, hip_stream=hip_stream)
+        self.labels: List[str] = []
+        self._keep: List[int] = []
+        col = 0
+        for n, h in heads.items():
+            if h["n_out"] == 1:
+                self.labels.append(n)
+                self._keep.append(col)
+            else:
+                for int_label, cls in model_class_mappings.get(n, {str(j): str(j) for j in range(h["n_out"])}).items():
+                    self.labels.append(cls)
+                    self._keep.append(col + int(int_label))
+            col += h["n_out"]
+        self._parent = {}
+        col = 0
+        for n, h in heads.items():
+            for j in range(h["n_out"]):
+                self._parent[col + j] = n
+            col += h["n_out"]
+        self.n_streams = n_streams
+
+    def set_postproc(self, patience: dict = {}, threshold: dict = {}, debounce_time: float = 0.0, chunk_samples: int = 1280):
+        """Same rules and errors as Model.predict's keyword arguments (model.py:340-359), applied to every stream."""
+        if patience != {} or debounce_time > 0:
+            if threshold == {}:
+                raise ValueError("Error! When using the `patience` argument, threshold "
+                                 "values must be provided via the `threshold` argument!")
+            if patience != {} and debounce_time > 0:
+                raise ValueError("Error! The `patience` and `debounce_time` arguments cannot be used together!")
+        NL = self.engine.n_labels
+        pat = [int(patience.get(self._parent[c], 0)) for c in range(NL)]
+        thr = [float(threshold.get(self._parent[c], np.nan)) for c in range(NL)]
+        frames = int(np.ceil(debounce_time / (chunk_samples / 16000))) if debounce_time > 0 else 0
+        self.engine.set_postproc(pat, thr, frames)
+
+    def reset(self, stream_ids: Optional[Sequence[int]] = None, init_features: Optional[np.ndarray] = None):
+        self.engine.reset(stream_ids, init_features)
+
+    def predict_batch(self, pcm: np.ndarray) -> np.ndarray:
+        if not isinstance(pcm, np.ndarray):
+            raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
+        return self.engine.step(pcm)[:, self._keep]
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,149 @@
+"""The reference's Python surface (openwakeword.Model) on the HIP library, checked against the golden vectors
+that the REFERENCE's own Model / AudioFeatures code produced (tests/golden/make_golden.py) and, shaped after the
+reference's tests (/root/reference/tests/test_models.py), chunk-size invariance, reset and error behaviour."""
+import numpy as np
+import pytest
+
+import cases
+from openwakeword_amd import weights as W
+
+TOL_SCORE = 1e-4          # fp32 path; north_star budget is 1e-3
+
+
+def _weights(names):
+    return {"embedding": W.synthetic_embedding(cases.SEED_WEIGHTS),
+            "heads": {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in names}}
+
+
+# ----------------------------------------------------------------------------- CPU: argument / error behaviour
+def test_constructor_errors_match_reference():
+    from openwakeword_amd import Model
+    with pytest.raises(ValueError, match="Could not find pretrained model"):       # model.py:96-97
+        Model(wakeword_models=["no_such_word"], weights="synthetic")
+    with pytest.raises(ValueError):                                                 # backend selector
+        Model(wakeword_models=["alexa"], inference_framework="onnx")
+    with pytest.raises(ValueError, match="does not exist"):                        # no silent synthetic weights
+        Model(wakeword_models=["alexa"])
+
+
+def test_registry_mirrors_reference():
+    import openwakeword_amd as oww
+    assert list(oww.MODELS) == ["alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather"]
+    assert oww.model_class_mappings["timer"]["6"] == "1_hour_timer"
+    assert len(oww.get_pretrained_model_paths()) == 6
+
+
+# ----------------------------------------------------------------------------- GPU: behaviour
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mdl3():
+    from openwakeword_amd import Model
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=list(cases.HEADS_BINARY), weights=_weights(cases.HEADS_BINARY))
+    yield m
+    m.close()
+
+
+@gpu
+@pytest.mark.parametrize("case", [c for c in cases.CLIP_CASES], ids=[c[0] for c in cases.CLIP_CASES])
+def test_predict_clip_matches_reference_golden(golden, case):
+    """Same clip, same weights, same np.random seed -> the scores the reference's own Model.predict_clip gave."""
+    from openwakeword_amd import Model
+    cid, head_names, clip, kw = case
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=list(head_names), weights=_weights(head_names))
+    try:
+        if cid == "c1280":
+            np.testing.assert_allclose(m.preprocessor.get_features(41)[0], golden["init/feature_buffer"], rtol=0, atol=2e-4)
+        preds = m.predict_clip(golden["pcm/" + clip], **kw)
+        labels = list(golden[cid + "/labels"])
+        assert sorted(preds[0].keys()) == labels
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        want = golden[cid + "/scores"]
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=TOL_SCORE)
+        feats = golden[cid + "/features"]
+        n = min(len(feats), 120)
+        np.testing.assert_allclose(m.preprocessor.get_features(n)[0], feats[-n:], rtol=0, atol=2e-4)
+        if cid == "c1280":
+            np.random.seed(cases.SEED_NP + 1)
+            m.reset()
+            preds2 = m.predict_clip(golden["pcm/hey_mycroft_test"], chunk_size=1280)
+            got2 = np.array([[float(p[k]) for k in labels] for p in preds2])
+            np.testing.assert_allclose(got2, golden["reset/scores"], rtol=0, atol=TOL_SCORE)
+    finally:
+        m.close()
+
+
+@gpu
+def test_predict_argument_errors(mdl3):
+    with pytest.raises(ValueError):                               # model.py:262-263
+        mdl3.predict([0] * 1280)
+    with pytest.raises(ValueError):                               # utils.py:195-197
+        mdl3.predict(np.zeros(1280, np.float32))
+    with pytest.raises(ValueError):                               # model.py:341-343
+        mdl3.predict(np.zeros(1280, np.int16), patience={"alexa": 3})
+    with pytest.raises(ValueError):                               # model.py:344-345
+        mdl3.predict(np.zeros(1280, np.int16), patience={"alexa": 3}, threshold={"alexa": 0.5}, debounce_time=1.0)
+
+
+@gpu
+def test_chunk_size_invariance(golden):
+    """Shaped after test_models.py:68-100: the clip maximum does not depend on how the audio was cut into calls,
+    as long as the calls add up to the same 1280-sample device steps (sub-multiples of 1280 here).  Calls of
+    2x1280 are NOT exactly invariant even in the reference when the weights are not the trained ones (one
+    top_db clamp per call; the reference's own Model gives 0.95190 vs 0.95126 on this clip with these synthetic
+    weights, golden c1280 vs c2560) -- that case is pinned by test_predict_clip_matches_reference_golden."""
+    from openwakeword_amd import Model
+    clip = golden["pcm/alexa_test"]
+    finals = []
+    for chunk in (1280, 640, 320):
+        np.random.seed(3)
+        m = Model(wakeword_models=["alexa"], weights="synthetic")
+        try:
+            preds = m.predict_clip(clip, chunk_size=chunk)
+            finals.append(max(p["alexa"] for p in preds))
+        finally:
+            m.close()
+    np.testing.assert_allclose(finals, finals[0], rtol=0, atol=1e-5)
+
+
+@gpu
+def test_timing_and_attributes(mdl3):
+    out, timing = mdl3.predict(np.zeros(1280, np.int16), timing=True)
+    assert set(out) == set(cases.HEADS_BINARY) and "preprocessor" in timing["models"]
+    assert mdl3.model_inputs == {n: 16 for n in cases.HEADS_BINARY}
+    assert mdl3.model_outputs == {n: 1 for n in cases.HEADS_BINARY}
+    assert mdl3.preprocessor.get_features(16).shape == (1, 16, 96)
+    assert all(len(v) <= 30 for v in mdl3.prediction_buffer.values())
+
+
+@gpu
+def test_batched_model_matches_single_stream_models(golden):
+    from openwakeword_amd import BatchedModel, Model
+    names = list(cases.HEADS_BINARY)
+    w = _weights(names)
+    S, steps = 5, 12
+    pcm = W.synthetic_pcm(S, 1280 * steps, seed=5)
+    pcm[0, : len(golden["pcm/alexa_test"])] = golden["pcm/alexa_test"][: 1280 * steps]
+    bm = BatchedModel(S, names, weights=w)
+    singles = []
+    try:
+        for s in range(S):
+            np.random.seed(100 + s)
+            m = Model(wakeword_models=names, weights=w)
+            singles.append(m)
+            bm.reset([s], m.preprocessor.get_features(16)[0])
+        bm.set_postproc(debounce_time=0.3, threshold={"alexa": 0.4, "hey_mycroft": 0.5})
+        for t in range(steps):
+            x = pcm[:, 1280 * t: 1280 * (t + 1)]
+            got = bm.predict_batch(x)
+            for s in range(S):
+                want = singles[s].predict(x[s], debounce_time=0.3, threshold={"alexa": 0.4, "hey_mycroft": 0.5})
+                np.testing.assert_allclose(got[s], [want[k] for k in bm.labels], rtol=0, atol=TOL_SCORE)
+    finally:
+        bm.close()
+        for m in singles:
+            m.close()
