@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--streams", type=int, default=131072, help="streams per GPU")
     ap.add_argument("--heads", default="alexa,hey_mycroft,hey_jarvis")
     ap.add_argument("--valu", action="store_true", help="plain-VALU kernels instead of MFMA (A/B only)")
+    ap.add_argument("--lds-mfma", action="store_true", help="LDS-tiled MFMA kernels instead of the register-resident ones (A/B only)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the cpu_baseline leg")
@@ -88,7 +89,7 @@ def main():
     # one side stream carries the engine's kernels AND the RCCL gather, so they are ordered without host syncs
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=not args.valu, hip_stream=stream.cuda_stream)
+    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=(0 if args.valu else 2 if args.lds_mfma else 1), hip_stream=stream.cuda_stream)
     NL = eng.n_labels
     eng.reset()
     if args.graph:
@@ -145,7 +146,7 @@ def main():
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
                        "collective": "RCCL gather of scores per step" if world > 1 else "none",
-                       "kernels": "valu" if args.valu else "mfma", "graph": bool(args.graph), "weights": "synthetic seed 1234"},
+                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else "mfma_rr"), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
             "realtime_streams": round(value / 12.5, 1),
             "frames_per_sec_per_gpu": round(value / world, 1),
             "scores_valid": ok,

@@ -14,6 +14,7 @@
 
 #include "owwhip.h"
 #include "owwhip_kernels.h"
+#include "owwhip_rr.h"
 
 using namespace owk;
 
@@ -74,6 +75,23 @@ void pack_mfma(const float* w, int ntaps, int cin, int cout, std::vector<float>&
                 }
 }
 
+// register-resident layout (owwhip_rr.h): out[((((oct*ntaps + tap)*ncti + ct)*64 + lane)*4 + e], lane = (i, j):
+// weight of input channel 16ct+4j+e and output channel 16oct+i
+void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
+    const int ncti = (cin + 15) / 16, ncto = (cout + 15) / 16;
+    out.assign((size_t)ncto * ntaps * ncti * 64 * 4, 0.f);
+    for (int oct = 0; oct < ncto; ++oct)
+        for (int tap = 0; tap < ntaps; ++tap)
+            for (int ct = 0; ct < ncti; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = lane & 15, j = lane >> 4;
+                        const int ci = ct * 16 + 4 * j + e, co = oct * 16 + i;
+                        if (ci < cin && co < cout)
+                            out[((((size_t)oct * ntaps + tap) * ncti + ct) * 64 + lane) * 4 + e] = w[((size_t)tap * cin + ci) * cout + co];
+                    }
+}
+
 struct HostBuf {                      // host image of the device weight buffer (256-byte aligned pieces)
     std::vector<float> data;
     size_t add(const float* p, size_t n) {
@@ -104,7 +122,14 @@ struct FastGroup {
 
 constexpr int N_STATE = 11;
 // per-stream floats of every state array: hist_mel, hist2, B:b,d  C:b,d  D:b,d  E:b,d  hist19
-const int kStateLen[N_STATE] = {64, 1536, 1536, 1536, 1152, 1152, 768, 768, 384, 384, 192};
+const int kStateLenLds[N_STATE] = {64, 1536, 1536, 1536, 1152, 1152, 768, 768, 384, 384, 192};
+// register-resident layout: channel tiles padded to 16 (24->32, 72->80), streams of one wave interleaved per block
+const int kStateLenRr[N_STATE] = {64, 2048, 1536, 1536, 1280, 1280, 768, 768, 384, 384, 384};
+const int kStateSpgRr[N_STATE] = {1, 1, 1, 1, 2, 2, 4, 4, 8, 8, 8};
+const int kStateFposRr[N_STATE] = {16, 16, 16, 16, 8, 8, 4, 4, 2, 2, 1};
+// pooled activations handed from stage to stage, floats per stream: xA, xB, xC, xD
+const int kXLenLds[4] = {1536, 1536, 576, 384};
+const int kXLenRr[4] = {2048, 1536, 640, 384};
 constexpr int DBG_FLOATS = 3 * 6144 + 4 * 3072 + 4 * 2304 + 4 * 768 + 4 * 384 + 96;
 
 struct EventRec { hipEvent_t a, b; int cls; };
@@ -116,6 +141,8 @@ struct oww_ctx {
     int S = 0, Spad = 0, kmax = 1, TR = 16, NL = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false, committed = false, mfma = true;
+    bool rr = true;                   // register-resident CNN kernels (owwhip_rr.h); false = LDS-tiled kernels (MFMA or VALU)
+    const int* state_len = kStateLenRr;
     // host side weights as loaded
     std::vector<float> mel_blob, emb_blob;
     std::vector<HeadHost> heads;
@@ -128,6 +155,7 @@ struct oww_ctx {
     const float* d_conv[20] = {};     // layer 0: natural [9][24]; 1..19: packed (mfma) or natural (valu)
     const float* d_scale[20] = {};
     const float* d_shift[20] = {};
+    const float* d_conv0_mfma = nullptr;   // conv0 in MFMA k-step order (shared by the LDS-MFMA and register-resident kernels)
     NetDesc* d_allnets = nullptr;
     std::vector<FastGroup> groups;
     std::vector<int> generic_nets;    // indices into nets (with verifier right after its primary)
@@ -258,9 +286,64 @@ int run_cnn_t(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     return 0;
 }
 
+// register-resident kernels (owwhip_rr.h): every wave independent, groups of 1 / 1 / 2 / 4 / 8 streams per wave
+template <bool DBG>
+int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
+    using namespace owr;
+    hipStream_t st = h->stream;
+    int off = 0, dbg_off[20];
+    for (int l = 0; l < 20; ++l) { dbg_off[l] = off; off += kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2]; }
+    {
+        RAParams p{};
+        p.mel = h->d_mel; p.mel_stride = mel_stride; p.mel_off = mel_off;
+        p.hist_mel = h->d_state[0]; p.hist2 = h->d_state[1];
+        p.w0 = h->d_conv[0]; p.w1 = h->d_conv[1]; p.w2 = h->d_conv[2];
+        for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
+        p.xout = h->d_xA; p.n_streams = n_active; p.S = h->Spad;
+        p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+        const int grid = std::min((n_active + 3) / 4, 512);           // persistent: 2 workgroups of 4 waves per CU
+        Timed t(h, 1);
+        hipLaunchKernelGGL(rstageA_kernel<DBG>, dim3(grid), dim3(256), 0, st, p);
+    }
+    auto fill = [&](RStageParams& p, const float* xin, float* xout, int first_layer, int sb, int sd, int spt) {
+        p.xin = xin; p.xout = xout; p.hist_b = h->d_state[sb]; p.hist_d = h->d_state[sd];
+        for (int i = 0; i < 4; ++i) {
+            p.w[i] = h->d_conv[first_layer + i]; p.scale[i] = h->d_scale[first_layer + i];
+            p.shift[i] = h->d_shift[first_layer + i]; p.dbg_off[i] = dbg_off[first_layer + i];
+        }
+        p.n_groups = (n_active + spt - 1) / spt; p.S = h->Spad;
+        p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+    };
+    {
+        RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
+        Timed t(h, 2);
+        hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+    }
+    {
+        RStageParams p{}; fill(p, h->d_xB, h->d_xC, 7, 4, 5, RC::SPT);
+        Timed t(h, 3);
+        hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+    }
+    {
+        RStageParams p{}; fill(p, h->d_xC, h->d_xD, 11, 6, 7, RD::SPT);
+        Timed t(h, 4);
+        hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+    }
+    {
+        RStageParams p{}; fill(p, h->d_xD, nullptr, 15, 8, 9, RE::SPT);
+        p.hist19 = h->d_state[10]; p.w19 = h->d_conv[19]; p.feat = h->d_feat; p.emb = h->d_emb; p.nfeat = h->d_nfeat; p.TR = h->TR;
+        p.dbg_off[4] = dbg_off[19];
+        Timed t(h, 5);
+        hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int run_cnn(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     // grids cover whole workgroups of streams: round up to the largest per-workgroup stream count
     n_active = std::min(h->Spad, (n_active + 7) / 8 * 8);
+    if (h->rr) return h->d_dbg ? run_cnn_rr<true>(h, n_active, mel_stride, mel_off) : run_cnn_rr<false>(h, n_active, mel_stride, mel_off);
     return h->mfma ? run_cnn_t<true>(h, n_active, mel_stride, mel_off) : run_cnn_t<false>(h, n_active, mel_stride, mel_off);
 }
 
@@ -334,7 +417,10 @@ int launch_mel(oww_ctx* h, const int16_t* d_pcm, int n_streams, int n_samples, i
 int do_reset(oww_ctx* h, const int* d_ids, int n, const float* d_featinit) {
     ResetParams p{};
     p.ids = d_ids; p.n = n; p.n_arrays = N_STATE;
-    for (int a = 0; a < N_STATE; ++a) { p.dst[a] = h->d_state[a]; p.tmpl[a] = h->d_tmpl[a]; p.len[a] = kStateLen[a]; }
+    for (int a = 0; a < N_STATE; ++a) {
+        p.dst[a] = h->d_state[a]; p.tmpl[a] = h->d_tmpl[a]; p.len[a] = h->state_len[a];
+        p.spg[a] = h->rr ? kStateSpgRr[a] : 1; p.fpos[a] = h->rr ? kStateFposRr[a] : 16;
+    }
     p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.npred = h->d_npred;
     p.ring = h->d_ring; p.ring_len = h->NL * OWW_SCORE_RING;
     p.feat = h->d_feat; p.feat_len = h->TR * OWW_EMB_DIM; p.feat_init = d_featinit;
@@ -410,6 +496,8 @@ int oww_create(const oww_config* cfg, oww_ctx** out) {
     h->Spad = (h->S + 31) / 32 * 32;
     h->kmax = std::max(1, cfg->max_chunks);
     h->mfma = cfg->use_mfma != 0;
+    h->rr = cfg->use_mfma == 1;
+    h->state_len = h->rr ? kStateLenRr : kStateLenLds;
     if (cfg->stream) h->stream = reinterpret_cast<hipStream_t>(cfg->stream);
     else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -522,6 +610,7 @@ int oww_commit(oww_ctx* h) {
             const LayerDef& L = kLayers[l];
             const size_t nw = (size_t)L.kh * L.kw * L.cin * L.cout;
             if (!h->mfma) o_conv[l] = hb.add(q, nw);
+            else if (h->rr && l > 0) { pack_rr(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
             else if (l == 0) {
                 // conv0: K = 9 taps padded to 12 -> three k-steps; lane (i, j) of k-step s holds w[k = 4s+j][cout = 16ct+i]
                 pk.assign(2 * 3 * 64, 0.f);
@@ -534,7 +623,13 @@ int oww_commit(oww_ctx* h) {
                 o_conv[l] = hb.add(pk);
             } else { pack_mfma(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
             q += nw;
-            if (l < 19) { o_scale[l] = hb.add(q, L.cout); q += L.cout; o_shift[l] = hb.add(q, L.cout); q += L.cout; }
+            if (l < 19) {
+                // zero padded to whole 16-channel tiles: the register-resident kernels evaluate the pad channels (as zeros)
+                std::vector<float> pad((size_t)(L.cout + 15) / 16 * 16, 0.f);
+                memcpy(pad.data(), q, L.cout * sizeof(float)); o_scale[l] = hb.add(pad); q += L.cout;
+                std::fill(pad.begin(), pad.end(), 0.f);
+                memcpy(pad.data(), q, L.cout * sizeof(float)); o_shift[l] = hb.add(pad); q += L.cout;
+            }
         }
     }
     // heads: natural arrays for every net (+ packed w2 for hidden==64), fast groups
@@ -619,13 +714,14 @@ int oww_commit(oww_ctx* h) {
     // ---- state ----
     const size_t SP = h->Spad;
     for (int a = 0; a < N_STATE; ++a) {
-        if (int rc = dalloc(&h->d_state[a], SP * kStateLen[a])) return rc;
-        if (int rc = dalloc(&h->d_tmpl[a], (size_t)kStateLen[a])) return rc;
+        if (int rc = dalloc(&h->d_state[a], SP * h->state_len[a])) return rc;
+        if (int rc = dalloc(&h->d_tmpl[a], (size_t)h->state_len[a] * (h->rr ? kStateSpgRr[a] : 1))) return rc;
     }
-    if (int rc = dalloc(&h->d_xA, SP * 1536)) return rc;
-    if (int rc = dalloc(&h->d_xB, SP * 1536)) return rc;
-    if (int rc = dalloc(&h->d_xC, SP * 576)) return rc;
-    if (int rc = dalloc(&h->d_xD, SP * 384)) return rc;
+    const int* xlen = h->rr ? kXLenRr : kXLenLds;
+    if (int rc = dalloc(&h->d_xA, SP * xlen[0])) return rc;
+    if (int rc = dalloc(&h->d_xB, SP * xlen[1])) return rc;
+    if (int rc = dalloc(&h->d_xC, SP * xlen[2])) return rc;
+    if (int rc = dalloc(&h->d_xD, SP * xlen[3])) return rc;
     if (int rc = dalloc(&h->d_mel, SP * 8 * h->kmax * 32)) return rc;
     if (int rc = dalloc(&h->d_feat, SP * h->TR * 96)) return rc;
     if (int rc = dalloc(&h->d_emb, SP * 96)) return rc;
@@ -668,7 +764,8 @@ int oww_commit(oww_ctx* h) {
             if (int rc = run_cnn(h, warm, 256, 0)) return rc;
         h->d_dbg = saved_dbg;
         for (int a = 0; a < N_STATE; ++a)
-            HIPCHK(hipMemcpyAsync(h->d_tmpl[a], h->d_state[a], kStateLen[a] * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_tmpl[a], h->d_state[a], (size_t)h->state_len[a] * (h->rr ? kStateSpgRr[a] : 1) * sizeof(float),
+                                  hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemsetAsync(h->d_mel, 0, SP * 8 * h->kmax * 32 * sizeof(float), h->stream));
         HIPCHK(hipMemsetAsync(h->d_emb, 0, SP * 96 * sizeof(float), h->stream));
         if (int rc = do_reset(h, nullptr, (int)SP, nullptr)) return rc;

@@ -1138,6 +1138,8 @@ struct ResetParams {
     float* dst[16];
     const float* tmpl[16];
     int len[16];             // floats per stream
+    int spg[16];             // streams per group block (register-dump layouts interleave the streams of a wave; 1 = plain)
+    int fpos[16];            // positions per stream inside the 16 positions of a tile (when spg > 1)
     int16_t* tail;
     uint32_t* nfeat;
     uint32_t* npred;
@@ -1149,8 +1151,16 @@ struct ResetParams {
 __global__ void reset_kernel(ResetParams p) {
     const int k = blockIdx.x;
     const int s = p.ids ? p.ids[k] : k;
-    for (int a = 0; a < p.n_arrays; ++a)
-        for (int i = threadIdx.x; i < p.len[a]; i += blockDim.x) p.dst[a][(size_t)s * p.len[a] + i] = p.tmpl[a][i];
+    for (int a = 0; a < p.n_arrays; ++a) {
+        if (p.spg[a] <= 1) {
+            for (int i = threadIdx.x; i < p.len[a]; i += blockDim.x) p.dst[a][(size_t)s * p.len[a] + i] = p.tmpl[a][i];
+        } else {
+            // block of spg streams in register-dump order [..][64 lanes]: stream sp owns the lanes whose position / fpos == sp
+            const int bl = p.len[a] * p.spg[a], g = s / p.spg[a], sp = s % p.spg[a];
+            for (int i = threadIdx.x; i < bl; i += blockDim.x)
+                if (((i & 15) / p.fpos[a]) == sp) p.dst[a][(size_t)g * bl + i] = p.tmpl[a][i];
+        }
+    }
     for (int i = threadIdx.x; i < 480; i += blockDim.x) p.tail[(size_t)s * 480 + i] = 0;
     for (int i = threadIdx.x; i < p.ring_len; i += blockDim.x) p.ring[(size_t)s * p.ring_len + i] = 0.f;
     for (int i = threadIdx.x; i < p.feat_len; i += blockDim.x)

@@ -1,0 +1,783 @@
+// owwhip_rr.h -- register-resident form of the incremental embedding CNN for gfx950 (included by owwhip.hip).
+//
+// Idea.  v_mfma_f32_16x16x4_f32 computes D[16 cout][16 pos] += A[16 cout][4 k] * B[4 k][16 pos] with the lane maps
+//     A: lane (i = l&15, j = l>>4) holds A[i][k=j]          B: lane (p = l&15, j) holds B[k=j][p]
+//     D: lane (p, j), register e of 4 holds D[cout = 4j+e][p]
+// The k index of a convolution is (tap, input channel) and its order is free.  If the k-step "(ct, e)" is defined
+// to carry the four input channels {16ct + 4j + e : j = 0..3}, then the B operand of that k-step is *exactly*
+// register e of the previous layer's output tile ct -- the output registers of one layer are the input operands of
+// the next, with no data movement.  A wave therefore owns whole position tiles (16 positions x all channels) and
+// carries them through the four convolutions of a stage in registers:
+//   * 3x1 (time) taps address other row tiles held by the same wave: a different register, same lane;
+//   * 1x3 (mel) taps are computed as three per-tap accumulators on the UNshifted input and combined in the epilogue
+//     with two DPP row shifts of the 4 accumulator registers (zero fill = the zero padding of the mel axis);
+//   * weights stream from L2 in MFMA operand order (one 16-byte load per lane = four k-steps), each loaded register
+//     feeding NT MFMAs; stage A keeps all of its weights in registers for the whole launch;
+//   * per-stream conv history and the arrays handed from stage to stage are stored in register-dump order
+//     [group][tile][register][64 lanes], i.e. every load/store is one fully coalesced 256-byte row.
+// No LDS, no barrier: every wave is independent, the matrix pipe sees a dense stream of independent MFMAs.
+//
+// Tile geometry per stage (F = mel positions per row, R = new rows per step, C channels):
+//   A: F=32 R=8 C=24   one stream per wave, a row = two tiles (halves), rows processed one after the other
+//   B: F=16 R=4 C=48   tile = one row of one stream,            NT = 4 tiles, 1 stream  per wave
+//   C: F=8  R=4 C=72   tile = one row of 2 streams (8 pos each) NT = 4,       2 streams per wave
+//   D: F=4  R=2 C=96   tile = one row of 4 streams              NT = 2,       4 streams per wave
+//   E: F=2  R=2 C=96   tile = one row of 8 streams              NT = 2,       8 streams per wave (+ conv19)
+// Channel counts that are not multiples of 16 (24, 72) are padded to whole tiles with zero weights / zero BN.
+//
+// Numerics: exact fp32 (the MFMA is a k-ordered fmaf chain); the only difference to the reference graph is the
+// summation order inside a dot product (per-tap partial sums for the 1x3 layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace owr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float leaky_clamp(float x) { return fmaxf(fmaxf(0.2f * x, x), -0.4f); }
+
+// ---- DPP helpers: shifts inside the 16-lane rows (= the 16 positions of a tile; j groups shift alike) ----------
+__device__ __forceinline__ float dpp_shr1_zero(float x) {      // lane p <- x[p-1], lane 0 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shl1_zero(float x) {      // lane p <- x[p+1], lane 15 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_shr1_carry(float x, float c) {   // lane p <- x[p-1], lane 0 <- c[15]
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x121 /*row_ror:1*/, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_shl1_carry(float x, float c) {   // lane p <- x[p+1], lane 15 <- c[0]
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x12F /*row_ror:15*/, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, false));
+}
+
+// combine the three per-tap accumulators of a 1x3 layer: out[p] = a0[p-1] + a1[p] + a2[p+1], zero beyond a
+// stream's F positions (F < 16: several streams share the 16 positions of a tile)
+template <int F>
+__device__ __forceinline__ f32x4 combine_taps(const f32x4 a0, const f32x4 a1, const f32x4 a2, int pos) {
+    f32x4 r;
+    const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float l = dpp_shr1_zero(a0[e]);
+        float h = dpp_shl1_zero(a2[e]);
+        if (F < 16) { l = first ? 0.f : l; h = last ? 0.f : h; }
+        r[e] = (a1[e] + l) + h;
+    }
+    return r;
+}
+
+// An opaque def/use: keeps the epilogue that produced v at this point of the program.  Without it LLVM's IR-level
+// sinking moves the whole per-tile epilogue (tap combine, BatchNorm, activation) down to the first use in the NEXT
+// layer, i.e. keeps the raw accumulators of every output tile alive (~2x the registers, spills).
+__device__ __forceinline__ void pin(f32x4& v) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    v = f32x4{a, b, c, d};
+}
+
+template <bool BN>
+__device__ __forceinline__ f32x4 bn_act(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        int oct, int j) {
+    if (!BN) return v;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + oct * 16 + 4 * j);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + oct * 16 + 4 * j);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = leaky_clamp(v[e] * sc[e] + sh[e]);
+    return r;
+}
+
+// packed weights of one layer: [oct][tap][ct][lane][e]  (lane (i,j), e -> w[tap][cin = 16ct+4j+e][cout = 16oct+i])
+template <int NCTI>
+__device__ __forceinline__ f32x4 load_w(const float* __restrict__ w, int oct, int tap, int ct, int lane) {
+    return *reinterpret_cast<const f32x4*>(w + ((size_t)(((oct * 3 + tap) * NCTI + ct) * 64 + lane)) * 4);
+}
+
+#ifndef OWR_PD
+#define OWR_PD 2      // weight prefetch distance in (oct,tap,ct) iterations
+#endif
+#ifndef OWR_WPS
+#define OWR_WPS 2     // waves per SIMD the register budget is sized for
+#endif
+#ifndef OWR_STAGGER
+#define OWR_STAGGER 0 // 1: waves start with a pseudo-random delay so that co-resident waves do not run their epilogues in lockstep
+#endif
+#ifndef OWR_SCHEDBAR
+#define OWR_SCHEDBAR 1
+#endif
+#if OWR_SCHEDBAR
+#define OWR_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define OWR_SB() do {} while (0)
+#endif
+__device__ __forceinline__ void stagger(int g) {
+#if OWR_STAGGER
+    const int n = (g * 2654435761u >> 27) & 31;       // 0..31 x 64 clocks... up to ~8k cycles
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
+#endif
+}
+
+// 1x3 (mel axis) layer on NT tiles held in registers
+template <int NCTI, int NCTO, int NT, int F, bool BN>
+__device__ __forceinline__ void conv_mel(const f32x4 (&in)[NT][NCTI], f32x4 (&out)[NT][NCTO], const float* __restrict__ w,
+                                         const float* __restrict__ scale, const float* __restrict__ shift, int lane) {
+    const int pos = lane & 15, j = lane >> 4;
+    const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
+    constexpr int NIT = NCTO * 3 * NCTI;
+    f32x4 wq[OWR_PD];
+#pragma unroll
+    for (int u = 0; u < OWR_PD; ++u) wq[u] = load_w<NCTI>(w, (u / NCTI) / 3, (u / NCTI) % 3, u % NCTI, lane);
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        f32x4 res[NT];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < NCTI; ++ct) {
+                const int it = (oct * 3 + tap) * NCTI + ct;
+                const f32x4 a = wq[it % OWR_PD];
+                const int nx = it + OWR_PD;
+                if (nx < NIT) wq[it % OWR_PD] = load_w<NCTI>(w, (nx / NCTI) / 3, (nx / NCTI) % 3, nx % NCTI, lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], in[t][ct][e], acc[t], 0, 0, 0);
+            }
+            // out[p] = tap0[p-1] + tap1[p] + tap2[p+1], zero beyond a stream's F positions
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (tap == 0) { const float l = dpp_shr1_zero(acc[t][e]); res[t][e] = (F < 16 && first) ? 0.f : l; }
+                    else if (tap == 1) res[t][e] += acc[t][e];
+                    else { const float hh = dpp_shl1_zero(acc[t][e]); res[t][e] += (F < 16 && last) ? 0.f : hh; }
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
+    }
+}
+
+// 3x1 (time axis) layer: rows[0..NR+1] are tiles of consecutive rows (two history rows first); out row r uses rows r..r+2
+template <int NCTI, int NCTO, int NR, bool BN>
+__device__ __forceinline__ void conv_time(const f32x4 (&h0)[NCTI], const f32x4 (&h1)[NCTI], const f32x4 (&in)[NR][NCTI],
+                                          f32x4 (&out)[NR][NCTO], const float* __restrict__ w,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, int lane) {
+    const int j = lane >> 4;
+    constexpr int NIT = NCTO * 3 * NCTI;
+    f32x4 wq[OWR_PD];
+#pragma unroll
+    for (int u = 0; u < OWR_PD; ++u) wq[u] = load_w<NCTI>(w, (u / NCTI) / 3, (u / NCTI) % 3, u % NCTI, lane);
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        f32x4 acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int ct = 0; ct < NCTI; ++ct) {
+                const int it = (oct * 3 + tap) * NCTI + ct;
+                const f32x4 a = wq[it % OWR_PD];
+                const int nx = it + OWR_PD;
+                if (nx < NIT) wq[it % OWR_PD] = load_w<NCTI>(w, (nx / NCTI) / 3, (nx / NCTI) % 3, nx % NCTI, lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int src = r + tap;                     // 0,1 = history rows
+                        const int ri = src >= 2 ? src - 2 : 0;
+                        const float b = src == 0 ? h0[ct][e] : (src == 1 ? h1[ct][e] : in[ri][ct][e]);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[r], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { out[r][oct] = bn_act<BN>(acc[r], scale, shift, oct, j); pin(out[r][oct]); }
+    }
+}
+
+// ---- weights streamed through LDS ---------------------------------------------------------------------------
+// Loading every weight register from L2 per wave caps the matrix pipe at ~80 % (all 2048 resident waves pull the same
+// 45-110 KB per layer; measured with tools/ubench).  Instead the four waves of a workgroup share ONE copy: the weights
+// of one output-channel tile ("chunk": 3 taps x NCTI blocks of 1 KB in MFMA operand order) are moved global -> LDS
+// by global_load_lds_dwordx4 (no VGPR staging) into a double buffer while the previous chunk is being consumed with
+// ds_read_b128; one s_waitcnt vmcnt(0) + s_barrier per chunk (every 48*NCTI*NT MFMAs).
+#ifndef OWR_SGB
+#define OWR_SGB 1     // pin the LDS-operand-read / MFMA interleave: reads run OWR_LDSPD blocks ahead, one read per 4*NT MFMAs
+#endif
+#ifndef OWR_LDSPD
+#define OWR_LDSPD 2
+#endif
+#if OWR_SGB
+#define OWR_SGB_PROLOGUE() __builtin_amdgcn_sched_group_barrier(0x100, OWR_LDSPD, 0)
+#define OWR_SGB_STEP(NMFMA) do { __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } while (0)
+#else
+#define OWR_SGB_PROLOGUE() do {} while (0)
+#define OWR_SGB_STEP(NMFMA) do {} while (0)
+#endif
+constexpr int WBUF_FLOATS = 3 * 6 * 256;          // largest chunk: 3 taps x 6 channel tiles x 1 KB
+constexpr int WG_WAVES = 4;
+
+template <int NBLK>
+__device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
+#pragma unroll
+    for (int u = 0; u < (NBLK + WG_WAVES - 1) / WG_WAVES; ++u) {
+        const int i = u * WG_WAVES + wave;
+        if (i < NBLK)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(ldst + i * 256), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void chunk_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+__device__ __forceinline__ f32x4 lds_w(const float* buf, int blk, int lane) {
+    return *reinterpret_cast<const f32x4*>(buf + (blk * 64 + lane) * 4);
+}
+
+// CH0 = running chunk number of this layer's first chunk (selects the buffer parity); NEXT_NBLK = blocks of the chunk
+// that follows this layer's last one (first chunk of the next layer), 0 = none.
+template <int NCTI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK>
+__device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 (&out)[NT][NCTO], float* wbuf,
+                                             const float* __restrict__ w, const float* __restrict__ w_next,
+                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
+    const int pos = lane & 15, j = lane >> 4;
+    const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        if (oct + 1 < NCTO) issue_chunk<3 * NCTI>(w + (size_t)(oct + 1) * 3 * NCTI * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+        f32x4 res[NT];
+        OWR_SGB_PROLOGUE();
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < NCTI; ++ct) {
+                const f32x4 a = lds_w(cur, tap * NCTI + ct, lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], in[t][ct][e], acc[t], 0, 0, 0);
+                OWR_SGB_STEP(4 * NT);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (tap == 0) { const float l = dpp_shr1_zero(acc[t][e]); res[t][e] = (F < 16 && first) ? 0.f : l; }
+                    else if (tap == 1) res[t][e] += acc[t][e];
+                    else { const float hh = dpp_shl1_zero(acc[t][e]); res[t][e] += (F < 16 && last) ? 0.f : hh; }
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
+        __builtin_amdgcn_sched_barrier(0);     // the epilogue of this tile is finished here, not sunk to the end of the layer
+        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+    }
+}
+
+template <int NCTI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK>
+__device__ __forceinline__ void conv_time_lds(const f32x4 (&h0)[NCTI], const f32x4 (&h1)[NCTI], const f32x4 (&in)[NR][NCTI],
+                                              f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w,
+                                              const float* __restrict__ w_next, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, int wave, int lane) {
+    const int j = lane >> 4;
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        if (oct + 1 < NCTO) issue_chunk<3 * NCTI>(w + (size_t)(oct + 1) * 3 * NCTI * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+        f32x4 acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        OWR_SGB_PROLOGUE();
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int ct = 0; ct < NCTI; ++ct) {
+                const f32x4 a = lds_w(cur, tap * NCTI + ct, lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int src = r + tap;
+                        const int ri = src >= 2 ? src - 2 : 0;
+                        const float b = src == 0 ? h0[ct][e] : (src == 1 ? h1[ct][e] : in[ri][ct][e]);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[r], 0, 0, 0);
+                    }
+                OWR_SGB_STEP(4 * NR);
+            }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { out[r][oct] = bn_act<BN>(acc[r], scale, shift, oct, j); pin(out[r][oct]); }
+        __builtin_amdgcn_sched_barrier(0);     // the epilogue of this tile is finished here, not sunk to the end of the layer
+        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+    }
+}
+
+// register-dump I/O: tile = NCT x f32x4 per lane; memory [..][4*NCT registers][64 lanes]
+template <int NCT>
+__device__ __forceinline__ void load_tile(f32x4 (&t)[NCT], const float* __restrict__ base, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[ct][e] = base[(ct * 4 + e) * 64 + lane];
+}
+template <int NCT>
+__device__ __forceinline__ void store_tile(const f32x4 (&t)[NCT], float* __restrict__ base, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
+}
+
+// debug: dense [rows][F][C] dump of a tile row for the streams it holds (tests only)
+template <int NCT, int F, int C>
+__device__ __forceinline__ void dump_tile(const f32x4 (&t)[NCT], float* __restrict__ dbg, size_t stride, int off, int s_first,
+                                          int row, int S, int lane) {
+    const int pos = lane & 15, j = lane >> 4;
+    const int sp = pos / F, f = pos % F, s = s_first + sp;
+    if (s >= S) return;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = ct * 16 + 4 * j + e;
+            if (c < C) dbg[(size_t)s * stride + off + (row * F + f) * C + c] = t[ct][e];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stages B..E
+// ------------------------------------------------------------------------------------------------
+template <int CIN_, int C_, int R_, int F_, int PT_, int PF_, int RP_, int WPS_>
+struct RCfg {
+    static constexpr int WPS = WPS_;                      // waves per SIMD the register allocation is sized for
+    static constexpr int CIN = CIN_, C = C_, R = R_, F = F_, PT = PT_, PF = PF_;
+    // rows per pass: the R new rows are carried through the four layers RP at a time (R/RP passes inside the kernel,
+    // the conv histories going through memory in between) -- halves the live registers of the widest stage
+    static constexpr int RP = RP_, NPASS = R_ / RP_;
+    static_assert(R_ % RP_ == 0 && RP_ % PT_ == 0, "passes are whole pooling groups");
+    static constexpr int NCTI = (CIN + 15) / 16, NCT = (C + 15) / 16;
+    static constexpr int SPT = 16 / F;                    // streams per tile = streams per wave
+    static constexpr int XIN_FLOATS = R * NCTI * 4 * 64;  // per group
+    static constexpr int HIST_FLOATS = 2 * NCT * 4 * 64;  // per group, per history array
+    static constexpr int RO = R / PT, FO = F / PF;
+    static constexpr int WAVES = 4;
+};
+#ifndef OWR_RC_RP
+#define OWR_RC_RP 4
+#endif
+#ifndef OWR_WPS_B
+#define OWR_WPS_B 2
+#endif
+#ifndef OWR_WPS_C
+#define OWR_WPS_C 2
+#endif
+#ifndef OWR_WPS_D
+#define OWR_WPS_D 2
+#endif
+#ifndef OWR_WPS_E
+#define OWR_WPS_E 2
+#endif
+using RB = RCfg<24, 48, 4, 16, 1, 2, 4, OWR_WPS_B>;
+using RC = RCfg<48, 72, 4, 8, 2, 2, OWR_RC_RP, OWR_WPS_C>;
+using RD = RCfg<72, 96, 2, 4, 1, 2, 2, OWR_WPS_D>;
+using RE = RCfg<96, 96, 2, 2, 2, 2, 2, OWR_WPS_E>;
+
+struct RStageParams {
+    const float* xin;      // [G][R][4*NCTI][64]
+    float* xout;           // next stage's xin (its own geometry)
+    float* hist_b;         // [G][2][4*NCT][64]
+    float* hist_d;
+    const float* w[4];     // rr-packed
+    const float* scale[4]; // padded to NCT*16
+    const float* shift[4];
+    int n_groups;          // groups (waves) to run
+    int S;                 // streams (debug / ring bounds)
+    // last stage
+    float* hist19;         // [G][2][24][64]
+    const float* w19;
+    float* feat;           // [S][TR][96]
+    float* emb;            // [S][96]
+    const uint32_t* nfeat;
+    int TR;
+    float* dbg;
+    size_t dbg_stride;
+    int dbg_off[5];
+};
+
+// max-pool PT x PF of the stage output and scatter into the next stage's register-dump layout
+//   next geometry: Fn = F/PF positions per stream, SPTn = 16/Fn streams per tile, rows RO, NCT channel tiles
+template <class C>
+__device__ __forceinline__ void pool_store(const f32x4 (&y)[C::RP][C::NCT], float* __restrict__ xout, int g, int ro0, int lane) {
+    constexpr int F = C::F, FO = C::FO, RO = C::RO, NCT = C::NCT;
+    constexpr int SPTN = 16 / FO;
+    const int pos = lane & 15, j = lane >> 4;
+    const int sp = pos / F, f = pos % F;
+    const int s = g * C::SPT + sp;                         // global stream of this lane
+    const int gn = s / SPTN, spn = s % SPTN;
+    const int posn = spn * FO + f / 2;
+    const bool writer = (f & 1) == 0;
+#pragma unroll
+    for (int ro = 0; ro < C::RP / C::PT; ++ro)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = y[ro * C::PT][ct][e];
+                if (C::PT == 2) m = fmaxf(m, y[ro * C::PT + 1][ct][e]);
+                m = fmaxf(m, dpp_shl1_zero(m));            // pair (f, f+1); valid on even f
+                if (writer) xout[((size_t)(gn * RO + ro0 + ro) * (NCT * 4) + ct * 4 + e) * 64 + j * 16 + posn] = m;
+            }
+}
+
+#ifndef OWR_WLDS
+#define OWR_WLDS 1    // 1: weights streamed through LDS once per workgroup; 0: every wave loads its operand registers from L2
+#endif
+
+template <class C, bool LAST, bool DBG>
+__global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
+    constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::R, RP = C::RP, F = C::F;
+    static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
+    constexpr int NBA = 3 * NCTI, NB = 3 * NCT;             // 1 KB blocks per chunk: first layer / other layers
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: addresses built from it stay in SGPRs
+    int g = blockIdx.x * C::WAVES + wave;
+#if OWR_WLDS
+    __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
+    // folded BatchNorm of the four layers in LDS: global loads of them would be hoisted over the chunk barriers into
+    // ~50 live registers; LDS reads stay inside their chunk
+    __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
+    const bool active = g < p.n_groups;                      // every wave keeps running (workgroup barriers); idle ones recompute
+    if (!active) g = p.n_groups - 1;                         // the last group and store nothing
+    issue_chunk<NBA>(p.w[0], wbuf, wave, lane);
+    for (int i = threadIdx.x; i < 4 * NCT * 16; i += 256) {
+        const int l = i / (NCT * 16), c = i % (NCT * 16);
+        sbn[l][0][c] = p.scale[l][c];
+        sbn[l][1][c] = p.shift[l][c];
+    }
+#else
+    if (g >= p.n_groups) return;
+    const bool active = true;
+#endif
+    const int s_first = g * C::SPT;
+    stagger(g);
+
+    float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
+    float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
+    f32x4 Yd[RP][NCT];
+#pragma unroll 1
+    for (int pass = 0; pass < C::NPASS; ++pass) {
+    f32x4 X[RP][NCTI];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) load_tile<NCTI>(X[r], p.xin + ((size_t)g * R + pass * RP + r) * (NCTI * 4 * 64), lane);
+#if OWR_WLDS
+    if (pass == 0) chunk_sync();
+#endif
+
+    // conv a: 1x3, CIN -> C
+    f32x4 Ya[RP][NCT];
+#if OWR_WLDS
+    conv_mel_lds<NCTI, NCT, RP, F, true, 0, NB>(X, Ya, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
+#else
+    conv_mel<NCTI, NCT, RP, F, true>(X, Ya, p.w[0], p.scale[0], p.shift[0], lane);
+#endif
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Ya[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * RP + r, p.S, lane);
+    }
+    OWR_SB();
+    // conv b: 3x1 over [hist_b(2) ; Ya]
+    f32x4 H0[NCT], H1[NCT];
+    load_tile<NCT>(H0, hb, lane);
+    load_tile<NCT>(H1, hb + NCT * 4 * 64, lane);
+    f32x4 Yb[RP][NCT];
+#if OWR_WLDS
+    conv_time_lds<NCT, NCT, RP, true, NCT, NB>(H0, H1, Ya, Yb, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane);
+#else
+    conv_time<NCT, NCT, RP, true>(H0, H1, Ya, Yb, p.w[1], p.scale[1], p.shift[1], lane);
+#endif
+    if (active) {
+        store_tile<NCT>(Ya[RP - 2], hb, lane);
+        store_tile<NCT>(Ya[RP - 1], hb + NCT * 4 * 64, lane);
+    }
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Yb[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * RP + r, p.S, lane);
+    }
+    OWR_SB();
+    // conv c: 1x3
+    f32x4 Yc[RP][NCT];
+#if OWR_WLDS
+    conv_mel_lds<NCT, NCT, RP, F, true, 2 * NCT, NB>(Yb, Yc, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
+#else
+    conv_mel<NCT, NCT, RP, F, true>(Yb, Yc, p.w[2], p.scale[2], p.shift[2], lane);
+#endif
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Yc[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * RP + r, p.S, lane);
+    }
+    OWR_SB();
+    // conv d: 3x1 over [hist_d(2) ; Yc]
+    load_tile<NCT>(H0, hd, lane);
+    load_tile<NCT>(H1, hd + NCT * 4 * 64, lane);
+#if OWR_WLDS
+    conv_time_lds<NCT, NCT, RP, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0))>(H0, H1, Yc, Yd, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], wave, lane);
+#else
+    conv_time<NCT, NCT, RP, true>(H0, H1, Yc, Yd, p.w[3], p.scale[3], p.shift[3], lane);
+#endif
+    if (active) {
+        store_tile<NCT>(Yc[RP - 2], hd, lane);
+        store_tile<NCT>(Yc[RP - 1], hd + NCT * 4 * 64, lane);
+    }
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Yd[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * RP + r, p.S, lane);
+    }
+
+    if (!LAST && active) pool_store<C>(Yd, p.xout, g, pass * (RP / C::PT), lane);
+    }   // pass
+#if OWR_WLDS
+    if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last pass prefetched a chunk nobody uses: drain it
+#endif
+
+    if (LAST) {
+        // pool 2x2 -> one position per stream (even lanes), compact to lanes pos' = stream via the LDS crossbar,
+        // then conv19: 3x1 96->96 without BN/activation over [hist19(2) ; pooled]
+        static_assert(!LAST || (C::RO == 1 && C::FO == 1 && NCT == 6), "last stage pools to one position, 96 channels");
+        const int pos = lane & 15, j = lane >> 4;
+        f32x4 Pl[1][NCT];
+        const int src = (j * 16 + 2 * (pos & 7)) * 4;                    // byte address of the source lane
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = fmaxf(Yd[0][ct][e], Yd[1][ct][e]);
+                m = fmaxf(m, dpp_shl1_zero(m));
+                Pl[0][ct][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, m)));
+            }
+        float* h19 = p.hist19 + (size_t)g * (2 * NCT * 4 * 64);
+        f32x4 H0[NCT], H1[NCT];
+        load_tile<NCT>(H0, h19, lane);
+        load_tile<NCT>(H1, h19 + NCT * 4 * 64, lane);
+        f32x4 E[1][NCT];
+#if OWR_WLDS
+        conv_time_lds<NCT, NCT, 1, false, 4 * NCT, 0>(H0, H1, Pl, E, wbuf, p.w19, nullptr, nullptr, nullptr, wave, lane);
+#else
+        conv_time<NCT, NCT, 1, false>(H0, H1, Pl, E, p.w19, nullptr, nullptr, lane);
+#endif
+        if (active) {
+            store_tile<NCT>(H1, h19, lane);
+            store_tile<NCT>(Pl[0], h19 + NCT * 4 * 64, lane);
+        }
+        const int s = s_first + pos;
+        if (active && pos < C::SPT && s < p.S) {
+            const uint32_t slot = p.nfeat[s] % (uint32_t)p.TR;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                *reinterpret_cast<f32x4*>(p.feat + ((size_t)s * p.TR + slot) * 96 + ct * 16 + 4 * j) = E[0][ct];
+                *reinterpret_cast<f32x4*>(p.emb + (size_t)s * 96 + ct * 16 + 4 * j) = E[0][ct];
+                if (DBG && p.dbg) *reinterpret_cast<f32x4*>(p.dbg + (size_t)s * p.dbg_stride + p.dbg_off[4] + ct * 16 + 4 * j) = E[0][ct];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage A: mel rows -> conv0 3x3 (1->24, ReLU, BN, act) -> conv1 1x3 -> conv2 3x1 -> pool 2x2
+// one stream per wave at a time, persistent over streams; conv1/conv2 weights live in registers
+// ------------------------------------------------------------------------------------------------
+struct RAParams {
+    const float* mel;      // [S][mel_stride], chunk rows at mel_off
+    int mel_stride, mel_off;
+    float* hist_mel;       // [S][2][32]
+    float* hist2;          // [S][2 rows][2 halves][8][64]  conv2 input history (register dump)
+    const float* w0;       // [2 oct][3 ksteps][64]
+    const float* w1;       // rr-packed, NCTI = 2
+    const float* w2;
+    const float* scale[3]; // padded to 32
+    const float* shift[3];
+    float* xout;           // stage B xin: [S][4][8][64]
+    int n_streams;         // streams to run
+    int S;
+    float* dbg;
+    size_t dbg_stride;
+    int dbg_off[3];
+};
+
+template <bool DBG>
+__global__ __launch_bounds__(256, OWR_WPS) void rstageA_kernel(RAParams p) {
+    const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = gridDim.x * 4;
+
+    // conv1 / conv2 weights (24 KB, MFMA operand order) -> LDS once per workgroup; conv0's six operand registers stay in VGPRs
+    __shared__ __attribute__((aligned(16))) float sW[2][2 * 3 * 2 * 64 * 4];
+    for (int i = threadIdx.x; i < 2 * 3 * 2 * 64; i += 256) {
+        reinterpret_cast<f32x4*>(sW[0])[i] = reinterpret_cast<const f32x4*>(p.w1)[i];
+        reinterpret_cast<f32x4*>(sW[1])[i] = reinterpret_cast<const f32x4*>(p.w2)[i];
+    }
+    float W0[2][3];
+#pragma unroll
+    for (int oct = 0; oct < 2; ++oct)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) W0[oct][k] = p.w0[(oct * 3 + k) * 64 + lane];
+    __syncthreads();
+    const f32x4* sW1b = reinterpret_cast<const f32x4*>(sW[0]) + lane;    // [(oct*3+tap)*2+ct][64 lanes]
+    const f32x4* sW2b = reinterpret_cast<const f32x4*>(sW[1]) + lane;
+    // conv0 operand gather: k-step ks carries tap 4ks+j = (dt, df)
+    int dt[3], df[3];
+    bool kv[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + j; kv[ks] = k < 9; dt[ks] = (k < 9 ? k : 0) / 3; df[ks] = (k < 9 ? k : 0) % 3; }
+
+    stagger(gw);
+    for (int s = gw; s < p.n_streams; s += nw) {
+        const float* mel = p.mel + (size_t)s * p.mel_stride + p.mel_off;
+        float* hm = p.hist_mel + (size_t)s * 64;
+        float* h2 = p.hist2 + (size_t)s * (2 * 2 * 8 * 64);
+        f32x4 Ym2[2][2], Ym1[2][2];                 // conv1 output rows r-2, r-1  [half][ct]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { load_tile<2>(Ym2[h], h2 + (0 * 2 + h) * 512, lane); load_tile<2>(Ym1[h], h2 + (1 * 2 + h) * 512, lane); }
+        f32x4 Y2p[2][2];                            // previous conv2 row (pool partner)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            // an opaque zero: keeps the (loop-invariant) LDS weight reads and BN loads inside the row instead of having
+            // them hoisted into ~150 live registers
+            OWR_SB();
+            int z = 0;
+            asm volatile("" : "+s"(z));
+            const f32x4* sW1 = sW1b + z;
+            const f32x4* sW2 = sW2b + z;
+            const float* sc0 = p.scale[0] + z; const float* sh0 = p.shift[0] + z;
+            const float* sc1 = p.scale[1] + z; const float* sh1 = p.shift[1] + z;
+            const float* sc2 = p.scale[2] + z; const float* sh2 = p.shift[2] + z;
+            // ---- conv0 row r: rows r..r+2 of [hist_mel(2) ; mel(8)], zero padded in mel
+            f32x4 Y0[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float b[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int rr = r + dt[ks], f = h * 16 + pos + df[ks] - 1;
+                    float v = 0.f;
+                    if (kv[ks] && f >= 0 && f < 32) v = rr < 2 ? hm[rr * 32 + f] : mel[(rr - 2) * 32 + f];
+                    b[ks] = v;
+                }
+#pragma unroll
+                for (int oct = 0; oct < 2; ++oct) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W0[oct][ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+                    Y0[h][oct] = bn_act<true>(acc, sc0, sh0, oct, j);
+                    pin(Y0[h][oct]);
+                }
+                if (DBG && p.dbg) dump_tile<2, 16, 24>(Y0[h], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
+            }
+            // ---- conv1 (1x3 over the 32 mel positions = two halves with carries across the seam)
+            f32x4 Y1[2][2];
+#pragma unroll
+            for (int oct = 0; oct < 2; ++oct) {
+                f32x4 acc[3][2];
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) { acc[tap][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[tap][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const f32x4 a = sW1[((oct * 3 + tap) * 2 + ct) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                acc[tap][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], Y0[h][ct][e], acc[tap][h], 0, 0, 0);
+                    }
+                f32x4 r0, r1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[e] = (acc[1][0][e] + dpp_shr1_zero(acc[0][0][e])) + dpp_shl1_carry(acc[2][0][e], acc[2][1][e]);
+                    r1[e] = (acc[1][1][e] + dpp_shr1_carry(acc[0][1][e], acc[0][0][e])) + dpp_shl1_zero(acc[2][1][e]);
+                }
+                Y1[0][oct] = bn_act<true>(r0, sc1, sh1, oct, j);
+                Y1[1][oct] = bn_act<true>(r1, sc1, sh1, oct, j);
+                pin(Y1[0][oct]); pin(Y1[1][oct]);
+            }
+            if (DBG && p.dbg) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) dump_tile<2, 16, 24>(Y1[h], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[1], s, r * 2, p.S, lane);
+            }
+            // ---- conv2 (3x1) over rows (r-2, r-1, r) of conv1's output
+            f32x4 Y2[2][2];
+#pragma unroll
+            for (int oct = 0; oct < 2; ++oct) {
+                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const f32x4 a = sW2[((oct * 3 + tap) * 2 + ct) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float b = tap == 0 ? Ym2[h][ct][e] : (tap == 1 ? Ym1[h][ct][e] : Y1[h][ct][e]);
+                                acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[h], 0, 0, 0);
+                            }
+                    }
+                Y2[0][oct] = bn_act<true>(acc[0], sc2, sh2, oct, j);
+                Y2[1][oct] = bn_act<true>(acc[1], sc2, sh2, oct, j);
+                pin(Y2[0][oct]); pin(Y2[1][oct]);
+            }
+            if (DBG && p.dbg) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) dump_tile<2, 16, 24>(Y2[h], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[2], s, r * 2, p.S, lane);
+            }
+            // rotate the conv2 input window
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { Ym2[h][ct] = Ym1[h][ct]; Ym1[h][ct] = Y1[h][ct]; }
+            // ---- pool 2x2 -> stage B input row r/2: 16 positions = pooled f of both halves
+            if (r & 1) {
+                float* xo = p.xout + ((size_t)s * 4 + (r >> 1)) * (8 * 64);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float m = fmaxf(Y2p[h][ct][e], Y2[h][ct][e]);
+                            m = fmaxf(m, dpp_shl1_zero(m));
+                            if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
+                        }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) Y2p[h][ct] = Y2[h][ct];
+            }
+        }
+        // new histories: conv1 rows 6,7 (now in Ym2, Ym1) and mel rows 6,7
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { store_tile<2>(Ym2[h], h2 + (0 * 2 + h) * 512, lane); store_tile<2>(Ym1[h], h2 + (1 * 2 + h) * 512, lane); }
+        hm[lane] = mel[6 * 32 + lane];
+    }
+}
+
+}  // namespace owr

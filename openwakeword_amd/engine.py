@@ -75,7 +75,7 @@ class StreamEngine:
     """One GPU, S streams.  `heads` maps model name -> head dict (see weights.synthetic_head)."""
 
     def __init__(self, n_streams: int, heads: Dict[str, dict], embedding: Optional[dict] = None,
-                 device: int = 0, max_chunks: int = 1, use_mfma: bool = True, debug_layers: bool = False,
+                 device: int = 0, max_chunks: int = 1, use_mfma: int = 1, debug_layers: bool = False,
                  feature_ring: int = 0, hip_stream: int = 0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
@@ -83,7 +83,7 @@ class StreamEngine:
         self.max_chunks = int(max_chunks)
         self.head_names = list(heads.keys())
         self.heads = heads
-        cfg = _lib.Config(int(device), self.n_streams, self.max_chunks, int(feature_ring), int(bool(use_mfma)),
+        cfg = _lib.Config(int(device), self.n_streams, self.max_chunks, int(feature_ring), int(use_mfma),
                           int(bool(debug_layers)), C.c_void_p(hip_stream) if hip_stream else None)
         _lib.check(self._lib.oww_create(C.byref(cfg), C.byref(self._h)))
         try:

@@ -12,7 +12,10 @@ def short(name):
     name = name.replace("void ", "").replace("owk::", "")
     for tag, s in (("StageCfg<24, 48", "stageB"), ("StageCfg<48, 72", "stageC"), ("StageCfg<72, 96", "stageD"), ("StageCfg<96, 96", "stageE")):
         if tag in name:
-            return s + ("(valu)" if ", false, " in name.split(">")[1] else "")
+            return s + ("_lds(valu)" if ", false, " in name.split(">")[1] else "_lds")
+    for tag, s in (("RCfg<24, 48", "stageB"), ("RCfg<48, 72", "stageC"), ("RCfg<72, 96", "stageD"), ("RCfg<96, 96", "stageE"), ("rstageA_kernel", "stageA")):
+        if tag in name:
+            return s + "_rr"
     return name.split("(")[0][:60]
 
 
@@ -48,7 +51,7 @@ def main():
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"\ncounters from {path} (mean per full-grid launch)")
         for k in sorted(agg):
-            if k.startswith(("stage", "mel", "heads")):
+            if k.startswith(("stage", "mel", "heads", "r")):
                 print(f"  {k:20s} " + "  ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(agg[k].items())))
 
 
