@@ -77,8 +77,11 @@ void pack_mfma(const float* w, int ntaps, int cin, int cout, std::vector<float>&
 
 // register-resident layout (owwhip_rr.h): out[((((oct*ntaps + tap)*ncti + ct)*64 + lane)*4 + e], lane = (i, j):
 // weight of input channel 16ct+4j+e and output channel 16oct+i
+// a half-filled last input-channel tile (cin % 16 == 8) is consumed in pack_half order: two k-steps, lane (i, j) of
+// k-step e' < 2 carrying channel 16ct + 4(j&1) + 2e' + (j>>1); k-steps 2,3 of that block are not executed
 void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
     const int ncti = (cin + 15) / 16, ncto = (cout + 15) / 16;
+    const bool half_in = cin % 16 == 8;
     out.assign((size_t)ncto * ntaps * ncti * 64 * 4, 0.f);
     for (int oct = 0; oct < ncto; ++oct)
         for (int tap = 0; tap < ntaps; ++tap)
@@ -86,7 +89,9 @@ void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 4; ++e) {
                         const int i = lane & 15, j = lane >> 4;
-                        const int ci = ct * 16 + 4 * j + e, co = oct * 16 + i;
+                        int ci = ct * 16 + 4 * j + e;
+                        if (half_in && ct == ncti - 1) ci = e < 2 ? ct * 16 + 4 * (j & 1) + 2 * e + (j >> 1) : cin;
+                        const int co = oct * 16 + i;
                         if (ci < cin && co < cout)
                             out[((((size_t)oct * ntaps + tap) * ncti + ct) * 64 + lane) * 4 + e] = w[((size_t)tap * cin + ci) * cout + co];
                     }
@@ -301,7 +306,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
         p.xout = h->d_xA; p.n_streams = n_active; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
-        const int grid = std::min((n_active + 3) / 4, 512);           // persistent: 2 workgroups of 4 waves per CU
+        const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
         Timed t(h, 1);
         hipLaunchKernelGGL(rstageA_kernel<DBG>, dim3(grid), dim3(256), 0, st, p);
     }

@@ -78,6 +78,20 @@ __device__ __forceinline__ void pin(f32x4& v) {
     v = f32x4{a, b, c, d};
 }
 
+// Channel counts with C % 16 == 8 (24, 72) leave the last channel tile half empty: lanes j = 2,3 of its four registers
+// carry no channel.  As an MFMA B operand that would waste half of four k-steps, so the tile is re-packed into TWO full
+// registers with v_permlane32_swap: P0 = [e0 | e1], P1 = [e2 | e3] (lower 32 lanes | upper 32 lanes), i.e. lane (p, j)
+// of P_e' carries channel 16ct + 4(j&1) + 2e' + (j>>1).  The weight packing (pack_rr, host) uses the same k order.
+__device__ __forceinline__ f32x4 pack_half(const f32x4 v) {
+    // inline asm on purpose: __builtin_amdgcn_permlane32_swap mis-models its second result on this toolchain (tools/ubench/
+    // lane_test.hip); the instruction swaps lanes 32..63 of its first operand with lanes 0..31 of the second, in place.
+    // s_nop: hipcc inserts no hazard wait states around asm operands (VALU write -> lane-crossing read, and -> MFMA read).
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return f32x4{a, c, 0.f, 0.f};
+}
+
 template <bool BN>
 __device__ __forceinline__ f32x4 bn_act(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift,
                                         int oct, int j) {
@@ -245,7 +259,7 @@ __device__ __forceinline__ f32x4 lds_w(const float* buf, int blk, int lane) {
 
 // CH0 = running chunk number of this layer's first chunk (selects the buffer parity); NEXT_NBLK = blocks of the chunk
 // that follows this layer's last one (first chunk of the next layer), 0 = none.
-template <int NCTI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK>
+template <int NCTI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, bool HIN = false, bool HOUT = false>
 __device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
@@ -267,12 +281,13 @@ __device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 
 #pragma unroll
             for (int ct = 0; ct < NCTI; ++ct) {
                 const f32x4 a = lds_w(cur, tap * NCTI + ct, lane);
+                const int ne = (HIN && ct == NCTI - 1) ? 2 : 4;       // packed half tile: two k-steps
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], in[t][ct][e], acc[t], 0, 0, 0);
-                OWR_SGB_STEP(4 * NT);
+                        if (e < ne) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], in[t][ct][e], acc[t], 0, 0, 0);
+                if (HIN && ct == NCTI - 1) OWR_SGB_STEP(2 * NT); else OWR_SGB_STEP(4 * NT);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -284,13 +299,17 @@ __device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 
                 }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
+        for (int t = 0; t < NT; ++t) {
+            out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j);
+            pin(out[t][oct]);
+            if (HOUT && oct == NCTO - 1) { out[t][oct] = pack_half(out[t][oct]); pin(out[t][oct]); }
+        }
         __builtin_amdgcn_sched_barrier(0);     // the epilogue of this tile is finished here, not sunk to the end of the layer
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
     }
 }
 
-template <int NCTI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK>
+template <int NCTI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, bool HIN = false, bool HOUT = false>
 __device__ __forceinline__ void conv_time_lds(const f32x4 (&h0)[NCTI], const f32x4 (&h1)[NCTI], const f32x4 (&in)[NR][NCTI],
                                               f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w,
                                               const float* __restrict__ w_next, const float* __restrict__ scale,
@@ -311,6 +330,7 @@ __device__ __forceinline__ void conv_time_lds(const f32x4 (&h0)[NCTI], const f32
 #pragma unroll
             for (int ct = 0; ct < NCTI; ++ct) {
                 const f32x4 a = lds_w(cur, tap * NCTI + ct, lane);
+                const int ne = (HIN && ct == NCTI - 1) ? 2 : 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -318,12 +338,16 @@ __device__ __forceinline__ void conv_time_lds(const f32x4 (&h0)[NCTI], const f32
                         const int src = r + tap;
                         const int ri = src >= 2 ? src - 2 : 0;
                         const float b = src == 0 ? h0[ct][e] : (src == 1 ? h1[ct][e] : in[ri][ct][e]);
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[r], 0, 0, 0);
+                        if (e < ne) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[r], 0, 0, 0);
                     }
-                OWR_SGB_STEP(4 * NR);
+                if (HIN && ct == NCTI - 1) OWR_SGB_STEP(2 * NR); else OWR_SGB_STEP(4 * NR);
             }
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { out[r][oct] = bn_act<BN>(acc[r], scale, shift, oct, j); pin(out[r][oct]); }
+        for (int r = 0; r < NR; ++r) {
+            out[r][oct] = bn_act<BN>(acc[r], scale, shift, oct, j);
+            pin(out[r][oct]);
+            if (HOUT && oct == NCTO - 1) { out[r][oct] = pack_half(out[r][oct]); pin(out[r][oct]); }
+        }
         __builtin_amdgcn_sched_barrier(0);     // the epilogue of this tile is finished here, not sunk to the end of the layer
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
     }
@@ -346,7 +370,7 @@ __device__ __forceinline__ void store_tile(const f32x4 (&t)[NCT], float* __restr
 }
 
 // debug: dense [rows][F][C] dump of a tile row for the streams it holds (tests only)
-template <int NCT, int F, int C>
+template <int NCT, int F, int C, bool PACKED = false>
 __device__ __forceinline__ void dump_tile(const f32x4 (&t)[NCT], float* __restrict__ dbg, size_t stride, int off, int s_first,
                                           int row, int S, int lane) {
     const int pos = lane & 15, j = lane >> 4;
@@ -356,7 +380,8 @@ __device__ __forceinline__ void dump_tile(const f32x4 (&t)[NCT], float* __restri
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = ct * 16 + 4 * j + e;
+            int c = ct * 16 + 4 * j + e;
+            if (PACKED && ct == NCT - 1) c = e < 2 ? ct * 16 + 4 * (j & 1) + 2 * e + (j >> 1) : C;   // pack_half order
             if (c < C) dbg[(size_t)s * stride + off + (row * F + f) * C + c] = t[ct][e];
         }
 }
@@ -373,6 +398,7 @@ struct RCfg {
     static constexpr int RP = RP_, NPASS = R_ / RP_;
     static_assert(R_ % RP_ == 0 && RP_ % PT_ == 0, "passes are whole pooling groups");
     static constexpr int NCTI = (CIN + 15) / 16, NCT = (C + 15) / 16;
+    static constexpr bool HIN = CIN % 16 == 8, HOUT = C % 16 == 8;     // half last channel tile: kept re-packed (pack_half)
     static constexpr int SPT = 16 / F;                    // streams per tile = streams per wave
     static constexpr int XIN_FLOATS = R * NCTI * 4 * 64;  // per group
     static constexpr int HIST_FLOATS = 2 * NCT * 4 * 64;  // per group, per history array
@@ -446,10 +472,6 @@ __device__ __forceinline__ void pool_store(const f32x4 (&y)[C::RP][C::NCT], floa
             }
 }
 
-#ifndef OWR_WLDS
-#define OWR_WLDS 1    // 1: weights streamed through LDS once per workgroup; 0: every wave loads its operand registers from L2
-#endif
-
 template <class C, bool LAST, bool DBG>
 __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::R, RP = C::RP, F = C::F;
@@ -458,7 +480,6 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: addresses built from it stay in SGPRs
     int g = blockIdx.x * C::WAVES + wave;
-#if OWR_WLDS
     __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
     // folded BatchNorm of the four layers in LDS: global loads of them would be hoisted over the chunk barriers into
     // ~50 live registers; LDS reads stay inside their chunk
@@ -471,10 +492,6 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         sbn[l][0][c] = p.scale[l][c];
         sbn[l][1][c] = p.shift[l][c];
     }
-#else
-    if (g >= p.n_groups) return;
-    const bool active = true;
-#endif
     const int s_first = g * C::SPT;
     stagger(g);
 
@@ -486,20 +503,14 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     f32x4 X[RP][NCTI];
 #pragma unroll
     for (int r = 0; r < RP; ++r) load_tile<NCTI>(X[r], p.xin + ((size_t)g * R + pass * RP + r) * (NCTI * 4 * 64), lane);
-#if OWR_WLDS
     if (pass == 0) chunk_sync();
-#endif
 
     // conv a: 1x3, CIN -> C
     f32x4 Ya[RP][NCT];
-#if OWR_WLDS
-    conv_mel_lds<NCTI, NCT, RP, F, true, 0, NB>(X, Ya, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
-#else
-    conv_mel<NCTI, NCT, RP, F, true>(X, Ya, p.w[0], p.scale[0], p.shift[0], lane);
-#endif
+    conv_mel_lds<NCTI, NCT, RP, F, true, 0, NB, C::HIN, C::HOUT>(X, Ya, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Ya[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * RP + r, p.S, lane);
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C, C::HOUT>(Ya[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * RP + r, p.S, lane);
     }
     OWR_SB();
     // conv b: 3x1 over [hist_b(2) ; Ya]
@@ -507,54 +518,40 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     load_tile<NCT>(H0, hb, lane);
     load_tile<NCT>(H1, hb + NCT * 4 * 64, lane);
     f32x4 Yb[RP][NCT];
-#if OWR_WLDS
-    conv_time_lds<NCT, NCT, RP, true, NCT, NB>(H0, H1, Ya, Yb, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane);
-#else
-    conv_time<NCT, NCT, RP, true>(H0, H1, Ya, Yb, p.w[1], p.scale[1], p.shift[1], lane);
-#endif
+    conv_time_lds<NCT, NCT, RP, true, NCT, NB, C::HOUT, C::HOUT>(H0, H1, Ya, Yb, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane);
     if (active) {
         store_tile<NCT>(Ya[RP - 2], hb, lane);
         store_tile<NCT>(Ya[RP - 1], hb + NCT * 4 * 64, lane);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Yb[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * RP + r, p.S, lane);
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C, C::HOUT>(Yb[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * RP + r, p.S, lane);
     }
     OWR_SB();
     // conv c: 1x3
     f32x4 Yc[RP][NCT];
-#if OWR_WLDS
-    conv_mel_lds<NCT, NCT, RP, F, true, 2 * NCT, NB>(Yb, Yc, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
-#else
-    conv_mel<NCT, NCT, RP, F, true>(Yb, Yc, p.w[2], p.scale[2], p.shift[2], lane);
-#endif
+    conv_mel_lds<NCT, NCT, RP, F, true, 2 * NCT, NB, C::HOUT, C::HOUT>(Yb, Yc, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Yc[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * RP + r, p.S, lane);
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C, C::HOUT>(Yc[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * RP + r, p.S, lane);
     }
     OWR_SB();
     // conv d: 3x1 over [hist_d(2) ; Yc]
     load_tile<NCT>(H0, hd, lane);
     load_tile<NCT>(H1, hd + NCT * 4 * 64, lane);
-#if OWR_WLDS
-    conv_time_lds<NCT, NCT, RP, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0))>(H0, H1, Yc, Yd, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], wave, lane);
-#else
-    conv_time<NCT, NCT, RP, true>(H0, H1, Yc, Yd, p.w[3], p.scale[3], p.shift[3], lane);
-#endif
+    conv_time_lds<NCT, NCT, RP, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), C::HOUT, C::HOUT>(H0, H1, Yc, Yd, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], wave, lane);
     if (active) {
         store_tile<NCT>(Yc[RP - 2], hd, lane);
         store_tile<NCT>(Yc[RP - 1], hd + NCT * 4 * 64, lane);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C>(Yd[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * RP + r, p.S, lane);
+        for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C, C::HOUT>(Yd[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * RP + r, p.S, lane);
     }
 
     if (!LAST && active) pool_store<C>(Yd, p.xout, g, pass * (RP / C::PT), lane);
     }   // pass
-#if OWR_WLDS
     if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last pass prefetched a chunk nobody uses: drain it
-#endif
 
     if (LAST) {
         // pool 2x2 -> one position per stream (even lanes), compact to lanes pos' = stream via the LDS crossbar,
@@ -576,11 +573,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         load_tile<NCT>(H0, h19, lane);
         load_tile<NCT>(H1, h19 + NCT * 4 * 64, lane);
         f32x4 E[1][NCT];
-#if OWR_WLDS
         conv_time_lds<NCT, NCT, 1, false, 4 * NCT, 0>(H0, H1, Pl, E, wbuf, p.w19, nullptr, nullptr, nullptr, wave, lane);
-#else
-        conv_time<NCT, NCT, 1, false>(H0, H1, Pl, E, p.w19, nullptr, nullptr, lane);
-#endif
         if (active) {
             store_tile<NCT>(H1, h19, lane);
             store_tile<NCT>(Pl[0], h19 + NCT * 4 * 64, lane);
@@ -620,17 +613,31 @@ struct RAParams {
     int dbg_off[3];
 };
 
-template <bool DBG>
-__global__ __launch_bounds__(256, OWR_WPS) void rstageA_kernel(RAParams p) {
-    const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
-    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = gridDim.x * 4;
+#ifndef OWR_WPS_A
+#define OWR_WPS_A 2
+#endif
 
-    // conv1 / conv2 weights (24 KB, MFMA operand order) -> LDS once per workgroup; conv0's six operand registers stay in VGPRs
+template <bool DBG>
+__global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
+    const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+
+    // conv1 / conv2 weights (2 x 12 KB, MFMA operand order) and the three folded BatchNorms -> LDS once per workgroup;
+    // per wave a [10][34] tile of mel rows (2 history + 8 new, a zero column either side = the mel-axis padding)
     __shared__ __attribute__((aligned(16))) float sW[2][2 * 3 * 2 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float sbn[3][2][32];
+    __shared__ float sMel[4][10 * 34];
     for (int i = threadIdx.x; i < 2 * 3 * 2 * 64; i += 256) {
         reinterpret_cast<f32x4*>(sW[0])[i] = reinterpret_cast<const f32x4*>(p.w1)[i];
         reinterpret_cast<f32x4*>(sW[1])[i] = reinterpret_cast<const f32x4*>(p.w2)[i];
     }
+    if (threadIdx.x < 96) {
+        const int l = threadIdx.x / 32, c = threadIdx.x % 32;
+        sbn[l][0][c] = p.scale[l][c];
+        sbn[l][1][c] = p.shift[l][c];
+    }
+    for (int i = threadIdx.x; i < 4 * 10 * 34; i += 256) sMel[0][i] = 0.f;
     float W0[2][3];
 #pragma unroll
     for (int oct = 0; oct < 2; ++oct)
@@ -639,45 +646,49 @@ __global__ __launch_bounds__(256, OWR_WPS) void rstageA_kernel(RAParams p) {
     __syncthreads();
     const f32x4* sW1b = reinterpret_cast<const f32x4*>(sW[0]) + lane;    // [(oct*3+tap)*2+ct][64 lanes]
     const f32x4* sW2b = reinterpret_cast<const f32x4*>(sW[1]) + lane;
-    // conv0 operand gather: k-step ks carries tap 4ks+j = (dt, df)
-    int dt[3], df[3];
-    bool kv[3];
+    float* sM = sMel[wave];
+    // conv0 operand gather: k-step ks carries tap k = 4ks+j = (dt, df); k >= 9 has zero weight (any finite operand will do)
+    int goff[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + j; kv[ks] = k < 9; dt[ks] = (k < 9 ? k : 0) / 3; df[ks] = (k < 9 ? k : 0) % 3; }
+    for (int ks = 0; ks < 3; ++ks) { const int k = min(4 * ks + j, 8); goff[ks] = (k / 3) * 34 + (k % 3) + pos; }
 
     stagger(gw);
     for (int s = gw; s < p.n_streams; s += nw) {
+        // an opaque zero per stream: keeps the loop-invariant LDS reads (weights, BatchNorm) from being hoisted out of
+        // the stream loop into ~150 live registers
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        const f32x4* sW1 = sW1b + z;
+        const f32x4* sW2 = sW2b + z;
+        const float* bn = &sbn[0][0][0] + z;
         const float* mel = p.mel + (size_t)s * p.mel_stride + p.mel_off;
         float* hm = p.hist_mel + (size_t)s * 64;
         float* h2 = p.hist2 + (size_t)s * (2 * 2 * 8 * 64);
-        f32x4 Ym2[2][2], Ym1[2][2];                 // conv1 output rows r-2, r-1  [half][ct]
+        // mel tile -> LDS (wave-private region; LDS operations of one wave execute in order)
+        {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mel + lane * 4);
+            const float hv = hm[lane];
+            const int row = lane >> 3, col = (lane & 7) * 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { load_tile<2>(Ym2[h], h2 + (0 * 2 + h) * 512, lane); load_tile<2>(Ym1[h], h2 + (1 * 2 + h) * 512, lane); }
-        f32x4 Y2p[2][2];                            // previous conv2 row (pool partner)
+            for (int e = 0; e < 4; ++e) sM[(2 + row) * 34 + 1 + col + e] = m4[e];
+            sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hv;
+        }
+        f32x4 Yh[2][2][2];                            // conv1 output rows r-2, r-1: [row][half][channel block], packed form
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            // an opaque zero: keeps the (loop-invariant) LDS weight reads and BN loads inside the row instead of having
-            // them hoisted into ~150 live registers
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) load_tile<2>(Yh[r][h], h2 + (r * 2 + h) * 512, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // rows 2q, 2q+1
             OWR_SB();
-            int z = 0;
-            asm volatile("" : "+s"(z));
-            const f32x4* sW1 = sW1b + z;
-            const f32x4* sW2 = sW2b + z;
-            const float* sc0 = p.scale[0] + z; const float* sh0 = p.shift[0] + z;
-            const float* sc1 = p.scale[1] + z; const float* sh1 = p.shift[1] + z;
-            const float* sc2 = p.scale[2] + z; const float* sh2 = p.shift[2] + z;
-            // ---- conv0 row r: rows r..r+2 of [hist_mel(2) ; mel(8)], zero padded in mel
-            f32x4 Y0[2][2];
+            // ---- conv0: 3x3, 1 -> 24 (K = 9 padded to 12), ReLU, BN, activation.  tile t = (row rr, half h)
+            f32x4 Y0[4][2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int t = 0; t < 4; ++t) {
+                const int r = 2 * q + (t >> 1), h = t & 1;
                 float b[3];
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const int rr = r + dt[ks], f = h * 16 + pos + df[ks] - 1;
-                    float v = 0.f;
-                    if (kv[ks] && f >= 0 && f < 32) v = rr < 2 ? hm[rr * 32 + f] : mel[(rr - 2) * 32 + f];
-                    b[ks] = v;
-                }
+                for (int ks = 0; ks < 3; ++ks) b[ks] = sM[r * 34 + h * 16 + goff[ks]];
 #pragma unroll
                 for (int oct = 0; oct < 2; ++oct) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -685,98 +696,112 @@ __global__ __launch_bounds__(256, OWR_WPS) void rstageA_kernel(RAParams p) {
                     for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W0[oct][ks], b[ks], acc, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
-                    Y0[h][oct] = bn_act<true>(acc, sc0, sh0, oct, j);
-                    pin(Y0[h][oct]);
+                    Y0[t][oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
+                    pin(Y0[t][oct]);
                 }
-                if (DBG && p.dbg) dump_tile<2, 16, 24>(Y0[h], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
+                Y0[t][1] = pack_half(Y0[t][1]);
+                pin(Y0[t][1]);
+                if (DBG && p.dbg) dump_tile<2, 16, 24, true>(Y0[t], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
             }
-            // ---- conv1 (1x3 over the 32 mel positions = two halves with carries across the seam)
-            f32x4 Y1[2][2];
+            // ---- conv1: 1x3 over the 32 mel positions of a row = two halves with carries across the seam
+            f32x4 Y1[4][2];
 #pragma unroll
             for (int oct = 0; oct < 2; ++oct) {
-                f32x4 acc[3][2];
+                f32x4 acc[3][4];
 #pragma unroll
-                for (int tap = 0; tap < 3; ++tap) { acc[tap][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[tap][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const f32x4 a = sW1[((oct * 3 + tap) * 2 + ct) * 64];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < (ct ? 2 : 4); ++e)
 #pragma unroll
-                            for (int h = 0; h < 2; ++h)
-                                acc[tap][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], Y0[h][ct][e], acc[tap][h], 0, 0, 0);
+                            for (int t = 0; t < 4; ++t)
+                                acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], Y0[t][ct][e], acc[tap][t], 0, 0, 0);
                     }
-                f32x4 r0, r1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r0[e] = (acc[1][0][e] + dpp_shr1_zero(acc[0][0][e])) + dpp_shl1_carry(acc[2][0][e], acc[2][1][e]);
-                    r1[e] = (acc[1][1][e] + dpp_shr1_carry(acc[0][1][e], acc[0][0][e])) + dpp_shl1_zero(acc[2][1][e]);
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int t0 = 2 * rr, t1 = 2 * rr + 1;
+                    f32x4 r0, r1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r0[e] = (acc[1][t0][e] + dpp_shr1_zero(acc[0][t0][e])) + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
+                        r1[e] = (acc[1][t1][e] + dpp_shr1_carry(acc[0][t1][e], acc[0][t0][e])) + dpp_shl1_zero(acc[2][t1][e]);
+                    }
+                    Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
+                    Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
+                    pin(Y1[t0][oct]); pin(Y1[t1][oct]);
+                    if (oct == 1) { Y1[t0][1] = pack_half(Y1[t0][1]); Y1[t1][1] = pack_half(Y1[t1][1]); pin(Y1[t0][1]); pin(Y1[t1][1]); }
                 }
-                Y1[0][oct] = bn_act<true>(r0, sc1, sh1, oct, j);
-                Y1[1][oct] = bn_act<true>(r1, sc1, sh1, oct, j);
-                pin(Y1[0][oct]); pin(Y1[1][oct]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (DBG && p.dbg) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) dump_tile<2, 16, 24>(Y1[h], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[1], s, r * 2, p.S, lane);
+                for (int t = 0; t < 4; ++t)
+                    dump_tile<2, 16, 24, true>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
             }
-            // ---- conv2 (3x1) over rows (r-2, r-1, r) of conv1's output
-            f32x4 Y2[2][2];
+            // ---- conv2: 3x1 over conv1 rows (r-2, r-1, r): rows of this step see [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1]
+            f32x4 Y2[4][2];
 #pragma unroll
             for (int oct = 0; oct < 2; ++oct) {
-                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                f32x4 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const f32x4 a = sW2[((oct * 3 + tap) * 2 + ct) * 64];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < (ct ? 2 : 4); ++e)
 #pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const float b = tap == 0 ? Ym2[h][ct][e] : (tap == 1 ? Ym1[h][ct][e] : Y1[h][ct][e]);
-                                acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[h], 0, 0, 0);
+                            for (int t = 0; t < 4; ++t) {
+                                const int src = (t >> 1) + tap, h = t & 1;      // 0,1 = history rows, 2,3 = this step's rows
+                                const float b = src < 2 ? Yh[src][h][ct][e] : Y1[(src - 2) * 2 + h][ct][e];
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b, acc[t], 0, 0, 0);
                             }
                     }
-                Y2[0][oct] = bn_act<true>(acc[0], sc2, sh2, oct, j);
-                Y2[1][oct] = bn_act<true>(acc[1], sc2, sh2, oct, j);
-                pin(Y2[0][oct]); pin(Y2[1][oct]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j);
+                    pin(Y2[t][oct]);
+                    if (oct == 1) { Y2[t][1] = pack_half(Y2[t][1]); pin(Y2[t][1]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (DBG && p.dbg) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) dump_tile<2, 16, 24>(Y2[h], p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[2], s, r * 2, p.S, lane);
+                for (int t = 0; t < 4; ++t)
+                    dump_tile<2, 16, 24, true>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
             }
-            // rotate the conv2 input window
+            // the conv2 input window moves on by two rows
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) { Ym2[h][ct] = Ym1[h][ct]; Ym1[h][ct] = Y1[h][ct]; }
-            // ---- pool 2x2 -> stage B input row r/2: 16 positions = pooled f of both halves
-            if (r & 1) {
-                float* xo = p.xout + ((size_t)s * 4 + (r >> 1)) * (8 * 64);
+                for (int ct = 0; ct < 2; ++ct) { Yh[0][h][ct] = Y1[h][ct]; Yh[1][h][ct] = Y1[2 + h][ct]; }
+            // ---- pool 2x2 -> stage B input row q: 16 positions = the pooled f of both halves (channels stay in pack_half order)
+            float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float m = fmaxf(Y2p[h][ct][e], Y2[h][ct][e]);
-                            m = fmaxf(m, dpp_shl1_zero(m));
-                            if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
-                        }
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) Y2p[h][ct] = Y2[h][ct];
-            }
+                    for (int e = 0; e < (ct ? 2 : 4); ++e) {
+                        float m = fmaxf(Y2[h][ct][e], Y2[2 + h][ct][e]);
+                        m = fmaxf(m, dpp_shl1_zero(m));
+                        if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
+                    }
         }
-        // new histories: conv1 rows 6,7 (now in Ym2, Ym1) and mel rows 6,7
+        // new histories: conv1 rows 6,7 (packed) and mel rows 6,7
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { store_tile<2>(Ym2[h], h2 + (0 * 2 + h) * 512, lane); store_tile<2>(Ym1[h], h2 + (1 * 2 + h) * 512, lane); }
-        hm[lane] = mel[6 * 32 + lane];
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) store_tile<2>(Yh[r][h], h2 + (r * 2 + h) * 512, lane);
+        hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
     }
 }
 
