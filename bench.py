@@ -44,6 +44,18 @@ def head_flops(heads) -> int:
     return n
 
 
+def pmc_traffic(kernel: str, streams: int, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, produced by
+    tools/pmc.sh on the same workload: FETCH_SIZE x2 + WRITE_SIZE); None when no pass matches this configuration."""
+    if args.valu or args.lds_mfma or streams != 131072:
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        return {"hbm_bytes_per_launch": t[kernel + "_rr"]["hbm_bytes"], "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +169,7 @@ def main():
             dom = max(STAGE_FLOPS, key=lambda k: per[k])
             tf = STAGE_FLOPS[dom] * S / (per[dom] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": pmc_traffic(dom, S, args),
                                "flops_per_launch": STAGE_FLOPS[dom] * S, "avg_ms": round(per[dom], 4)}
             cnn_ms = sum(per[k] for k in STAGE_FLOPS)
             cnn_tf = sum(STAGE_FLOPS.values()) * S / (cnn_ms * 1e-3) / 1e12

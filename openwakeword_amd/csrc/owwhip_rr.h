@@ -271,13 +271,23 @@ __device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 
         float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
         if (oct + 1 < NCTO) issue_chunk<3 * NCTI>(w + (size_t)(oct + 1) * 3 * NCTI * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
-        f32x4 res[NT];
+        // out[p] = tap0[p-1] + tap1[p] + tap2[p+1] (zero beyond a stream's F positions).  Tap order 0, 2, 1: the two taps
+        // that need a lane shift of their accumulators run first, so that their DPP epilogues overlap with the MFMA
+        // chain of the following tap; the shifted tap-0 sum is the starting accumulator of the tap-1 chain.
+        f32x4 res[NT], accs[2][NT];
         OWR_SGB_PROLOGUE();
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
+        for (int ti = 0; ti < 3; ++ti) {
+            const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
             f32x4 acc[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) {
+                if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && first) ? 0.f : l; }
+                }
+            }
 #pragma unroll
             for (int ct = 0; ct < NCTI; ++ct) {
                 const f32x4 a = lds_w(cur, tap * NCTI + ct, lane);
@@ -290,13 +300,13 @@ __device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 
                 if (HIN && ct == NCTI - 1) OWR_SGB_STEP(2 * NT); else OWR_SGB_STEP(4 * NT);
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                if (ti < 2) accs[ti][t] = acc[t];
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (tap == 0) { const float l = dpp_shr1_zero(acc[t][e]); res[t][e] = (F < 16 && first) ? 0.f : l; }
-                    else if (tap == 1) res[t][e] += acc[t][e];
-                    else { const float hh = dpp_shl1_zero(acc[t][e]); res[t][e] += (F < 16 && last) ? 0.f : hh; }
+                    for (int e = 0; e < 4; ++e) { const float hh = dpp_shl1_zero(accs[1][t][e]); res[t][e] = acc[t][e] + ((F < 16 && last) ? 0.f : hh); }
                 }
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -415,10 +425,10 @@ struct RCfg {
 #define OWR_WPS_C 2
 #endif
 #ifndef OWR_WPS_D
-#define OWR_WPS_D 2
+#define OWR_WPS_D 3
 #endif
 #ifndef OWR_WPS_E
-#define OWR_WPS_E 2
+#define OWR_WPS_E 3
 #endif
 using RB = RCfg<24, 48, 4, 16, 1, 2, 4, OWR_WPS_B>;
 using RC = RCfg<48, 72, 4, 8, 2, 2, OWR_RC_RP, OWR_WPS_C>;
@@ -707,13 +717,20 @@ __global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
             f32x4 Y1[4][2];
 #pragma unroll
             for (int oct = 0; oct < 2; ++oct) {
+                // tap order 0, 2, 1 (see conv_mel_lds): the shifted tap-0 sums start the tap-1 accumulators
                 f32x4 acc[3][4];
 #pragma unroll
-                for (int tap = 0; tap < 3; ++tap)
+                for (int ti = 0; ti < 3; ++ti) {
+                    const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int t = 0; t < 4; ++t) {
+                        if (ti < 2) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        else {
 #pragma unroll
-                for (int tap = 0; tap < 3; ++tap)
+                            for (int e = 0; e < 4; ++e)
+                                acc[1][t][e] = (t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]);
+                        }
+                    }
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const f32x4 a = sW1[((oct * 3 + tap) * 2 + ct) * 64];
@@ -723,14 +740,15 @@ __global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
                             for (int t = 0; t < 4; ++t)
                                 acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], Y0[t][ct][e], acc[tap][t], 0, 0, 0);
                     }
+                }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int t0 = 2 * rr, t1 = 2 * rr + 1;
                     f32x4 r0, r1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        r0[e] = (acc[1][t0][e] + dpp_shr1_zero(acc[0][t0][e])) + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
-                        r1[e] = (acc[1][t1][e] + dpp_shr1_carry(acc[0][t1][e], acc[0][t0][e])) + dpp_shl1_zero(acc[2][t1][e]);
+                        r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
+                        r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
                     }
                     Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
                     Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
