@@ -47,7 +47,7 @@ def head_flops(heads) -> int:
 def pmc_traffic(kernel: str, streams: int, args):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, produced by
     tools/pmc.sh on the same workload: FETCH_SIZE x2 + WRITE_SIZE); None when no pass matches this configuration."""
-    if args.valu or args.lds_mfma or streams != 131072:
+    if args.valu or args.lds_mfma or args.f16x3 or streams != 131072:
         return None
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--heads", default="alexa,hey_mycroft,hey_jarvis")
     ap.add_argument("--valu", action="store_true", help="plain-VALU kernels instead of MFMA (A/B only)")
     ap.add_argument("--lds-mfma", action="store_true", help="LDS-tiled MFMA kernels instead of the register-resident ones (A/B only)")
+    ap.add_argument("--f16x3", action="store_true", help="fp16-split (3 x f16 MFMA per fp32 product) form of the register-resident CNN")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the cpu_baseline leg")
@@ -101,7 +102,7 @@ def main():
     # one side stream carries the engine's kernels AND the RCCL gather, so they are ordered without host syncs
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=(0 if args.valu else 2 if args.lds_mfma else 1), hip_stream=stream.cuda_stream)
+    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=(0 if args.valu else 2 if args.lds_mfma else 3 if args.f16x3 else 1), hip_stream=stream.cuda_stream)
     NL = eng.n_labels
     eng.reset()
     if args.graph:
@@ -158,7 +159,7 @@ def main():
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
                        "collective": "RCCL gather of scores per step" if world > 1 else "none",
-                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else "mfma_rr"), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
+                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_f16x3" if args.f16x3 else "mfma_rr")), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
             "realtime_streams": round(value / 12.5, 1),
             "frames_per_sec_per_gpu": round(value / world, 1),
             "scores_valid": ok,

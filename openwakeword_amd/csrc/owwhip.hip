@@ -15,6 +15,7 @@
 #include "owwhip.h"
 #include "owwhip_kernels.h"
 #include "owwhip_rr.h"
+#include "owwhip_hx.h"
 
 using namespace owk;
 
@@ -97,6 +98,45 @@ void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                     }
 }
 
+// fp16-split operand order (owwhip_hx.h): blocks [oct][tap][ks][part hi/lo] of 64 lanes x 8 halves; lane (i, g), half q
+// <-> weight of input channel 16*(2ks + q/4) + 4g + q%4 and output channel 16oct + i, pre-scaled by 2^8
+void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
+    const int ks_n = ((cin + 15) / 16 + 1) / 2, ncto = (cout + 15) / 16;
+    std::vector<_Float16> hbuf((size_t)ncto * ntaps * ks_n * 2 * 64 * 8, (_Float16)0.f);
+    for (int oct = 0; oct < ncto; ++oct)
+        for (int tap = 0; tap < ntaps; ++tap)
+            for (int ks = 0; ks < ks_n; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = lane & 15, g = lane >> 4;
+                        const int ci = 16 * (2 * ks + q / 4) + 4 * g + q % 4, co = oct * 16 + i;
+                        if (ci >= cin || co >= cout) continue;
+                        const float v = w[((size_t)tap * cin + ci) * cout + co] * owh::WSCALE;
+                        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                        const size_t blk = (((size_t)oct * ntaps + tap) * ks_n + ks) * 2;
+                        hbuf[(blk * 64 + lane) * 8 + q] = hi;
+                        hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
+                    }
+    out.assign(hbuf.size() / 2, 0.f);
+    memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
+}
+// conv0 (3x3, one input channel): one k-step, k = tap index (9 of 32 used)
+void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out) {
+    std::vector<_Float16> hbuf((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
+    for (int oct = 0; oct < 2; ++oct)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int q = 0; q < 8; ++q) {
+                const int i = lane & 15, g = lane >> 4, k = 8 * g + q, co = oct * 16 + i;
+                if (k >= 9 || co >= 24) continue;
+                const float v = w[k * 24 + co] * owh::WSCALE;
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                hbuf[((size_t)(oct * 2 + 0) * 64 + lane) * 8 + q] = hi;
+                hbuf[((size_t)(oct * 2 + 1) * 64 + lane) * 8 + q] = lo;
+            }
+    out.assign(hbuf.size() / 2, 0.f);
+    memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
+}
+
 struct HostBuf {                      // host image of the device weight buffer (256-byte aligned pieces)
     std::vector<float> data;
     size_t add(const float* p, size_t n) {
@@ -147,6 +187,7 @@ struct oww_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false, committed = false, mfma = true;
     bool rr = true;                   // register-resident CNN kernels (owwhip_rr.h); false = LDS-tiled kernels (MFMA or VALU)
+    bool hx = false;                  // fp16-split form of the register-resident kernels (owwhip_hx.h); shares rr's layouts
     const int* state_len = kStateLenRr;
     // host side weights as loaded
     std::vector<float> mel_blob, emb_blob;
@@ -292,7 +333,7 @@ int run_cnn_t(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
 }
 
 // register-resident kernels (owwhip_rr.h): every wave independent, groups of 1 / 1 / 2 / 4 / 8 streams per wave
-template <bool DBG>
+template <bool DBG, bool HX>
 int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     using namespace owr;
     hipStream_t st = h->stream;
@@ -308,7 +349,8 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
         Timed t(h, 1);
-        hipLaunchKernelGGL(rstageA_kernel<DBG>, dim3(grid), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 512)), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(rstageA_kernel<DBG>, dim3(grid), dim3(256), 0, st, p);
     }
     auto fill = [&](RStageParams& p, const float* xin, float* xout, int first_layer, int sb, int sd, int spt) {
         p.xin = xin; p.xout = xout; p.hist_b = h->d_state[sb]; p.hist_d = h->d_state[sd];
@@ -322,24 +364,28 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
         Timed t(h, 2);
-        hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xB, h->d_xC, 7, 4, 5, RC::SPT);
         Timed t(h, 3);
-        hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xC, h->d_xD, 11, 6, 7, RD::SPT);
         Timed t(h, 4);
-        hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xD, nullptr, 15, 8, 9, RE::SPT);
         p.hist19 = h->d_state[10]; p.w19 = h->d_conv[19]; p.feat = h->d_feat; p.emb = h->d_emb; p.nfeat = h->d_nfeat; p.TR = h->TR;
         p.dbg_off[4] = dbg_off[19];
         Timed t(h, 5);
-        hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -348,7 +394,8 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
 int run_cnn(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     // grids cover whole workgroups of streams: round up to the largest per-workgroup stream count
     n_active = std::min(h->Spad, (n_active + 7) / 8 * 8);
-    if (h->rr) return h->d_dbg ? run_cnn_rr<true>(h, n_active, mel_stride, mel_off) : run_cnn_rr<false>(h, n_active, mel_stride, mel_off);
+    if (h->hx) return h->d_dbg ? run_cnn_rr<true, true>(h, n_active, mel_stride, mel_off) : run_cnn_rr<false, true>(h, n_active, mel_stride, mel_off);
+    if (h->rr) return h->d_dbg ? run_cnn_rr<true, false>(h, n_active, mel_stride, mel_off) : run_cnn_rr<false, false>(h, n_active, mel_stride, mel_off);
     return h->mfma ? run_cnn_t<true>(h, n_active, mel_stride, mel_off) : run_cnn_t<false>(h, n_active, mel_stride, mel_off);
 }
 
@@ -501,7 +548,8 @@ int oww_create(const oww_config* cfg, oww_ctx** out) {
     h->Spad = (h->S + 31) / 32 * 32;
     h->kmax = std::max(1, cfg->max_chunks);
     h->mfma = cfg->use_mfma != 0;
-    h->rr = cfg->use_mfma == 1;
+    h->rr = cfg->use_mfma == 1 || cfg->use_mfma == 3;
+    h->hx = cfg->use_mfma == 3;
     h->state_len = h->rr ? kStateLenRr : kStateLenLds;
     if (cfg->stream) h->stream = reinterpret_cast<hipStream_t>(cfg->stream);
     else {
@@ -615,6 +663,7 @@ int oww_commit(oww_ctx* h) {
             const LayerDef& L = kLayers[l];
             const size_t nw = (size_t)L.kh * L.kw * L.cin * L.cout;
             if (!h->mfma) o_conv[l] = hb.add(q, nw);
+            else if (h->hx) { if (l == 0) pack_hx_conv0(q, pk); else pack_hx(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
             else if (h->rr && l > 0) { pack_rr(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
             else if (l == 0) {
                 // conv0: K = 9 taps padded to 12 -> three k-steps; lane (i, j) of k-step s holds w[k = 4s+j][cout = 16ct+i]
@@ -631,7 +680,9 @@ int oww_commit(oww_ctx* h) {
             if (l < 19) {
                 // zero padded to whole 16-channel tiles: the register-resident kernels evaluate the pad channels (as zeros)
                 std::vector<float> pad((size_t)(L.cout + 15) / 16 * 16, 0.f);
-                memcpy(pad.data(), q, L.cout * sizeof(float)); o_scale[l] = hb.add(pad); q += L.cout;
+                memcpy(pad.data(), q, L.cout * sizeof(float));
+                if (h->hx) for (float& v : pad) v *= owh::WUNSCALE;          // the f16-split weights carry a factor 2^8
+                o_scale[l] = hb.add(pad); q += L.cout;
                 std::fill(pad.begin(), pad.end(), 0.f);
                 memcpy(pad.data(), q, L.cout * sizeof(float)); o_shift[l] = hb.add(pad); q += L.cout;
             }

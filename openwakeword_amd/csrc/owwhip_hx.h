@@ -1,0 +1,521 @@
+// owwhip_hx.h -- fp16-split ("f16x3") form of the register-resident embedding CNN (included by owwhip.hip).
+//
+// Same dataflow, tiles, state arrays and memory layouts as owwhip_rr.h; only the inner product changes.  The fp32 MFMA
+// runs at the fp32 VECTOR rate (157 TFLOP/s); the f16 MFMA is 16x faster.  Every fp32 operand is split into two f16
+// halves, x = xh + xl with xh = f16(x), xl = f16(x - xh) (22 mantissa bits together), and
+//        x * w  ~=  xh*wh + xh*wl + xl*wh                       (the dropped xl*wl term is < 2^-22 |x w|)
+// is evaluated by three v_mfma_f32_16x16x32_f16 with fp32 accumulation: f16 x f16 products are exact in fp32, so the
+// result differs from the fp32 kernels by ~2^-22 relative per product -- the same class as fp32 round-off itself
+// (oracle emulation: |embedding error| 4.7e-6 vs 4.5e-6 for plain fp32 against float64; tests hold it to the same
+// tolerances as the fp32 paths).  Weights are pre-scaled by 2^8 on the host (keeps their low halves out of the f16
+// subnormal range; undone exactly by the folded BatchNorm scale) and pre-split.
+//
+// Operand form.  16x16x32: A lane (i, g) holds A[i][k = 8g..8g+7], B lane (p, g) holds B[k = 8g..8g+7][p] (8 halves =
+// 4 VGPRs each), D as in the fp32 form (lane (p, j), register e <-> D[4j+e][p]).  A k-step carries 32 input channels =
+// two channel tiles: k = 8g + q  <->  channel 16*(2ks + q/4) + 4g + q%4, i.e. the B operand of k-step ks is the
+// f16 split of D registers 0..3 of channel tiles 2ks and 2ks+1 of the same lane: again no data movement between layers,
+// only the split (3 VALU ops per value) after the BatchNorm/activation epilogue.
+#pragma once
+#include "owwhip_rr.h"
+
+namespace owh {
+
+using owr::f32x4;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float WSCALE = 256.0f;            // weights are stored as f16 halves of 2^8 * w
+constexpr float WUNSCALE = 1.0f / 256.0f;
+
+// operand pair (hi, lo) of one k-step of one position tile
+struct Op { f16x8 h, l; };
+
+__device__ __forceinline__ Op split_pair(const f32x4 a, const f32x4 b) {
+    Op o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 ha = (_Float16)a[e], hb = (_Float16)b[e];
+        o.h[e] = ha; o.h[4 + e] = hb;
+        o.l[e] = (_Float16)(a[e] - (float)ha);
+        o.l[4 + e] = (_Float16)(b[e] - (float)hb);
+    }
+    return o;
+}
+__device__ __forceinline__ void pin_op(Op& o) {
+    // f16x8 = 4 VGPRs; keep the split where it was written (see owr::pin)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 a = __builtin_bit_cast(u32x4, o.h), b = __builtin_bit_cast(u32x4, o.l);
+    asm volatile("" : "+v"(a), "+v"(b));
+    o.h = __builtin_bit_cast(f16x8, a); o.l = __builtin_bit_cast(f16x8, b);
+}
+
+// operand form of a whole fp32 tile (NCT channel tiles -> KS = ceil(NCT/2) k-steps; an odd last tile pairs with zeros)
+template <int NCT>
+__device__ __forceinline__ void to_ops(const f32x4 (&t)[NCT], Op (&o)[(NCT + 1) / 2]) {
+#pragma unroll
+    for (int k = 0; k < (NCT + 1) / 2; ++k) {
+        o[k] = split_pair(t[2 * k], 2 * k + 1 < NCT ? t[2 * k + 1] : f32x4{0.f, 0.f, 0.f, 0.f});
+        pin_op(o[k]);
+    }
+}
+
+__device__ __forceinline__ f16x8 lds_h(const float* buf, int blk, int lane) {
+    return *reinterpret_cast<const f16x8*>(buf + (blk * 64 + lane) * 4);
+}
+
+using HB = owr::RCfg<24, 48, 4, 16, 1, 2, 4, 2>;
+using HC = owr::RCfg<48, 72, 4, 8, 2, 2, 2, 2>;
+using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, 2>;
+using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, 2>;
+
+#define OWH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+// chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
+// 1x3 (mel) layer: NT tiles in operand form -> NT fp32 D tiles (BatchNorm + activation applied)
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK>
+__device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
+                                            const float* __restrict__ w, const float* __restrict__ w_next,
+                                            const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
+    using namespace owr;
+    const int pos = lane & 15, j = lane >> 4;
+    const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
+    constexpr int NBLK = 3 * KSI * 2;
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        if (oct + 1 < NCTO) issue_chunk<NBLK>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+        f32x4 res[NT], accs[2][NT];
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
+            const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && first) ? 0.f : l; }
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSI; ++ks) {
+                const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
+                const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, in[t][ks].h, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, in[t][ks].l, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(al, in[t][ks].h, acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (ti < 2) accs[ti][t] = acc[t];
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float hh = dpp_shl1_zero(accs[1][t][e]); res[t][e] = acc[t][e] + ((F < 16 && last) ? 0.f : hh); }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+    }
+}
+
+// 3x1 (time) layer: rows h0, h1 (history) and in[0..NR-1] in operand form; out row r uses rows r, r+1, r+2
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK>
+__device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
+                                             float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
+                                             const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane) {
+    using namespace owr;
+    const int j = lane >> 4;
+    constexpr int NBLK = 3 * KSI * 2;
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        if (oct + 1 < NCTO) issue_chunk<NBLK>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+        f32x4 acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < KSI; ++ks) {
+                const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
+                const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int src = r + tap;
+                        const int ri = src >= 2 ? src - 2 : 0;
+                        const Op& b = src == 0 ? h0[ks] : (src == 1 ? h1[ks] : in[ri][ks]);
+                        acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[r]);
+                    }
+            }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (BN) out[r][oct] = bn_act<true>(acc[r], scale, shift, oct, j);
+            else out[r][oct] = acc[r] * post;
+            pin(out[r][oct]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stages B..E (parameters, geometry and memory layouts: owr::RStageParams / owr::RCfg, channel tiles NOT re-packed)
+// ------------------------------------------------------------------------------------------------
+template <class C, bool LAST, bool DBG>
+__global__ __launch_bounds__(256, 2) void hstage_kernel(owr::RStageParams p) {
+    using namespace owr;
+    constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
+    static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
+    constexpr int KSA = (NCTI + 1) / 2, KS = (NCT + 1) / 2;          // k-steps per tap: first layer / other layers
+    constexpr int NBA = 3 * KSA * 2, NB = 3 * KS * 2;                // 1 KB blocks per chunk
+    static_assert(NB * 256 <= WBUF_FLOATS, "chunk fits the LDS buffer");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int g = blockIdx.x * C::WAVES + wave;
+    __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
+    const bool active = g < p.n_groups;
+    if (!active) g = p.n_groups - 1;
+    issue_chunk<NBA>(p.w[0], wbuf, wave, lane);
+    for (int i = threadIdx.x; i < 4 * NCT * 16; i += 256) {
+        const int l = i / (NCT * 16), c = i % (NCT * 16);
+        sbn[l][0][c] = p.scale[l][c];
+        sbn[l][1][c] = p.shift[l][c];
+    }
+    const int s_first = g * C::SPT;
+    float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
+    float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
+
+    f32x4 Y[R][NCT];
+#pragma unroll
+    for (int pass = 0; pass < C::NPASS; ++pass) {
+    Op Xo[R][KSA];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        f32x4 X[NCTI];
+        load_tile<NCTI>(X, p.xin + ((size_t)g * C::R + pass * R + r) * (NCTI * 4 * 64), lane);
+        to_ops<NCTI>(X, Xo[r]);
+    }
+    if (pass == 0) chunk_sync();
+
+    // conv a: 1x3, CIN -> C
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NB>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
+    }
+    Op Ao[R][KS], H0[KS], H1[KS];
+    {
+        f32x4 T0[NCT], T1[NCT];
+        load_tile<NCT>(T0, hb, lane);
+        load_tile<NCT>(T1, hb + NCT * 4 * 64, lane);
+        to_ops<NCT>(T0, H0);
+        to_ops<NCT>(T1, H1);
+    }
+    if (active) {
+        store_tile<NCT>(Y[R - 2], hb, lane);
+        store_tile<NCT>(Y[R - 1], hb + NCT * 4 * 64, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
+    __builtin_amdgcn_sched_barrier(0);
+    // conv b: 3x1 over [hist_b(2) ; Ya]
+    conv_time_hx<KS, NCT, R, true, NCT, NB>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane);
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
+    __builtin_amdgcn_sched_barrier(0);
+    // conv c: 1x3
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
+    }
+    {
+        f32x4 T0[NCT], T1[NCT];
+        load_tile<NCT>(T0, hd, lane);
+        load_tile<NCT>(T1, hd + NCT * 4 * 64, lane);
+        to_ops<NCT>(T0, H0);
+        to_ops<NCT>(T1, H1);
+    }
+    if (active) {
+        store_tile<NCT>(Y[R - 2], hd, lane);
+        store_tile<NCT>(Y[R - 1], hd + NCT * 4 * 64, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
+    __builtin_amdgcn_sched_barrier(0);
+    // conv d: 3x1 over [hist_d(2) ; Yc]
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0))>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane);
+    if (DBG && p.dbg && active) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
+    }
+
+    if (!LAST && active) {
+        constexpr int FO = C::FO, RO = C::RO;
+        constexpr int SPTN = 16 / FO;
+        const int pos = lane & 15, j = lane >> 4;
+        const int sp = pos / F, f = pos % F;
+        const int s = g * C::SPT + sp;
+        const int gn = s / SPTN, spn = s % SPTN;
+        const int posn = spn * FO + f / 2;
+#pragma unroll
+        for (int ro = 0; ro < R / C::PT; ++ro)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float m = Y[ro * C::PT][ct][e];
+                    if (C::PT == 2) m = fmaxf(m, Y[ro * C::PT + 1][ct][e]);
+                    m = fmaxf(m, dpp_shl1_zero(m));
+                    if ((f & 1) == 0) p.xout[((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4) + ct * 4 + e) * 64 + j * 16 + posn] = m;
+                }
+    }
+    }   // pass
+    if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the chunk the last pass prefetched
+
+    if (LAST) {
+        static_assert(!LAST || (C::RO == 1 && C::FO == 1 && NCT == 6), "last stage pools to one position, 96 channels");
+        const int pos = lane & 15, j = lane >> 4;
+        f32x4 Pl[NCT];
+        const int src = (j * 16 + 2 * (pos & 7)) * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = fmaxf(Y[0][ct][e], Y[1][ct][e]);
+                m = fmaxf(m, dpp_shl1_zero(m));
+                Pl[ct][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, m)));
+            }
+        float* h19 = p.hist19 + (size_t)g * (2 * NCT * 4 * 64);
+        f32x4 T0[NCT], T1[NCT];
+        Op H0[KS], H1[KS];
+        load_tile<NCT>(T0, h19, lane);
+        load_tile<NCT>(T1, h19 + NCT * 4 * 64, lane);
+        to_ops<NCT>(T0, H0);
+        to_ops<NCT>(T1, H1);
+        Op Po[1][KS];
+        to_ops<NCT>(Pl, Po[0]);
+        f32x4 E[1][NCT];
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane);
+        if (active) {
+            store_tile<NCT>(T1, h19, lane);
+            store_tile<NCT>(Pl, h19 + NCT * 4 * 64, lane);
+        }
+        const int s = s_first + pos;
+        if (active && pos < C::SPT && s < p.S) {
+            const uint32_t slot = p.nfeat[s] % (uint32_t)p.TR;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                *reinterpret_cast<f32x4*>(p.feat + ((size_t)s * p.TR + slot) * 96 + ct * 16 + 4 * j) = E[0][ct];
+                *reinterpret_cast<f32x4*>(p.emb + (size_t)s * 96 + ct * 16 + 4 * j) = E[0][ct];
+                if (DBG && p.dbg) *reinterpret_cast<f32x4*>(p.dbg + (size_t)s * p.dbg_stride + p.dbg_off[4] + ct * 16 + 4 * j) = E[0][ct];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage A (parameters and layouts: owr::RAParams; w0 / w1 / w2 = hx-packed, hist2 tiles in plain D order)
+// ------------------------------------------------------------------------------------------------
+template <bool DBG>
+__global__ __launch_bounds__(256, 2) void hstageA_kernel(owr::RAParams p) {
+    using namespace owr;
+    const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+
+    // weights: conv0 [2 oct][part 2] (4 KB), conv1 / conv2 [2 oct][3 taps][part 2] (12 KB each); BatchNorms; mel tile
+    __shared__ __attribute__((aligned(16))) float sW0[2 * 2 * 256];
+    __shared__ __attribute__((aligned(16))) float sW[2][2 * 3 * 2 * 256];
+    __shared__ __attribute__((aligned(16))) float sbn[3][2][32];
+    __shared__ float sMel[4][11 * 34];
+    for (int i = threadIdx.x; i < 2 * 2 * 64; i += 256) reinterpret_cast<f32x4*>(sW0)[i] = reinterpret_cast<const f32x4*>(p.w0)[i];
+    for (int i = threadIdx.x; i < 2 * 3 * 2 * 64; i += 256) {
+        reinterpret_cast<f32x4*>(sW[0])[i] = reinterpret_cast<const f32x4*>(p.w1)[i];
+        reinterpret_cast<f32x4*>(sW[1])[i] = reinterpret_cast<const f32x4*>(p.w2)[i];
+    }
+    if (threadIdx.x < 96) {
+        const int l = threadIdx.x / 32, c = threadIdx.x % 32;
+        sbn[l][0][c] = p.scale[l][c];
+        sbn[l][1][c] = p.shift[l][c];
+    }
+    for (int i = threadIdx.x; i < 4 * 11 * 34; i += 256) sMel[0][i] = 0.f;
+    __syncthreads();
+    float* sM = sMel[wave];
+    // conv0 operand gather: lane (p, g) supplies taps k = 8g + q, q = 0..7 (k < 9 real, the rest has zero weight)
+    int goff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int k = min(8 * j + q, 8); goff[q] = (k / 3) * 34 + (k % 3) + pos; }
+
+    for (int s = gw; s < p.n_streams; s += nw) {
+        int z = 0;
+        asm volatile("" : "+s"(z));
+        const float* w0s = sW0 + z;
+        const float* w1s = sW[0] + z;
+        const float* w2s = sW[1] + z;
+        const float* bn = &sbn[0][0][0] + z;
+        const float* mel = p.mel + (size_t)s * p.mel_stride + p.mel_off;
+        float* hm = p.hist_mel + (size_t)s * 64;
+        float* h2 = p.hist2 + (size_t)s * (2 * 2 * 8 * 64);
+        {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mel + lane * 4);
+            const float hv = hm[lane];
+            const int row = lane >> 3, col = (lane & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sM[(2 + row) * 34 + 1 + col + e] = m4[e];
+            sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hv;
+        }
+        Op Yh[2][2][1];                               // conv1 output rows r-2, r-1 in operand form: [row][half][ks]
+        f32x4 Yf[2][2][2];                            // the same rows in fp32 (become the stored history)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { load_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane); to_ops<2>(Yf[r][h], Yh[r][h]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                 // rows 2q, 2q+1
+            OWR_SB();
+            // ---- conv0 (K = 9 -> one k-step)
+            Op Y0o[4][1];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = 2 * q + (t >> 1), h = t & 1;
+                f32x4 b0, b1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { b0[e] = sM[r * 34 + h * 16 + goff[e]]; b1[e] = sM[r * 34 + h * 16 + goff[4 + e]]; }
+                const Op b = split_pair(b0, b1);
+                f32x4 Y0[2];
+#pragma unroll
+                for (int oct = 0; oct < 2; ++oct) {
+                    const f16x8 ah = lds_h(w0s, oct * 2 + 0, lane), al = lds_h(w0s, oct * 2 + 1, lane);
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = OWH_MFMA(ah, b.h, acc);
+                    acc = OWH_MFMA(ah, b.l, acc);
+                    acc = OWH_MFMA(al, b.h, acc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+                    Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
+                    pin(Y0[oct]);
+                }
+                if (DBG && p.dbg) dump_tile<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
+                to_ops<2>(Y0, Y0o[t]);
+            }
+            // ---- conv1: 1x3 over two half-row tiles with carries across the seam
+            f32x4 Y1[4][2];
+#pragma unroll
+            for (int oct = 0; oct < 2; ++oct) {
+                f32x4 acc[3][4];
+#pragma unroll
+                for (int ti = 0; ti < 3; ++ti) {
+                    const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (ti < 2) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[1][t][e] = (t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]);
+                        }
+                    }
+                    const f16x8 ah = lds_h(w1s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + tap) * 2 + 1, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].h, acc[tap][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].l, acc[tap][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(al, Y0o[t][0].h, acc[tap][t]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int t0 = 2 * rr, t1 = 2 * rr + 1;
+                    f32x4 r0, r1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
+                        r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
+                    }
+                    Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
+                    Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
+                    pin(Y1[t0][oct]); pin(Y1[t1][oct]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DBG && p.dbg) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    dump_tile<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+            }
+            Op Y1o[4][1];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) to_ops<2>(Y1[t], Y1o[t]);
+            // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1]
+            f32x4 Y2[4][2];
+#pragma unroll
+            for (int oct = 0; oct < 2; ++oct) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const f16x8 ah = lds_h(w2s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w2s, (oct * 3 + tap) * 2 + 1, lane);
+#pragma unroll
+                    for (int part = 0; part < 3; ++part)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int src = (t >> 1) + tap, h = t & 1;
+                            const Op& b = src < 2 ? Yh[src][h][0] : Y1o[(src - 2) * 2 + h][0];
+                            acc[t] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[t]);
+                        }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j); pin(Y2[t][oct]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (DBG && p.dbg) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    dump_tile<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Yh[0][h][0] = Y1o[h][0]; Yh[1][h][0] = Y1o[2 + h][0];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { Yf[0][h][ct] = Y1[h][ct]; Yf[1][h][ct] = Y1[2 + h][ct]; }
+            }
+            // ---- pool 2x2 -> stage B input row q
+            float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m = fmaxf(Y2[h][ct][e], Y2[2 + h][ct][e]);
+                        m = fmaxf(m, dpp_shl1_zero(m));
+                        if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
+                    }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) store_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
+        hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
+    }
+}
+
+}  // namespace owh

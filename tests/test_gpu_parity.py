@@ -32,7 +32,7 @@ def heads():
     return {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in HEADS3}
 
 
-@pytest.fixture(scope="module", params=[1, 0, 2], ids=["mfma_rr", "valu", "mfma_lds"])
+@pytest.fixture(scope="module", params=[1, 3, 0, 2], ids=["mfma_rr", "mfma_f16x3", "valu", "mfma_lds"])
 def eng(request, emb, heads):
     e = StreamEngine(6, heads, emb, max_chunks=3, use_mfma=request.param, debug_layers=True)
     yield e
@@ -232,7 +232,7 @@ def test_mfma_and_valu_paths_agree(emb, heads):
     S = 70                                                            # not a multiple of any per-workgroup stream count
     pcm = W.synthetic_pcm(S, 1280 * 12, seed=61)
     outs = []
-    for mfma in (1, 0, 2):
+    for mfma in (1, 0, 2, 3):
         e = StreamEngine(S, heads, emb, use_mfma=mfma)
         try:
             outs.append(np.stack([e.step(pcm[:, 1280 * t: 1280 * (t + 1)]).copy() for t in range(12)]))
@@ -240,6 +240,7 @@ def test_mfma_and_valu_paths_agree(emb, heads):
             e.close()
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=TOL_SCORE)
     np.testing.assert_allclose(outs[0], outs[2], rtol=0, atol=TOL_SCORE)
+    np.testing.assert_allclose(outs[0], outs[3], rtol=0, atol=TOL_SCORE)
 
 
 def test_large_batch_properties(emb, heads):
