@@ -349,7 +349,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
         Timed t(h, 1);
-        if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 512)), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 256 * OWH_WPS_A)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(rstageA_kernel<DBG>, dim3(grid), dim3(256), 0, st, p);
     }
     auto fill = [&](RStageParams& p, const float* xin, float* xout, int first_layer, int sb, int sd, int spt) {

@@ -62,10 +62,28 @@ __device__ __forceinline__ f16x8 lds_h(const float* buf, int blk, int lane) {
     return *reinterpret_cast<const f16x8*>(buf + (blk * 64 + lane) * 4);
 }
 
-using HB = owr::RCfg<24, 48, 4, 16, 1, 2, 4, 2>;
-using HC = owr::RCfg<48, 72, 4, 8, 2, 2, 2, 2>;
-using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, 2>;
-using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, 2>;
+#ifndef OWH_WPS_A
+#define OWH_WPS_A 3
+#endif
+#ifndef OWH_WPS_B
+#define OWH_WPS_B 3
+#endif
+#ifndef OWH_WPS_C
+#define OWH_WPS_C 2
+#endif
+#ifndef OWH_WPS_D
+#define OWH_WPS_D 2
+#endif
+#ifndef OWH_WPS_E
+#define OWH_WPS_E 3
+#endif
+#ifndef OWH_RC_RP
+#define OWH_RC_RP 4
+#endif
+using HB = owr::RCfg<24, 48, 4, 16, 1, 2, 4, OWH_WPS_B>;
+using HC = owr::RCfg<48, 72, 4, 8, 2, 2, OWH_RC_RP, OWH_WPS_C>;
+using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, OWH_WPS_D>;
+using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
 #define OWH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
@@ -173,7 +191,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
 // stages B..E (parameters, geometry and memory layouts: owr::RStageParams / owr::RCfg, channel tiles NOT re-packed)
 // ------------------------------------------------------------------------------------------------
 template <class C, bool LAST, bool DBG>
-__global__ __launch_bounds__(256, 2) void hstage_kernel(owr::RStageParams p) {
+__global__ __launch_bounds__(256, C::WPS) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
@@ -197,9 +215,9 @@ __global__ __launch_bounds__(256, 2) void hstage_kernel(owr::RStageParams p) {
     float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
     float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
 
-    f32x4 Y[R][NCT];
 #pragma unroll
     for (int pass = 0; pass < C::NPASS; ++pass) {
+    f32x4 Y[R][NCT];
     Op Xo[R][KSA];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -286,9 +304,6 @@ __global__ __launch_bounds__(256, 2) void hstage_kernel(owr::RStageParams p) {
                     if ((f & 1) == 0) p.xout[((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4) + ct * 4 + e) * 64 + j * 16 + posn] = m;
                 }
     }
-    }   // pass
-    if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the chunk the last pass prefetched
-
     if (LAST) {
         static_assert(!LAST || (C::RO == 1 && C::FO == 1 && NCT == 6), "last stage pools to one position, 96 channels");
         const int pos = lane & 15, j = lane >> 4;
@@ -328,13 +343,15 @@ __global__ __launch_bounds__(256, 2) void hstage_kernel(owr::RStageParams p) {
             }
         }
     }
+    }   // pass
+    if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the chunk the last pass prefetched
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage A (parameters and layouts: owr::RAParams; w0 / w1 / w2 = hx-packed, hist2 tiles in plain D order)
 // ------------------------------------------------------------------------------------------------
 template <bool DBG>
-__global__ __launch_bounds__(256, 2) void hstageA_kernel(owr::RAParams p) {
+__global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p) {
     using namespace owr;
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -239,13 +239,23 @@ __device__ __forceinline__ void conv_time(const f32x4 (&h0)[NCTI], const f32x4 (
 constexpr int WBUF_FLOATS = 3 * 6 * 256;          // largest chunk: 3 taps x 6 channel tiles x 1 KB
 constexpr int WG_WAVES = 4;
 
+// a pointer the compiler can keep in SGPRs (the DMA below then uses the scalar-base + lane-offset address form instead of
+// one 64-bit VGPR address pair per block)
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+}
+
 template <int NBLK>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
+    const float* base = uniform_ptr(gsrc + wave * 256);
+    const unsigned voff = lane * 4;
 #pragma unroll
     for (int u = 0; u < (NBLK + WG_WAVES - 1) / WG_WAVES; ++u) {
         const int i = u * WG_WAVES + wave;
         if (i < NBLK)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + i * 256 + lane * 4),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + u * WG_WAVES * 256 + voff),
                                              (__attribute__((address_space(3))) void*)(ldst + i * 256), 16, 0, 0);
     }
 }
