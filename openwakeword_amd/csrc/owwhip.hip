@@ -120,6 +120,24 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
     out.assign(hbuf.size() / 2, 0.f);
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
 }
+// heads layer 1 (owh::heads_hx_kernel): k-step major [K/32][NH/16][part][64][8]; lane (i, g), half q <-> input 32ks + 8g + q
+void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, std::vector<float>& out) {
+    const int nks = K / 32, nct = NH / 16;
+    std::vector<_Float16> hbuf((size_t)nks * nct * 2 * 64 * 8, (_Float16)0.f);
+    for (int ks = 0; ks < nks; ++ks)
+        for (int ct = 0; ct < nct; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 8; ++q) {
+                    const int i = lane & 15, g = lane >> 4;
+                    const float v = wcat[(size_t)(32 * ks + 8 * g + q) * NH + 16 * ct + i] * owh::WSCALE;
+                    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                    const size_t blk = ((size_t)ks * nct + ct) * 2;
+                    hbuf[(blk * 64 + lane) * 8 + q] = hi;
+                    hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
+                }
+    out.assign(hbuf.size() / 2, 0.f);
+    memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
+}
 // conv0 (3x3, one input channel): one k-step, k = tap index (9 of 32 used)
 void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out) {
     std::vector<_Float16> hbuf((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
@@ -163,6 +181,8 @@ struct FastGroup {
     NetDesc* d_nets = nullptr;
     const float* d_w1pk = nullptr;
     const float* d_b1cat = nullptr;
+    const float* d_w1hx = nullptr;    // fp16-split k-step-major layer-1 weights (heads_hx_kernel)
+    std::vector<const float*> d_w2hx; // per net
 };
 
 constexpr int N_STATE = 11;
@@ -203,6 +223,7 @@ struct oww_ctx {
     const float* d_shift[20] = {};
     const float* d_conv0_mfma = nullptr;   // conv0 in MFMA k-step order (shared by the LDS-MFMA and register-resident kernels)
     NetDesc* d_allnets = nullptr;
+    std::vector<NetDesc> host_descs;  // device pointers of every net's arrays (host copy of d_allnets)
     std::vector<FastGroup> groups;
     std::vector<int> generic_nets;    // indices into nets (with verifier right after its primary)
     NetDesc* d_generic = nullptr;
@@ -425,6 +446,27 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 bool has = false;
                 for (int ni : g.nets) has |= h->nets[ni].head == only_head;
                 if (!has) continue;
+            }
+            if (h->hx) {
+                owh::HeadHxParams q{};
+                q.feat = base.feat; q.ext = base.ext; q.TR = base.TR; q.T = g.T; q.nfeat = base.nfeat; q.w1hx = g.d_w1hx;
+                q.raw = raw_out; q.NL = h->NL; q.S = n_active; q.accumulate_max = base.accumulate_max;
+                for (int i = 0; i < g.n_nets; ++i) {
+                    const NetHost& n = h->nets[g.nets[i]];
+                    const NetDesc d = h->host_descs[g.nets[i]];
+                    owh::HeadHxNet& o = q.net[i];
+                    o.w2hx = g.d_w2hx[i]; o.b1 = d.b1; o.ln1g = d.ln1g; o.ln1b = d.ln1b; o.b2 = d.b2; o.ln2g = d.ln2g; o.ln2b = d.ln2b;
+                    o.w3 = d.w3; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
+                }
+                const dim3 grid((n_active + 127) / 128);
+                const int lds = 2 * g.n_nets * 8 * 1024;
+                switch (g.n_nets) {
+                    case 1: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, dim3(256), lds, st, q); break;
+                    case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<2>, grid, dim3(256), lds, st, q); break;
+                    case 3: hipLaunchKernelGGL(owh::heads_hx_kernel<3>, grid, dim3(256), lds, st, q); break;
+                    default: hipLaunchKernelGGL(owh::heads_hx_kernel<4>, grid, dim3(256), lds, st, q); break;
+                }
+                continue;
             }
             HeadParams p = base;
             p.nets = g.d_nets; p.n_nets = g.n_nets; p.T = g.T; p.NH = g.NH; p.w1pk = g.d_w1pk; p.b1cat = g.d_b1cat;
@@ -705,7 +747,7 @@ int oww_commit(oww_ctx* h) {
     }
     // grouping: heads whose nets are all (hidden 64, n_out 1, sigmoid) share a fast group per T (<= 8 nets each)
     h->groups.clear(); h->generic_nets.clear();
-    struct GOff { size_t w1pk, b1cat; };
+    struct GOff { size_t w1pk, b1cat, w1hx; std::vector<size_t> w2hx; };
     std::vector<GOff> goff;
     for (size_t hi = 0; hi < h->heads.size(); ++hi) {
         const auto [nb, ne] = h->head_nets[hi];
@@ -713,7 +755,8 @@ int oww_commit(oww_ctx* h) {
         for (int ni = nb; ni < ne; ++ni) fast = fast && h->nets[ni].hidden == 64 && h->nets[ni].n_out == 1 && h->nets[ni].final_act == 0;
         if (!fast) { for (int ni = nb; ni < ne; ++ni) h->generic_nets.push_back(ni); continue; }
         FastGroup* g = nullptr;
-        for (auto& gg : h->groups) if (gg.T == h->nets[nb].T && gg.n_nets + (ne - nb) <= HD_MAXNETS) { g = &gg; break; }
+        const int cap = h->hx ? 4 : HD_MAXNETS;                      // heads_hx_kernel: at most four nets per launch
+        for (auto& gg : h->groups) if (gg.T == h->nets[nb].T && gg.n_nets + (ne - nb) <= cap) { g = &gg; break; }
         if (!g) { h->groups.push_back(FastGroup{}); g = &h->groups.back(); g->T = h->nets[nb].T; g->n_nets = 0; }
         for (int ni = nb; ni < ne; ++ni) { g->nets.push_back(ni); g->n_nets++; }
     }
@@ -727,7 +770,13 @@ int oww_commit(oww_ctx* h) {
             memcpy(&bcat[64 * gi], n.b1, 64 * sizeof(float));
         }
         pack_mfma(wcat.data(), g.T, 96, g.NH, pk);
-        goff.push_back({hb.add(pk), hb.add(bcat)});
+        GOff go{hb.add(pk), hb.add(bcat), 0, {}};
+        if (h->hx) {
+            pack_hx_w1(wcat.data(), (int)K, g.NH, pk);
+            go.w1hx = hb.add(pk);
+            for (int gi = 0; gi < g.n_nets; ++gi) { pack_hx(h->nets[g.nets[gi]].w2, 1, 64, 64, pk); go.w2hx.push_back(hb.add(pk)); }
+        }
+        goff.push_back(go);
     }
     HIPCHK(hipMalloc(&h->d_w, hb.data.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -754,6 +803,7 @@ int oww_commit(oww_ctx* h) {
     if (!h->nets.empty()) {
         std::vector<NetDesc> all;
         for (size_t ni = 0; ni < h->nets.size(); ++ni) all.push_back(make_desc((int)ni, 0));
+        h->host_descs = all;
         HIPCHK(hipMalloc(&h->d_allnets, all.size() * sizeof(NetDesc)));
         HIPCHK(hipMemcpy(h->d_allnets, all.data(), all.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
     }
@@ -764,6 +814,7 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(hipMalloc(&g.d_nets, ds.size() * sizeof(NetDesc)));
         HIPCHK(hipMemcpy(g.d_nets, ds.data(), ds.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
         g.d_w1pk = h->d_w + goff[gi].w1pk; g.d_b1cat = h->d_w + goff[gi].b1cat;
+        if (h->hx) { g.d_w1hx = h->d_w + goff[gi].w1hx; for (size_t o : goff[gi].w2hx) g.d_w2hx.push_back(h->d_w + o); }
         if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
     }
 
@@ -799,6 +850,10 @@ int oww_commit(oww_ctx* h) {
     if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
     if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
+    if (int rc = set_lds(owh::heads_hx_kernel<1>, 2 * 1 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<2>, 2 * 2 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<3>, 2 * 3 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<4>, 2 * 4 * 8 * 1024)) return rc;
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stageA_kernel<false>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stage_kernel<CfgB, true, false>, CfgB::LDS_BYTES)) return rc;

@@ -535,4 +535,185 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// wake-word heads, fp16-split GEMM form (model.py:299-302; architecture train.py:56-83)
+//   layer 1: D[64*NN hidden][stream] = W1[hidden][K = T*96] * F[K][stream]  -- K streamed 32 channels (one k-step) at a time:
+//            the weights of a k-step (NN*4 hidden tiles x hi/lo x 1 KB) go global -> LDS once per 4-wave workgroup (double
+//            buffered, global_load_lds), the feature operands of a wave's own 32 streams come straight from the feature ring
+//   LayerNorm + ReLU in registers (cross-lane part of the sums by two xor-shuffles), layer 2 (64x64 per net) chained on the
+//   D registers like the CNN layers, LayerNorm + ReLU, layer 3 dot product + sigmoid, hey_jarvis-style gating.
+// A workgroup = 4 waves x 2 stream tiles = 128 streams; NN <= 4 nets of hidden 64 per launch.
+// ------------------------------------------------------------------------------------------------
+struct HeadHxNet {
+    const float *w2hx;                       // [4 oct][2 ks][2 part][64][8 halves]
+    const float *b1, *ln1g, *ln1b, *b2, *ln2g, *ln2b, *w3, *b3;
+    int has_ln, role, head, out_col;
+};
+struct HeadHxParams {
+    const float* feat;      // ring [S][TR][96] or external [B][T][96] when ext != 0
+    int ext, TR, T;
+    const uint32_t* nfeat;
+    const float* w1hx;      // [T*3 ksteps][NN*4 ct][2 part][64][8 halves]
+    HeadHxNet net[4];
+    float* raw;             // [S][NL]
+    int NL, S, accumulate_max;
+};
+
+__device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int NN>
+__device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__ bias, const float* __restrict__ g,
+                                        const float* __restrict__ b, int has_ln, int j) {
+    // h: the 64 hidden values of one net for this lane's stream: tile ct, register e <-> hidden 16ct + 4j + e
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * j);
+        h[ct] = h[ct] * WUNSCALE + bb;
+    }
+    if (has_ln) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += h[ct][e];
+        const float mu = xsum4(sum) * (1.0f / 64.f);
+        float var = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = h[ct][e] - mu; var = fmaf(d, d, var); }
+        const float rs = 1.0f / sqrtf(xsum4(var) * (1.0f / 64.f) + 1e-5f);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + ct * 16 + 4 * j);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(b + ct * 16 + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[ct][e] = fmaxf((h[ct][e] - mu) * rs * gg[e] + be[e], 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[ct][e] = fmaxf(h[ct][e], 0.f);
+    }
+}
+
+template <int NN>
+__global__ __launch_bounds__(256, 2) void heads_hx_kernel(HeadHxParams p) {
+    using namespace owr;
+    constexpr int NCT = NN * 4;                 // hidden tiles of 16
+    constexpr int NBLK = NCT * 2;               // 1 KB blocks per k-step chunk
+    constexpr int CHUNK = NBLK * 256;           // floats
+    extern __shared__ __attribute__((aligned(16))) float hbuf[];      // 2 x CHUNK
+    const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KST = p.T * 3;
+    issue_chunk<NBLK>(p.w1hx, hbuf, wave, lane);
+
+    // this lane's streams (two tiles of 16) and the address of ring row t
+    int s[2];
+    const float* frow[2];
+    uint32_t slot0[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        s[t] = min((blockIdx.x * 4 + wave) * 32 + t * 16 + pos, p.S - 1);
+        if (p.ext) { frow[t] = p.feat + (size_t)s[t] * p.T * 96; slot0[t] = 0; }
+        else { frow[t] = p.feat + (size_t)s[t] * p.TR * 96; slot0[t] = p.nfeat[s[t]] + (uint32_t)(2 * p.TR - p.T + 1); }
+    }
+    auto load_b = [&](int ks, Op (&b)[2]) {
+        const int tr = ks / 3, c0 = (ks % 3) * 32 + 8 * j;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t slot = p.ext ? (uint32_t)tr : (slot0[t] + (uint32_t)tr) % (uint32_t)p.TR;
+            const float* src = frow[t] + (size_t)slot * 96 + c0;
+            b[t] = split_pair(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+        }
+    };
+    f32x4 acc[NCT][2];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    Op bcur[2], bnxt[2];
+    load_b(0, bcur);
+    chunk_sync();
+    for (int ks = 0; ks < KST; ++ks) {
+        const float* cur = hbuf + (ks & 1) * CHUNK;
+        if (ks + 1 < KST) {
+            issue_chunk<NBLK>(p.w1hx + (size_t)(ks + 1) * CHUNK, hbuf + ((ks + 1) & 1) * CHUNK, wave, lane);
+            load_b(ks + 1, bnxt);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < NCT; c2 += 2) {
+            const f16x8 ah0 = lds_h(cur, c2 * 2 + 0, lane), al0 = lds_h(cur, c2 * 2 + 1, lane);
+            const f16x8 ah1 = lds_h(cur, c2 * 2 + 2, lane), al1 = lds_h(cur, c2 * 2 + 3, lane);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[c2][t] = OWH_MFMA(part == 2 ? al0 : ah0, part == 1 ? bcur[t].l : bcur[t].h, acc[c2][t]);
+                    acc[c2 + 1][t] = OWH_MFMA(part == 2 ? al1 : ah1, part == 1 ? bcur[t].l : bcur[t].h, acc[c2 + 1][t]);
+                }
+            }
+        }
+        if (ks + 1 < KST) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; chunk_sync(); }
+    }
+    // ---- per net: bias, LayerNorm, ReLU, 64x64, bias, LayerNorm, ReLU, dot, sigmoid
+    float score[NN][2];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const HeadHxNet& net = p.net[n];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 h1[4] = {acc[4 * n][t], acc[4 * n + 1][t], acc[4 * n + 2][t], acc[4 * n + 3][t]};
+            ln_relu<NN>(h1, net.b1, net.ln1g, net.ln1b, net.has_ln, j);
+            Op ho[2];
+            to_ops<4>(h1, ho);
+            f32x4 h2[4];
+#pragma unroll
+            for (int oct = 0; oct < 4; ++oct) {
+                f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(net.w2hx + (((oct * 2 + k2) * 2 + 0) * 64 + lane) * 4);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(net.w2hx + (((oct * 2 + k2) * 2 + 1) * 64 + lane) * 4);
+                    a2 = OWH_MFMA(wh, ho[k2].h, a2);
+                    a2 = OWH_MFMA(wh, ho[k2].l, a2);
+                    a2 = OWH_MFMA(wl, ho[k2].h, a2);
+                }
+                h2[oct] = a2;
+            }
+            ln_relu<NN>(h2, net.b2, net.ln2g, net.ln2b, net.has_ln, j);
+            float z = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const f32x4 w3 = *reinterpret_cast<const f32x4*>(net.w3 + ct * 16 + 4 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z = fmaf(h2[ct][e], w3[e], z);
+            }
+            z = xsum4(z) + net.b3[0];
+            score[n][t] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+    // ---- gating + store (one lane group per stream: j == 0)
+    if (j == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int st = (blockIdx.x * 4 + wave) * 32 + t * 16 + pos;
+            if (st >= p.S) continue;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                if (p.net[n].role != 0) continue;
+                float sc = score[n][t];
+                if (n + 1 < NN && p.net[n + 1].role == 1 && p.net[n + 1].head == p.net[n].head && sc > 0.5f) sc = score[n + 1][t];
+                float* o = p.raw + (size_t)st * p.NL + p.net[n].out_col;
+                *o = p.accumulate_max ? fmaxf(*o, sc) : sc;
+            }
+        }
+    }
+}
+
 }  // namespace owh
