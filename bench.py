@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 STAGE_FLOPS = {"stageA": 1_880_064, "stageB": 3_096_576, "stageC": 3_649_536, "stageD": 1_658_880, "stageE": 940_032}
 MEL_BYTES = 3584            # 2560 B new PCM + 1024 B mel rows per stream-step
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA dense peak
+PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
+# f16 MFMAs (v_mfma_f32_16x16x32_f16, 16384 flop each) the fp16-split kernels execute per stream-step, channel padding included
+HX_MFMAS = {"stageA": 672, "stageB": 756, "stageC": 990, "stageD": 324, "stageE": 182}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -47,11 +50,12 @@ def head_flops(heads) -> int:
 def pmc_traffic(kernel: str, streams: int, args):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, produced by
     tools/pmc.sh on the same workload: FETCH_SIZE x2 + WRITE_SIZE); None when no pass matches this configuration."""
-    if args.valu or args.lds_mfma or args.f16x3 or streams != 131072:
+    if args.valu or args.lds_mfma or streams != 131072:
         return None
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        return {"hbm_bytes_per_launch": t[kernel + "_rr"]["hbm_bytes"], "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+        key = kernel + ("_rr" if args.fp32 else "_hx")
+        return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
     except Exception:
         return None
 
@@ -65,7 +69,9 @@ def main():
     ap.add_argument("--heads", default="alexa,hey_mycroft,hey_jarvis")
     ap.add_argument("--valu", action="store_true", help="plain-VALU kernels instead of MFMA (A/B only)")
     ap.add_argument("--lds-mfma", action="store_true", help="LDS-tiled MFMA kernels instead of the register-resident ones (A/B only)")
-    ap.add_argument("--f16x3", action="store_true", help="fp16-split (3 x f16 MFMA per fp32 product) form of the register-resident CNN")
+    ap.add_argument("--fp32", action="store_true", help="exact-fp32 MFMA form of the register-resident kernels instead of the default "
+                    "fp16-split form (three f16 MFMAs per fp32 product)")
+    ap.add_argument("--f16x3", action="store_true", help="(default) fp16-split form; kept for A/B scripts")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the cpu_baseline leg")
@@ -102,7 +108,7 @@ def main():
     # one side stream carries the engine's kernels AND the RCCL gather, so they are ordered without host syncs
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=(0 if args.valu else 2 if args.lds_mfma else 3 if args.f16x3 else 1), hip_stream=stream.cuda_stream)
+    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=(0 if args.valu else 2 if args.lds_mfma else 1 if args.fp32 else 3), hip_stream=stream.cuda_stream)
     NL = eng.n_labels
     eng.reset()
     if args.graph:
@@ -153,13 +159,13 @@ def main():
             "metric": "real-time audio frames/sec (80 ms frame, 3 wakewords), whole job; real-time streams = value/12.5",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f32" if (args.fp32 or args.valu or args.lds_mfma) else "f32 as 3xf16 split MFMA, fp32 accumulate"), "data": "synthetic",
             "config": {"workload": f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), "
                                    "80 ms frames, BASELINE configs[3] per-GPU shard" if S == 131072 else
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
                        "collective": "RCCL gather of scores per step" if world > 1 else "none",
-                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_f16x3" if args.f16x3 else "mfma_rr")), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
+                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_rr_fp32" if args.fp32 else "mfma_rr_f16x3")), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
             "realtime_streams": round(value / 12.5, 1),
             "frames_per_sec_per_gpu": round(value / world, 1),
             "scores_valid": ok,
@@ -168,18 +174,34 @@ def main():
             per = {k: (v["ms"] / max(v["launches"], 1)) for k, v in ktimes.items()}
             out["kernel_ms"] = {k: round(v, 4) for k, v in per.items()}
             dom = max(STAGE_FLOPS, key=lambda k: per[k])
-            tf = STAGE_FLOPS[dom] * S / (per[dom] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4), "traffic": pmc_traffic(dom, S, args),
+            f16 = not (args.fp32 or args.valu or args.lds_mfma)
+            peak = PEAK_F16_TFLOPS if f16 else PEAK_FP32_TFLOPS
+
+            def stage_roof(k):
+                tf = STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12           # algorithmic (fp32-equivalent) flops only
+                r = {"achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / peak, 4)}
+                if f16:
+                    ex = HX_MFMAS[k] * 16384 * S / (per[k] * 1e-3) / 1e12  # what the matrix pipe executes: 3 MFMAs per product + padding
+                    r.update({"executed_f16_tflops": round(ex, 1), "executed_frac_of_f16_peak": round(ex / peak, 4),
+                              "x_fp32_mfma_peak": round(tf / PEAK_FP32_TFLOPS, 3)})
+                return r
+
+            d = stage_roof(dom)
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s",
+                               "frac": d["frac"], "traffic": pmc_traffic(dom, S, args),
                                "flops_per_launch": STAGE_FLOPS[dom] * S, "avg_ms": round(per[dom], 4)}
+            if f16:
+                out["roofline"].update({k: d[k] for k in ("executed_f16_tflops", "executed_frac_of_f16_peak", "x_fp32_mfma_peak")})
+                out["roofline"]["note"] = ("fp32 products evaluated as 3 f16 MFMAs (hi/lo operand split, fp32 accumulate): 'achieved' counts the "
+                                           "algorithmic fp32 flops once, against the dense f16 MFMA peak; the scheme's own ceiling is peak/3")
             cnn_ms = sum(per[k] for k in STAGE_FLOPS)
             cnn_tf = sum(STAGE_FLOPS.values()) * S / (cnn_ms * 1e-3) / 1e12
+            hf = head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12
             out["roofline_all"] = {
-                "cnn_all_stages": {"achieved": round(cnn_tf, 2), "unit": "TFLOP/s", "frac": round(cnn_tf / PEAK_FP32_TFLOPS, 4)},
-                **{k: {"achieved": round(STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                       "frac": round(STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)} for k in STAGE_FLOPS},
-                "heads": {"achieved": round(head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                          "frac": round(head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)},
+                "cnn_all_stages": {"achieved": round(cnn_tf, 2), "unit": "TFLOP/s", "frac": round(cnn_tf / peak, 4),
+                                   "x_fp32_mfma_peak": round(cnn_tf / PEAK_FP32_TFLOPS, 3)},
+                **{k: stage_roof(k) for k in STAGE_FLOPS},
+                "heads": {"achieved": round(hf, 2), "unit": "TFLOP/s", "frac": round(hf / peak, 4)},
                 "mel": {"bound": "hbm", "achieved": round(MEL_BYTES * S / (per["mel"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": round(MEL_BYTES * S / (per["mel"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
             }

@@ -50,7 +50,10 @@ typedef struct oww_config {
     int32_t n_streams;     /* S: concurrent audio streams owned by this handle */
     int32_t max_chunks;    /* largest n_chunks a single oww_step may carry (>=1) */
     int32_t feature_ring;  /* rows of the per-stream feature ring; 0 = max head T (>=16) */
-    int32_t use_mfma;      /* CNN kernel family: 1 = register-resident fp32-MFMA kernels (default path),
+    int32_t use_mfma;      /* kernel family of the embedding CNN and the heads:
+                              3 = register-resident kernels, fp32 products as three f16 MFMAs (hi/lo split, fp32 accumulate;
+                                  default path, agrees with the fp32 families to fp32 round-off),
+                              1 = register-resident kernels on the exact fp32 MFMA,
                               2 = LDS-tiled fp32-MFMA kernels, 0 = plain-VALU kernels of the LDS-tiled dataflow */
     int32_t debug_layers;  /* 1 = keep per-layer CNN outputs of the last step for oww_debug_read */
     void*   stream;        /* hipStream_t to launch on; NULL = a stream owned by the handle */

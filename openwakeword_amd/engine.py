@@ -72,10 +72,14 @@ def _ptr(a: Optional[np.ndarray]):
 
 
 class StreamEngine:
-    """One GPU, S streams.  `heads` maps model name -> head dict (see weights.synthetic_head)."""
+    """One GPU, S streams.  `heads` maps model name -> head dict (see weights.synthetic_head).
+
+    use_mfma selects the kernel family of the embedding CNN / heads (include/owwhip.h): 3 = register-resident kernels with
+    every fp32 product evaluated as three f16 MFMAs (hi/lo operand split, fp32 accumulation; default, same tolerances as
+    fp32), 1 = the same kernels on the exact-fp32 MFMA, 2 = LDS-tiled fp32 MFMA kernels, 0 = plain VALU."""
 
     def __init__(self, n_streams: int, heads: Dict[str, dict], embedding: Optional[dict] = None,
-                 device: int = 0, max_chunks: int = 1, use_mfma: int = 1, debug_layers: bool = False,
+                 device: int = 0, max_chunks: int = 1, use_mfma: int = 3, debug_layers: bool = False,
                  feature_ring: int = 0, hip_stream: int = 0):
         self._lib = _lib.load()
         self._h = C.c_void_p()

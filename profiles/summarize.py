@@ -13,9 +13,13 @@ def short(name):
     for tag, s in (("StageCfg<24, 48", "stageB"), ("StageCfg<48, 72", "stageC"), ("StageCfg<72, 96", "stageD"), ("StageCfg<96, 96", "stageE")):
         if tag in name:
             return s + ("_lds(valu)" if ", false, " in name.split(">")[1] else "_lds")
-    for tag, s in (("RCfg<24, 48", "stageB"), ("RCfg<48, 72", "stageC"), ("RCfg<72, 96", "stageD"), ("RCfg<96, 96", "stageE"), ("rstageA_kernel", "stageA")):
-        if tag in name:
+    for tag, s in (("RCfg<24, 48", "stageB"), ("RCfg<48, 72", "stageC"), ("RCfg<72, 96", "stageD"), ("RCfg<96, 96", "stageE"), ("stageA_kernel", "stageA")):
+        if tag in name and ("owr::rstage" in ("owr::" + name) or name.startswith("rstage")):
             return s + "_rr"
+        if tag in name and name.startswith(("owh::hstage", "hstage")):
+            return s + "_hx"
+    if "heads_hx_kernel" in name:
+        return "heads_hx"
     return name.split("(")[0][:60]
 
 
