@@ -1,0 +1,151 @@
+"""onnx_ingest: the reference's model-file format read without the `onnx` package.  No real .onnx file exists offline, so the
+reader is pinned by a round trip: a minimal protobuf writer (below) emits ModelProto files with the reference's graph
+structures (train.py:56-83 heads, the 20-conv embedding model), onnx_ingest reads them back, and the oracle must give the
+same outputs from the re-read weights."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oww_oracle as O
+from openwakeword_amd import onnx_ingest, weights as W
+
+
+# ---- minimal ONNX (protobuf) writer ---------------------------------------------------------------------------------
+def _vi(x):
+    x &= (1 << 64) - 1
+    out = b""
+    while True:
+        b = x & 0x7F
+        x >>= 7
+        out += bytes([b | (0x80 if x else 0)])
+        if not x:
+            return out
+
+
+def _ld(fno, payload):
+    return _vi((fno << 3) | 2) + _vi(len(payload)) + payload
+
+
+def _tensor(name, arr, raw=True):
+    arr = np.ascontiguousarray(arr, np.float32)
+    t = b"".join(_vi((1 << 3) | 0) + _vi(d) for d in arr.shape) + _vi((2 << 3) | 0) + _vi(1) + _ld(8, name.encode())
+    return t + (_ld(9, arr.tobytes()) if raw else _ld(4, arr.tobytes()))
+
+
+def _attr_i(name, v):
+    return _ld(1, name.encode()) + _vi((3 << 3) | 0) + _vi(v) + _vi((20 << 3) | 0) + _vi(2)
+
+
+def _attr_f(name, v):
+    return _ld(1, name.encode()) + _vi((2 << 3) | 5) + struct.pack("<f", v) + _vi((20 << 3) | 0) + _vi(1)
+
+
+def _node(op, inputs, outputs, attrs=()):
+    return b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs) + \
+        _ld(3, (op + "_" + outputs[0]).encode()) + _ld(4, op.encode()) + b"".join(_ld(5, a) for a in attrs)
+
+
+def _model(nodes, inits):
+    graph = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"g") + b"".join(_ld(5, t) for t in inits)
+    return _vi((1 << 3) | 0) + _vi(8) + _ld(7, graph)
+
+
+def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True):
+    nodes, inits, cur = [_node("Flatten", ["x"], ["f0"], [_attr_i("axis", 1)])], [], "f0"
+    nets = [head["net"]] + ([head["net2"]] if head["kind"] == "gated" else [])
+    for k, net in enumerate(nets):
+        cur = "f0"
+        for li in (1, 2, 3):
+            w, b = net[f"w{li}"], net[f"b{li}"]
+            if use_matmul:
+                inits += [_tensor(f"n{k}w{li}", w, raw), _tensor(f"n{k}b{li}", b, raw)]
+                nodes += [_node("MatMul", [cur, f"n{k}w{li}"], [f"n{k}m{li}"]), _node("Add", [f"n{k}m{li}", f"n{k}b{li}"], [f"n{k}l{li}"])]
+            else:
+                inits += [_tensor(f"n{k}w{li}", w.T, raw), _tensor(f"n{k}b{li}", b, raw)]       # torch Linear: [out, in], transB=1
+                nodes.append(_node("Gemm", [cur, f"n{k}w{li}", f"n{k}b{li}"], [f"n{k}l{li}"], [_attr_i("transB", 1)]))
+            cur = f"n{k}l{li}"
+            if li < 3:
+                ln = net.get(f"ln{li}")
+                if ln is not None:
+                    inits += [_tensor(f"n{k}g{li}", ln[0], raw), _tensor(f"n{k}be{li}", ln[1], raw)]
+                    if layernorm_op:
+                        nodes.append(_node("LayerNormalization", [cur, f"n{k}g{li}", f"n{k}be{li}"], [f"n{k}n{li}"], [_attr_f("epsilon", 1e-5)]))
+                    else:
+                        nodes += [_node("Mul", [cur, f"n{k}g{li}"], [f"n{k}q{li}"]), _node("Add", [f"n{k}q{li}", f"n{k}be{li}"], [f"n{k}n{li}"])]
+                    cur = f"n{k}n{li}"
+                nodes.append(_node("Relu", [cur], [f"n{k}r{li}"]))
+                cur = f"n{k}r{li}"
+        if head["kind"] == "multiclass":
+            nodes += [_node("Relu", [cur], [f"n{k}rr"]), _node("Softmax", [f"n{k}rr"], [f"n{k}out"])]
+        else:
+            nodes.append(_node("Sigmoid", [cur], [f"n{k}out"]))
+    open(path, "wb").write(_model(nodes, inits))
+
+
+def write_embedding(path, emb, fold_last_bns=0):
+    nodes, inits, cur = [], [], "x"
+    n = len(emb["conv"])
+    for li, w in enumerate(emb["conv"]):
+        inits.append(_tensor(f"w{li}", np.transpose(w, (3, 2, 0, 1))))                       # HWIO -> OIHW
+        folded = li < n - 1 and li >= n - 1 - fold_last_bns
+        if folded:
+            scale, shift = W.bn_scale_shift(emb["bn"][li])
+            inits[-1] = _tensor(f"w{li}", np.transpose(w * scale, (3, 2, 0, 1)))
+            inits.append(_tensor(f"b{li}", shift))
+            nodes.append(_node("Conv", [cur, f"w{li}", f"b{li}"], [f"c{li}"]))
+        else:
+            nodes.append(_node("Conv", [cur, f"w{li}"], [f"c{li}"]))
+        cur = f"c{li}"
+        if li == 0:
+            nodes.append(_node("Relu", [cur], ["r0"]))
+            cur = "r0"
+        if li < n - 1 and not folded:
+            for nm, arr in zip("gbmv", emb["bn"][li]):
+                inits.append(_tensor(f"{nm}{li}", arr))
+            nodes.append(_node("BatchNormalization", [cur, f"g{li}", f"b{li}", f"m{li}", f"v{li}"], [f"n{li}"], [_attr_f("epsilon", W.BN_EPS)]))
+            cur = f"n{li}"
+    open(path, "wb").write(_model(nodes, inits))
+
+
+# ---- tests -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [("alexa", {}), ("hey_jarvis", {}), ("timer", {}), ("weather", dict(layernorm_op=False, use_matmul=True, raw=False))])
+def test_head_round_trip(tmp_path, name, kw):
+    head = W.synthetic_head(name, 77)
+    path = os.path.join(tmp_path, name + ".onnx")
+    write_head(path, head, **kw)
+    got = onnx_ingest.load_head(path)
+    assert (got["kind"], got["T"], got["hidden"], got["n_out"]) == (head["kind"], head["T"], head["hidden"], head["n_out"])
+    feats = np.random.default_rng(1).normal(0, 2, (5, head["T"], 96)).astype(np.float32)
+    np.testing.assert_array_equal(O.head_stage(feats, got, np.float32), O.head_stage(feats, head, np.float32))
+
+
+def test_embedding_round_trip(tmp_path):
+    emb = W.synthetic_embedding(55)
+    x = np.random.default_rng(2).normal(10, 1.5, (2, 76, 32, 1)).astype(np.float32)
+    want = O.embedding_stage(x, emb, np.float64)
+    for fold in (0, 3):
+        path = os.path.join(tmp_path, f"emb{fold}.onnx")
+        write_embedding(path, emb, fold_last_bns=fold)
+        got = onnx_ingest.load_embedding(path)
+        assert W.embedding_param_count(got) == W.embedding_param_count(emb) == 332088
+        np.testing.assert_allclose(O.embedding_stage(x, got, np.float64), want, rtol=0, atol=1e-6 if fold else 1e-9)
+
+
+def test_unrecognised_graphs_raise(tmp_path):
+    path = os.path.join(tmp_path, "bad.onnx")
+    open(path, "wb").write(_model([_node("Relu", ["x"], ["y"])], []))
+    with pytest.raises(ValueError):
+        onnx_ingest.load_head(path)
+    with pytest.raises(ValueError):
+        onnx_ingest.load_embedding(path)
+    open(path, "wb").write(b"\x00\x01garbage")
+    with pytest.raises(ValueError):
+        onnx_ingest.load_graph(path)
+
+
+def test_melspectrogram_check(tmp_path):
+    path = os.path.join(tmp_path, "mel.onnx")
+    open(path, "wb").write(_model([_node("MatMul", ["p", "fb"], ["m"])], [_tensor("fb", W.mel_filterbank())]))
+    assert onnx_ingest.check_melspectrogram(path)["filterbank_max_abs_diff"] == 0.0
