@@ -130,7 +130,7 @@ def test_embedding_round_trip(tmp_path):
         write_embedding(path, emb, fold_last_bns=fold)
         got = onnx_ingest.load_embedding(path)
         assert W.embedding_param_count(got) == W.embedding_param_count(emb) == 332088
-        np.testing.assert_allclose(O.embedding_stage(x, got, np.float64), want, rtol=0, atol=1e-6 if fold else 1e-9)
+        np.testing.assert_allclose(O.embedding_stage(x, got, np.float64), want, rtol=0, atol=1e-5 if fold else 1e-9)  # folding rounds w*scale to fp32
 
 
 def test_unrecognised_graphs_raise(tmp_path):
