@@ -114,6 +114,9 @@ int  oww_get_raw(oww_ctx* h, float* out);
  *          scratch state and CLOBBERS the streaming state of streams [0,B): reset afterwards.
  * oww_head: features [B][T][96] -> raw outputs [B][n_out] of head `head` (model.py:137-138). */
 int  oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db);
+/* the same with one clamp floor PER CLIP: what the reference's CPU path computes when it maps _get_melspectrogram over
+ * the clips of a batch (utils.py:243-290, embed_clips / feature extraction for training, utils.py:542-601) */
+int  oww_mel_clips(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db);
 int  oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float* out);
 int  oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out);
 

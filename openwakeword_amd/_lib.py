@@ -39,6 +39,7 @@ SYMBOLS = {
     "oww_scores_dev": (_P, [_P]),
     "oww_get_raw": (C.c_int, [_P, _P]),
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "oww_mel_clips": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_embed": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     "oww_get_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),

@@ -983,7 +983,7 @@ int oww_get_raw(oww_ctx* h, float* out) {
     return OWW_OK;
 }
 
-int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) {
+static int mel_impl(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db, bool per_clip) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_mel: handle not committed");
     if (!pcm || !out_db || B < 1 || n < 512) return fail(OWW_EINVAL, "oww_mel: bad argument (B=%d n=%d)", B, n);
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -996,19 +996,26 @@ int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db)
     do {
         if (hipMemcpyAsync(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: H2D failed"); break; }
         if ((rc = launch_mel(h, d_in, B, n, F, 0, d_out, d_max))) break;
-        std::vector<float> mx(B);
-        if (hipMemcpyAsync(mx.data(), d_max, B * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
-        float gmax = -INFINITY;                       // one clamp floor for the whole call (ipynb cell 15: log_spec.max())
-        for (float v : mx) gmax = std::max(gmax, v);
         const size_t tot = (size_t)B * F * 32;
-        hipLaunchKernelGGL(clamp_db_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, d_out, tot, gmax - 80.0f);
+        if (per_clip) {
+            hipLaunchKernelGGL(clamp_db_rows_kernel, dim3((F * 32 + 255) / 256, B), dim3(256), 0, h->stream, d_out, F * 32, d_max);
+        } else {
+            std::vector<float> mx(B);
+            if (hipMemcpyAsync(mx.data(), d_max, B * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
+            float gmax = -INFINITY;                       // one clamp floor for the whole call (ipynb cell 15: log_spec.max())
+            for (float v : mx) gmax = std::max(gmax, v);
+            hipLaunchKernelGGL(clamp_db_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, d_out, tot, gmax - 80.0f);
+        }
         if (hipMemcpyAsync(out_db, d_out, tot * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
     } while (0);
     (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_max);
     return rc;
 }
+
+int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) { return mel_impl(h, pcm, B, n, out_db, false); }
+int oww_mel_clips(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) { return mel_impl(h, pcm, B, n, out_db, true); }
 
 int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float* out) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_embed: handle not committed");

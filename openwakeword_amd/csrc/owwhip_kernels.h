@@ -827,6 +827,11 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     }
 }
 
+__global__ void clamp_db_rows_kernel(float* x, int per_clip, const float* smax) {       // one floor per clip
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < per_clip) { float* q = x + (size_t)blockIdx.y * per_clip + i; *q = fmaxf(*q, smax[blockIdx.y] - 80.0f); }
+}
+
 __global__ void clamp_db_kernel(float* x, size_t n, float floor_db) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = fmaxf(x[i], floor_db);

@@ -107,6 +107,7 @@ class StreamEngine:
             self.close()
             raise
         self.n_labels = self._lib.oww_n_labels(self._h)
+        self.n_streams_padded = (self.n_streams + 31) // 32 * 32
         self.feature_ring = max([16] + [int(h["T"]) for h in heads.values()] + [int(feature_ring)])
 
     # ---- lifetime
@@ -191,6 +192,18 @@ class StreamEngine:
         B, n = pcm.shape
         out = np.empty((B, (n - 512) // 160 + 1, 32), dtype=np.float32)
         _lib.check(self._lib.oww_mel(self._h, _ptr(pcm), B, n, _ptr(out)))
+        return out
+
+    def mel_clips(self, pcm: np.ndarray) -> np.ndarray:
+        """Like mel(), but every clip gets its own clamp floor (the reference's per-clip CPU path, utils.py:243-290)."""
+        pcm = np.ascontiguousarray(np.atleast_2d(pcm))
+        if pcm.dtype != np.int16:
+            raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {pcm.dtype} data.")
+        B, n = pcm.shape
+        if B > self.n_streams_padded:
+            raise ValueError(f"at most {self.n_streams_padded} clips per call (the handle's stream count)")
+        out = np.empty((B, (n - 512) // 160 + 1, 32), dtype=np.float32)
+        _lib.check(self._lib.oww_mel_clips(self._h, _ptr(pcm), B, n, _ptr(out)))
         return out
 
     def embed(self, mel_rows: np.ndarray) -> np.ndarray:

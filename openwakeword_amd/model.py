@@ -96,6 +96,26 @@ class AudioFeatures:
         out = self.engine.embed(spec[None, : 76 + 8 * (n_win - 1)].astype(np.float32))[0]
         return out
 
+    def embed_clips(self, x: np.ndarray, batch_size: int = 128, ncpu: int = 1) -> np.ndarray:
+        """Embeddings of N equally long clips, `[N, samples] int16 -> [N, n_windows, 96]` (utils.py:354-385: mel per clip,
+        76-row windows every 8 rows, the embedding model over all windows).  `ncpu` is accepted for signature
+        compatibility; batching is by the handle's stream count.  Runs the streaming kernels from a zero state per clip
+        and therefore clobbers the streaming state of the streams it borrows: call reset() before streaming again."""
+        x = np.asarray(x)
+        if x.ndim != 2 or x.dtype != np.int16:
+            raise ValueError("embed_clips expects a 2-D int16 array [N, samples]")
+        cap = min(int(batch_size), self.engine.n_streams_padded)
+        out = []
+        for o in range(0, x.shape[0], cap):
+            spec = self.engine.mel_clips(x[o:o + cap]) / 10.0 + 2.0
+            n_win = (spec.shape[1] - 76) // 8 + 1
+            if n_win < 1:
+                raise ValueError("clips are shorter than one 76-frame embedding window (775 ms)")
+            out.append(self.engine.embed(np.ascontiguousarray(spec[:, : 76 + 8 * (n_win - 1)], dtype=np.float32)))
+        self.engine.reset()                 # borrowed streams back to the start-up state ...
+        self.reset()                        # ... and this object's stream re-seeded like a fresh AudioFeatures
+        return np.concatenate(out, axis=0)
+
     def reset(self):
         """utils.py:172-178: the feature ring restarts from the embeddings of 4 s of random audio."""
         self._pending = np.empty(0, dtype=np.int16)
@@ -114,35 +134,30 @@ class AudioFeatures:
         if x.dtype != np.int16:                                     # utils.py:195-197 (lists are cast, 194)
             raise ValueError("Input data must be 16-bit integers (i.e., 16-bit PCM audio)."
                              f"You provided {x.dtype} data.")
-        processed = 0
-        if self.raw_data_remainder.shape[0] != 0:
+        # 1280-sample alignment (utils.py:413-430): samples beyond the last whole chunk wait in `raw_data_remainder`
+        # -- but only once at least one whole chunk has accumulated; shorter input simply accumulates
+        if self.raw_data_remainder.shape[0]:
             x = np.concatenate((self.raw_data_remainder, x))
             self.raw_data_remainder = np.empty(0, dtype=np.int16)
-        if self.accumulated_samples + x.shape[0] >= CHUNK:
-            remainder = (self.accumulated_samples + x.shape[0]) % CHUNK
-            if remainder != 0:
-                even = x[0:-remainder]
-                self._pending = np.concatenate((self._pending, even))
-                self.accumulated_samples += len(even)
-                self.raw_data_remainder = x[-remainder:]
-            else:
-                self._pending = np.concatenate((self._pending, x))
-                self.accumulated_samples += x.shape[0]
-        else:
-            self.accumulated_samples += x.shape[0]
-            self._pending = np.concatenate((self._pending, x))
+        total = self.accumulated_samples + x.shape[0]
+        take = x.shape[0] - (total % CHUNK if total >= CHUNK else 0)
+        self._pending = np.concatenate((self._pending, x[:take]))
+        self.raw_data_remainder = x[take:]
+        self.accumulated_samples += take
 
-        if self.accumulated_samples >= CHUNK and self.accumulated_samples % CHUNK == 0:
-            k = self.accumulated_samples // CHUNK
-            if k > self.engine.max_chunks:
-                raise ValueError(f"a single call may carry at most {self.engine.max_chunks} x 1280 samples "
-                                 f"(max_chunks); got {self.accumulated_samples}")
-            self.last_scores = self.engine.step_raw(self._pending[None, :])[0]
-            self._n_features = min(self._n_features + k, self.feature_buffer_max_len)
-            self._pending = np.empty(0, dtype=np.int16)
-            processed = self.accumulated_samples
-            self.accumulated_samples = 0
-        return processed if processed != 0 else self.accumulated_samples
+        n = self.accumulated_samples
+        if n < CHUNK or n % CHUNK:
+            return n                                             # nothing processed yet: the caller repeats its last scores
+        k = n // CHUNK
+        if k > self.engine.max_chunks:
+            raise ValueError(f"a single call may carry at most {self.engine.max_chunks} x 1280 samples "
+                             f"(max_chunks); got {n}")
+        # one device step: mel over the k chunks (one clamp floor), k embeddings, heads per chunk, max over chunks
+        self.last_scores = self.engine.step_raw(self._pending[None, :])[0]
+        self._n_features = min(self._n_features + k, self.feature_buffer_max_len)
+        self._pending = np.empty(0, dtype=np.int16)
+        self.accumulated_samples = 0
+        return n
 
     def get_features(self, n_feature_frames: int = 16, start_ndx: int = -1) -> np.ndarray:
         have = min(self._n_features, self.engine.feature_ring)
@@ -242,131 +257,130 @@ class Model:
     def close(self):
         self._engine.close()
 
-    # model.py:215-224
+    # ---- label bookkeeping ---------------------------------------------------------------------------------------
     def get_parent_model_from_label(self, label):
-        parent_model = ""
-        for mdl in self.class_mapping.keys():
-            if label in self.class_mapping[mdl].values():
-                parent_model = mdl
-            elif label in self.class_mapping.keys() and label == mdl:
-                parent_model = mdl
-        return parent_model
+        """Model that owns a prediction label (model.py:215-224): a binary model's label is its own name, a multiclass
+        model owns the values of its class mapping.  The last match wins, '' when nothing matches."""
+        owner = ""
+        for name, mapping in self.class_mapping.items():
+            if label in mapping.values() or label == name:
+                owner = name
+        return owner
 
-    # model.py:226-230
     def reset(self):
+        """Model.reset (model.py:226-230): empty score history, fresh front-end state (new random feature-ring seed)."""
         self.prediction_buffer = defaultdict(partial(deque, maxlen=30))
         self.preprocessor.reset()
 
-    def _suppress_noise_with_speex(self, x: np.ndarray, frame_size: int = 160):      # model.py:481-504
-        cleaned = [self.speex_ns.process(x[i:i + frame_size].tobytes()) for i in range(0, x.shape[0], frame_size)]
-        return np.frombuffer(b"".join(cleaned), np.int16)
+    def _suppress_noise_with_speex(self, x: np.ndarray, frame_size: int = 160):
+        # host-side pre-filter exactly as in the reference (model.py:481-504): 10 ms frames through SpeexDSP
+        pieces = (self.speex_ns.process(x[o:o + frame_size].tobytes()) for o in range(0, x.shape[0], frame_size))
+        return np.frombuffer(b"".join(pieces), np.int16)
 
-    # model.py:232-386
+    # ---- one predict() call = the reference's model.py:232-386, split into its four phases ------------------------
+    def _raw_outputs(self, name: str, n_prepared: int):
+        """Per-model output vector of this call: device result when at least one 80 ms chunk was completed (already the
+        maximum over chunks for longer calls, model.py:287-298), otherwise the previous prediction / zeros (299-307)."""
+        lo, hi = self._cols[name]
+        if n_prepared >= CHUNK:
+            return self.preprocessor.last_scores[lo:hi]
+        if self.model_outputs[name] == 1:
+            history = self.prediction_buffer[name]
+            return [history[-1] if len(history) else 0]
+        return [0] * (max(int(k) for k in self.class_mapping[name]) + 1)
+
+    def _apply_verifiers(self, scores: dict, name: str):
+        # model.py:320-328: a pickled scikit-learn classifier re-scores frames the base model already likes
+        for label, value in list(scores.items()):
+            if value < self.custom_verifier_threshold:
+                continue
+            verifier = self.custom_verifier_models.get(self.get_parent_model_from_label(label), False)
+            if verifier:
+                scores[label] = verifier.predict_proba(self.preprocessor.get_features(self.model_inputs[name]))[0][-1]
+
+    def _gate(self, scores: dict, n_prepared: int, patience: dict, threshold: dict, debounce_time: float):
+        # model.py:340-359 -- the rules look at scores buffered BEFORE this call
+        if not patience and not debounce_time > 0:
+            return
+        if threshold == {}:
+            raise ValueError("Error! When using the `patience` argument, threshold "
+                             "values must be provided via the `threshold` argument!")
+        if patience != {} and debounce_time > 0:
+            raise ValueError("Error! The `patience` and `debounce_time` arguments cannot be used together!")
+        for label in scores:
+            if scores[label] == 0.0:
+                continue
+            owner = self.get_parent_model_from_label(label)
+            past = np.array(self.prediction_buffer[label])
+            if owner in patience:
+                need = patience[owner]
+                if (past[-need:] >= threshold[owner]).sum() < need:
+                    scores[label] = 0.0
+            elif debounce_time > 0 and owner in threshold:
+                span = int(np.ceil(debounce_time / (n_prepared / 16000)))
+                if scores[label] >= threshold[owner] and (past[-span:] >= threshold[owner]).sum() > 0:
+                    scores[label] = 0.0
+
     def predict(self, x: np.ndarray, patience: dict = {}, threshold: dict = {}, debounce_time: float = 0.0,
                 timing: bool = False):
         if not isinstance(x, np.ndarray):
             raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(x)}.")
         import time
-        if timing:
-            timing_dict: Dict[str, Dict] = {"models": {}}
-            t0 = time.time()
-        n_prepared_samples = self.preprocessor(self._suppress_noise_with_speex(x) if self.speex_ns else x)
-        if timing:
-            # the device evaluates mel, embedding and every head in the same call
-            timing_dict["models"]["preprocessor"] = time.time() - t0
+        clock = {"models": {}}
+        t0 = time.time()
+        n_prepared = self.preprocessor(self._suppress_noise_with_speex(x) if self.speex_ns else x)
+        clock["models"]["preprocessor"] = time.time() - t0          # mel, embedding AND every head run in this one device call
 
-        predictions = {}
-        raw = self.preprocessor.last_scores
-        for mdl in self.models.keys():
-            if timing:
-                t1 = time.time()
-            lo, hi = self._cols[mdl]
-            if n_prepared_samples >= 1280:
-                prediction = raw[lo:hi]             # multi-chunk calls: already the max over chunks (model.py:298)
-            else:                                    # model.py:299-307: not enough samples yet
-                if self.model_outputs[mdl] == 1:
-                    prediction = [self.prediction_buffer[mdl][-1]] if len(self.prediction_buffer[mdl]) > 0 else [0]
-                else:
-                    n_classes = max([int(i) for i in self.class_mapping[mdl].keys()])
-                    prediction = [0] * (n_classes + 1)
-            if self.model_outputs[mdl] == 1:
-                predictions[mdl] = prediction[0]
+        scores: dict = {}
+        for name in self.models:
+            t1 = time.time()
+            out = self._raw_outputs(name, n_prepared)
+            if self.model_outputs[name] == 1:
+                scores[name] = out[0]
             else:
-                for int_label, cls in self.class_mapping[mdl].items():
-                    predictions[cls] = prediction[int(int_label)]
+                scores.update({cls: out[int(idx)] for idx, cls in self.class_mapping[name].items()})
+            if self.custom_verifier_models:
+                self._apply_verifiers(scores, name)
+            for label in scores:                                    # model.py:331-333: warm-up, first five frames
+                if len(self.prediction_buffer[label]) < 5:
+                    scores[label] = 0.0
+            clock["models"][name] = time.time() - t1
+        self._gate(scores, n_prepared, patience, threshold, debounce_time)
+        for label, value in scores.items():                         # model.py:362-363
+            self.prediction_buffer[label].append(value)
+        return (scores, clock) if timing else scores
 
-            if self.custom_verifier_models != {}:                                # model.py:320-328
-                for cls in predictions.keys():
-                    if predictions[cls] >= self.custom_verifier_threshold:
-                        parent_model = self.get_parent_model_from_label(cls)
-                        if self.custom_verifier_models.get(parent_model, False):
-                            predictions[cls] = self.custom_verifier_models[parent_model].predict_proba(
-                                self.preprocessor.get_features(self.model_inputs[mdl]))[0][-1]
+    # ---- conveniences on top of predict() --------------------------------------------------------------------------
+    @staticmethod
+    def _read_wav(path: str) -> np.ndarray:
+        with wave.open(path, mode="rb") as f:
+            return np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
 
-            for cls in predictions.keys():                                       # model.py:331-333
-                if len(self.prediction_buffer[cls]) < 5:
-                    predictions[cls] = 0.0
-            if timing:
-                timing_dict["models"][mdl] = time.time() - t1
-
-        if patience != {} or debounce_time > 0:                                  # model.py:340-359
-            if threshold == {}:
-                raise ValueError("Error! When using the `patience` argument, threshold "
-                                 "values must be provided via the `threshold` argument!")
-            if patience != {} and debounce_time > 0:
-                raise ValueError("Error! The `patience` and `debounce_time` arguments cannot be used together!")
-            for mdl in predictions.keys():
-                parent_model = self.get_parent_model_from_label(mdl)
-                if predictions[mdl] != 0.0:
-                    if parent_model in patience.keys():
-                        scores = np.array(self.prediction_buffer[mdl])[-patience[parent_model]:]
-                        if (scores >= threshold[parent_model]).sum() < patience[parent_model]:
-                            predictions[mdl] = 0.0
-                    elif debounce_time > 0:
-                        if parent_model in threshold.keys():
-                            n_frames = int(np.ceil(debounce_time / (n_prepared_samples / 16000)))
-                            recent_predictions = np.array(self.prediction_buffer[mdl])[-n_frames:]
-                            if predictions[mdl] >= threshold[parent_model] and \
-                               (recent_predictions >= threshold[parent_model]).sum() > 0:
-                                predictions[mdl] = 0.0
-
-        for mdl in predictions.keys():                                           # model.py:362-363
-            self.prediction_buffer[mdl].append(predictions[mdl])
-        return (predictions, timing_dict) if timing else predictions
-
-    # model.py:388-426
     def predict_clip(self, clip: Union[str, np.ndarray], padding: int = 1, chunk_size=1280, **kwargs):
-        if isinstance(clip, str):
-            with wave.open(clip, mode="rb") as f:
-                data = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
-        elif isinstance(clip, np.ndarray):
-            data = clip
+        """Stream a whole clip through predict() (model.py:388-426): `padding` seconds of silence either side, calls of
+        `chunk_size` samples; like the reference the final partial chunk (and one full one) is not fed."""
+        data = self._read_wav(clip) if isinstance(clip, str) else clip
         if padding:
-            data = np.concatenate((np.zeros(16000 * padding).astype(np.int16), data,
-                                   np.zeros(16000 * padding).astype(np.int16)))
-        predictions = []
-        for i in range(0, data.shape[0] - chunk_size, chunk_size):
-            predictions.append(self.predict(data[i:i + chunk_size], **kwargs))
-        return predictions
+            silence = np.zeros(16000 * padding, dtype=np.int16)
+            data = np.concatenate((silence, data, silence))
+        starts = range(0, data.shape[0] - chunk_size, chunk_size)
+        return [self.predict(data[o:o + chunk_size], **kwargs) for o in starts]
 
-    # model.py:428-479
     def _get_positive_prediction_frames(self, file: str, threshold: float = 0.5, return_type: str = "features", **kwargs):
-        with wave.open(file, mode="rb") as f:
-            data = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
-        positive_data = defaultdict(list)
-        step_size = 1280
-        for i in range(0, data.shape[0] - step_size, step_size):
-            predictions = self.predict(data[i:i + step_size], **kwargs)
-            for lbl in predictions.keys():
-                if predictions[lbl] >= threshold:
-                    mdl = self.get_parent_model_from_label(lbl)
-                    if return_type == "features":
-                        positive_data[lbl].append(self.preprocessor.get_features(self.model_inputs[mdl]))
-                    if return_type == "audio":
-                        context = data[max(0, i - 16000 * 3):i + 16000]
-                        if len(context) == 16000 * 4:
-                            positive_data[lbl].append(context)
-        return {lbl: np.vstack(v) for lbl, v in positive_data.items()}
+        """Features (or 4 s of audio) behind every frame scoring >= threshold (model.py:428-479; false-positive mining)."""
+        data = self._read_wav(file)
+        found = defaultdict(list)
+        for o in range(0, data.shape[0] - CHUNK, CHUNK):
+            for label, value in self.predict(data[o:o + CHUNK], **kwargs).items():
+                if value < threshold:
+                    continue
+                if return_type == "features":
+                    found[label].append(self.preprocessor.get_features(self.model_inputs[self.get_parent_model_from_label(label)]))
+                elif return_type == "audio":
+                    context = data[max(0, o - 3 * 16000):o + 16000]
+                    if len(context) == 4 * 16000:
+                        found[label].append(context)
+        return {label: np.vstack(v) for label, v in found.items()}
 
 
 class BatchedModel:

@@ -147,3 +147,25 @@ def test_batched_model_matches_single_stream_models(golden):
         bm.close()
         for m in singles:
             m.close()
+
+
+@gpu
+def test_embed_clips_matches_oracle(golden):
+    """AudioFeatures.embed_clips (utils.py:354-385): per-clip mel clamp, 76-row windows every 8 rows."""
+    from oracle import oww_oracle as O
+    from openwakeword_amd import Model
+    w = _weights(["alexa"])
+    m = Model(wakeword_models=["alexa"], weights=w)
+    try:
+        clip = golden["pcm/hey_jane"]
+        x = np.stack([clip[:16000], clip[8000:24000] // 4, np.zeros(16000, np.int16), W.synthetic_pcm(1, 16000, seed=9)[0]])
+        got = m.preprocessor.embed_clips(x, batch_size=3)           # two device batches
+        oracle = O.OracleAudioFeatures(w["embedding"], init_noise=np.zeros(64000, np.int16))
+        want = np.stack([oracle.clip_embeddings(c) for c in x])
+        assert got.shape == want.shape == (4, 3, 96)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+        # the object streams normally afterwards
+        out = m.predict(np.zeros(1280, np.int16))
+        assert set(out) == {"alexa"}
+    finally:
+        m.close()
