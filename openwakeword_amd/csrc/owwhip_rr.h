@@ -251,6 +251,9 @@ template <int NBLK>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
     const float* base = uniform_ptr(gsrc + wave * 256);
     const unsigned voff = lane * 4;
+#ifdef OWR_EXP_NODMA
+    return;
+#endif
 #pragma unroll
     for (int u = 0; u < (NBLK + WG_WAVES - 1) / WG_WAVES; ++u) {
         const int i = u * WG_WAVES + wave;
@@ -260,8 +263,12 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, floa
     }
 }
 __device__ __forceinline__ void chunk_sync() {
+#ifndef OWR_EXP_NOWAIT          // (timing experiments only: results are wrong without the wait / barrier)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef OWR_EXP_NOBARRIER
     __syncthreads();
+#endif
 }
 __device__ __forceinline__ f32x4 lds_w(const float* buf, int blk, int lane) {
     return *reinterpret_cast<const f32x4*>(buf + (blk * 64 + lane) * 4);

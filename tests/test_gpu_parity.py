@@ -155,6 +155,33 @@ def test_streaming_every_layer_and_score(eng, emb, heads, golden):
                 h = O._pool(h, *pool)
 
 
+def test_all_catalogue_heads_together(emb):
+    """Every pretrained model of the reference's registry at once (openwakeword/__init__.py:26-60): five 64-wide heads
+    (six networks: two launches of the grouped head kernel) + the multiclass `timer` (generic kernel, T = 34)."""
+    names = ["alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather"]
+    heads = {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in names}
+    S = 5
+    e = StreamEngine(S, heads, emb)
+    try:
+        assert e.n_labels == 5 + 7 and e.feature_ring == 34
+        models = oracle_streams(e, heads, emb, S, seed0=700)
+        pcm = W.synthetic_pcm(S, 1280 * 9, seed=81)
+        for t in range(9):
+            x = pcm[:, 1280 * t: 1280 * (t + 1)]
+            got = e.step_raw(x)
+            for s in range(S):
+                col = 0
+                for n in names:
+                    h = heads[n]
+                    feats = models[s].preprocessor
+                    models[s].predict(x[s]) if n == names[0] else None
+                    want = O.head_stage(feats.get_features(h["T"]), h, np.float64)[0]
+                    np.testing.assert_allclose(got[s, col: col + h["n_out"]], want, rtol=0, atol=TOL_SCORE, err_msg=n)
+                    col += h["n_out"]
+    finally:
+        e.close()
+
+
 def test_multi_chunk_calls(eng, emb, heads):
     """n_chunks>1: one mel pass with a single clamp floor, one embedding per chunk, max over chunks (model.py:287-298)."""
     S = 6
