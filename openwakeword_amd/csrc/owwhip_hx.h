@@ -85,6 +85,14 @@ using HC = owr::RCfg<48, 72, 4, 8, 2, 2, OWH_RC_RP, OWH_WPS_C>;
 using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, OWH_WPS_D>;
 using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
+#ifndef OWH_OCT_SCHEDBAR
+#define OWH_OCT_SCHEDBAR 1
+#endif
+#if OWH_OCT_SCHEDBAR
+#define OWH_OCT_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define OWH_OCT_SB() do {} while (0)
+#endif
 #define OWH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
 // chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
@@ -138,12 +146,21 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
-        __builtin_amdgcn_sched_barrier(0);
+        OWH_OCT_SB();
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
     }
 }
 
-// 3x1 (time) layer: rows h0, h1 (history) and in[0..NR-1] in operand form; out row r uses rows r, r+1, r+2
+// 3x1 (time) layer: rows h0, h1 (history) and in[0..NR-1] in operand form; out row r uses rows r, r+1, r+2.
+// Software pipelined over the output-channel tiles: the MFMA chain of tile k is issued interleaved with the BatchNorm /
+// activation epilogue of tile k-1 (a wave issues in order, so VALU work only overlaps a MFMA if it sits between two MFMAs
+// in program order; OWH_PIPE pins one MFMA : OWH_PIPE_VALU VALU instructions with sched_group_barrier).
+#ifndef OWH_PIPE
+#define OWH_PIPE 1
+#endif
+#ifndef OWH_PIPE_VALU
+#define OWH_PIPE_VALU 2
+#endif
 template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
@@ -151,39 +168,57 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = 3 * KSI * 2;
+    f32x4 prev[NR];
 #pragma unroll
-    for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
-        if (oct + 1 < NCTO) issue_chunk<NBLK>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+    for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
+        if (oct < NCTO) {
+            const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+            if (oct + 1 < NCTO) issue_chunk<NBLK>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
 #pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
+            for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-            for (int ks = 0; ks < KSI; ++ks) {
-                const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
-                const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                for (int ks = 0; ks < KSI; ++ks) {
+                    const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
+                    const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
 #pragma unroll
-                for (int part = 0; part < 3; ++part)
+                    for (int part = 0; part < 3; ++part)
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const int src = r + tap;
-                        const int ri = src >= 2 ? src - 2 : 0;
-                        const Op& b = src == 0 ? h0[ks] : (src == 1 ? h1[ks] : in[ri][ks]);
-                        acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[r]);
-                    }
-            }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if (BN) out[r][oct] = bn_act<true>(acc[r], scale, shift, oct, j);
-            else out[r][oct] = acc[r] * post;
-            pin(out[r][oct]);
+                        for (int r = 0; r < NR; ++r) {
+                            const int src = r + tap;
+                            const int ri = src >= 2 ? src - 2 : 0;
+                            const Op& b = src == 0 ? h0[ks] : (src == 1 ? h1[ks] : in[ri][ks]);
+                            acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[r]);
+                        }
+                }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+        if (oct > 0) {                                       // epilogue of the previous tile
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (BN) out[r][oct - 1] = bn_act<true>(prev[r], scale, shift, oct - 1, j);
+                else out[r][oct - 1] = prev[r] * post;
+                pin(out[r][oct - 1]);
+            }
+        }
+#if OWH_PIPE
+        if (oct > 0 && oct < NCTO) {
+#pragma unroll
+            for (int i = 0; i < 9 * KSI * NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, OWH_PIPE_VALU, 0);
+            }
+        }
+#endif
+        if (oct < NCTO) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) prev[r] = acc[r];
+            OWH_OCT_SB();
+            if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+        }
     }
 }
 
