@@ -654,16 +654,23 @@ __device__ __forceinline__ void dft8(float* re, float* im) {
 }
 
 constexpr int MEL_NT = 256;
-constexpr int MEL_XBUF = 1760 + 512;    // samples of one 8-frame group (+ slack so partial groups read zeros)
+constexpr int MEL_WX = 672 + 8;         // samples a wave needs for its two frames (160 + 512), padded
 constexpr int MEL_PBINS = 120;          // FFT bins 2..121 are the only ones the filterbank touches
 
+// wave-local ordering point: the LDS operations of one wave execute in order, so data exchanged between the lanes of ONE
+// wave through LDS needs no s_barrier -- only the outstanding LDS operations must have been issued/completed and the
+// compiler must not move accesses across this point
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One workgroup (4 waves) per stream-step; wave w owns frames 2w and 2w+1 of every 8-frame group from the PCM samples to
+// the log-mel values (its own LDS regions, no workgroup barrier); the waves only meet once per call for the clamp maximum.
 __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
-    __shared__ float s_x[MEL_XBUF];
+    __shared__ float s_x[4][MEL_WX];
     __shared__ float s_hann[400];
     __shared__ float s_re[4][576];
     __shared__ float s_im[4][576];
     __shared__ float s_pow[8][MEL_PBINS + 8];
-    __shared__ float s_red[4];
+    __shared__ float s_red[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     for (int i = tid; i < 400; i += MEL_NT) s_hann[i] = p.hann[i];
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
         sincospif(-(float)(lane * k) / 256.f, &tw1i[k], &tw1r[k]);          // exp(-2 pi i lane k / 512)
         sincospif(-(float)((lane & 7) * k) / 32.f, &tw2i[k], &tw2r[k]);     // exp(-2 pi i m0 k / 64)
     }
-    // mel filter of this thread's output bin
+    // mel filter of this thread's output bin; thread (fr, mbin) with fr = tid >> 5 in {2 wave, 2 wave + 1}: its own wave's frames
     const int mbin = tid & 31, fr = tid >> 5;
     const int mstart = p.mel_start[mbin] - 2;
     float taps[16];
@@ -682,21 +689,27 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     for (int t = 0; t < 16; ++t) taps[t] = p.mel_taps[mbin * 16 + t];
     const int n_groups = (p.n_frames + 7) / 8;
     const int hist = p.streaming ? 480 : 0;
+    float* sx = s_x[wave];
+    float* xr = s_re[wave];
+    float* xi = s_im[wave];
+    __syncthreads();                             // s_hann
 
-    for (int s = blockIdx.x; s < p.S; s += gridDim.x) {
+    int it = 0;
+    for (int s = blockIdx.x; s < p.S; s += gridDim.x, ++it) {
         const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
+        const int16_t* tail = p.tail + (size_t)s * 480;
         const bool first = p.streaming && (p.nfeat[s] == 0);
         float vmax = -INFINITY;
         float last_db = 0.f;
         for (int g = 0; g < n_groups; ++g) {
-            __syncthreads();                     // previous group's readers of s_x / s_pow are done
-            // ---- load the group's samples: virtual index c0 + i, c = [tail(hist) ; pcm]
-            const int c0 = g * 1280;
-            for (int i = tid * 8; i < MEL_XBUF; i += MEL_NT * 8) {
+            // ---- this wave's samples: virtual index c0 + i of [tail(hist) ; pcm], c0 = first sample of frame 2*wave
+            const int c0 = g * 1280 + 320 * wave;
+            wave_sync();                         // previous group's readers of sx / s_pow (same wave) are done
+            for (int i = lane * 8; i < MEL_WX; i += 64 * 8) {
                 const int c = c0 + i;
                 float v[8];
                 if (c + 8 <= hist) {
-                    const int4 raw = *reinterpret_cast<const int4*>(p.tail + (size_t)s * 480 + c);
+                    const int4 raw = *reinterpret_cast<const int4*>(tail + c);
                     const int16_t* h = reinterpret_cast<const int16_t*>(&raw);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
@@ -711,27 +724,24 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                     for (int e = 0; e < 8; ++e) {
                         const int cc = c + e;
                         float x = 0.f;
-                        if (cc < hist) x = (float)p.tail[(size_t)s * 480 + cc];
+                        if (cc < hist) x = (float)tail[cc];
                         else if (cc - hist < p.n_samples) x = (float)pcm[cc - hist];
                         v[e] = x;
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s_x[i + e] = v[e];
+                for (int e = 0; e < 8; ++e) sx[i + e] = v[e];
             }
-            __syncthreads();
-            // ---- one complex FFT per wave: frames fa = 2*wave, fb = fa + 1 of this group
+            wave_sync();
+            // ---- one complex FFT per wave: z = frame_a + i * frame_b (frames 2*wave and 2*wave + 1 of this group)
             float re[8], im[8];
-            {
-                const int oa = 160 * (2 * wave), ob = oa + 160;
 #pragma unroll
-                for (int n2 = 0; n2 < 8; ++n2) {
-                    const int n = 64 * n2 + lane;
-                    const bool in = (n >= 56) && (n < 456);
-                    const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
-                    re[n2] = w * s_x[oa + n];
-                    im[n2] = w * s_x[ob + n];
-                }
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const int n = 64 * n2 + lane;
+                const bool in = (n >= 56) && (n < 456);
+                const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
+                re[n2] = w * sx[n];
+                im[n2] = w * sx[160 + n];
             }
             dft8(re, im);
 #pragma unroll
@@ -740,11 +750,9 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 im[k] = re[k] * tw1i[k] + im[k] * tw1r[k];
                 re[k] = r;
             }
-            float* xr = s_re[wave];
-            float* xi = s_im[wave];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { xr[k * 72 + lane] = re[k]; xi[k * 72 + lane] = im[k]; }
-            __syncthreads();
+            wave_sync();
             {
                 const int q = lane >> 3, m0 = lane & 7;
 #pragma unroll
@@ -757,17 +765,17 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 im[k] = re[k] * tw2i[k] + im[k] * tw2r[k];
                 re[k] = r;
             }
-            __syncthreads();
+            wave_sync();
             {
                 const int q = lane >> 3, m0 = lane & 7;
 #pragma unroll
                 for (int k1 = 0; k1 < 8; ++k1) { xr[(q * 8 + k1) * 9 + m0] = re[k1]; xi[(q * 8 + k1) * 9 + m0] = im[k1]; }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int m0 = 0; m0 < 8; ++m0) { re[m0] = xr[lane * 9 + m0]; im[m0] = xi[lane * 9 + m0]; }
             dft8(re, im);
-            __syncthreads();
+            wave_sync();
             {
                 // lane = k0*8 + k1 holds Z[k0 + 8*k1 + 64*k2], k2 = 0..7; only k<128 and k>=384 are needed
                 const int kb = (lane >> 3) + 8 * (lane & 7);
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 xr[kb + 384] = re[6];  xi[kb + 384] = im[6];
                 xr[kb + 448] = re[7];  xi[kb + 448] = im[7];
             }
-            __syncthreads();
+            wave_sync();
             for (int i = lane; i < MEL_PBINS; i += 64) {
                 const int k = i + 2;
                 const float zr = xr[k], zi = xi[k], yr = xr[512 - k], yi = xi[512 - k];
@@ -785,8 +793,8 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 s_pow[2 * wave][i] = 0.25f * (ar * ar + ai * ai);
                 s_pow[2 * wave + 1][i] = 0.25f * (br * br + bi * bi);
             }
-            __syncthreads();
-            // ---- mel + log: thread (fr, mbin)
+            wave_sync();
+            // ---- mel + log: thread (fr, mbin), frames of its own wave
             const int frame = g * 8 + fr;
             if (frame < p.n_frames) {
                 float acc = 0.f;
@@ -800,13 +808,12 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 if (n_groups > 1 || !p.streaming) p.out[((size_t)s * p.n_frames + frame) * 32 + mbin] = db;
             }
         }
-        // ---- block max over the whole call
+        // ---- workgroup maximum over the whole call (the only point where the four waves meet)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) s_red[it & 1][wave] = vmax;
         __syncthreads();
-        if (lane == 0) s_red[wave] = vmax;
-        __syncthreads();
-        vmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        vmax = fmaxf(fmaxf(s_red[it & 1][0], s_red[it & 1][1]), fmaxf(s_red[it & 1][2], s_red[it & 1][3]));
         if (p.streaming) {
             const float floor_db = vmax - 80.0f;
             for (int g = 0; g < n_groups; ++g) {
@@ -817,9 +824,19 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 *o = (db == INFINITY) ? 1.0f : fmaxf(db, floor_db) / 10.0f + 2.0f;
             }
             // new 480-sample tail = last 480 samples of [tail ; pcm]
-            for (int i = tid; i < 480; i += MEL_NT) {
-                const int src = p.n_samples - 480 + i;
-                p.tail[(size_t)s * 480 + i] = (src >= 0) ? pcm[src] : p.tail[(size_t)s * 480 + p.n_samples + i];
+            if (p.n_samples >= 480) {
+                for (int i = tid; i < 480; i += MEL_NT) p.tail[(size_t)s * 480 + i] = pcm[p.n_samples - 480 + i];
+            } else {
+                // shorter call: the tail shifts; read everything before anyone overwrites it
+                int16_t keep[2];
+                int n_keep = 0;
+                for (int i = tid; i < 480; i += MEL_NT) {
+                    const int src = p.n_samples - 480 + i;
+                    keep[n_keep++] = (src >= 0) ? pcm[src] : p.tail[(size_t)s * 480 + p.n_samples + i];
+                }
+                __syncthreads();
+                n_keep = 0;
+                for (int i = tid; i < 480; i += MEL_NT) p.tail[(size_t)s * 480 + i] = keep[n_keep++];
             }
         } else if (tid == 0) {
             p.smax[s] = vmax;
