@@ -29,14 +29,37 @@ constexpr float WUNSCALE = 1.0f / 256.0f;
 // operand pair (hi, lo) of one k-step of one position tile
 struct Op { f16x8 h, l; };
 
+#ifndef OWH_MIXSPLIT
+#define OWH_MIXSPLIT 1     // residual halves by v_fma_mix{lo,hi}_f16 (f16 source read in place): 1.5 instead of 2.6 VALU ops per value
+#endif
+template <bool MIX = (OWH_MIXSPLIT != 0)>
 __device__ __forceinline__ Op split_pair(const f32x4 a, const f32x4 b) {
     Op o;
+    if constexpr (MIX) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float x0 = v < 2 ? a[2 * v] : b[2 * v - 4], x1 = v < 2 ? a[2 * v + 1] : b[2 * v - 3];
+        const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)x0, (_Float16)x1});       // v_cvt_pk_f16_f32
+        unsigned lp;
+        // lo16 = f16(x0 - f32(hp.lo16)), hi16 = f16(x1 - f32(hp.hi16)); op_sel_hi marks source 0 as f16, op_sel picks its half
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(lp) : "v"(hp), "v"(x0), "v"(x1));
+        h[v] = hp; l[v] = lp;
+    }
+    o.h = __builtin_bit_cast(f16x8, h);
+    o.l = __builtin_bit_cast(f16x8, l);
+    } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const _Float16 ha = (_Float16)a[e], hb = (_Float16)b[e];
         o.h[e] = ha; o.h[4 + e] = hb;
         o.l[e] = (_Float16)(a[e] - (float)ha);
         o.l[4 + e] = (_Float16)(b[e] - (float)hb);
+    }
     }
     return o;
 }
@@ -666,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void heads_hx_kernel(HeadHxParams p) {
         for (int t = 0; t < 2; ++t) {
             const uint32_t slot = p.ext ? (uint32_t)tr : (slot0[t] + (uint32_t)tr) % (uint32_t)p.TR;
             const float* src = frow[t] + (size_t)slot * 96 + c0;
-            b[t] = split_pair(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+            b[t] = split_pair<false>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));   // (the asm form is slower here)
         }
     };
     f32x4 acc[NCT][2];
