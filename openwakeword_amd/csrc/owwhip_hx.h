@@ -351,16 +351,24 @@ __global__ __launch_bounds__(256, C::WPS) void hstage_kernel(owr::RStageParams p
         const int gn = s / SPTN, spn = s % SPTN;
         const int posn = spn * FO + f / 2;
 #pragma unroll
-        for (int ro = 0; ro < R / C::PT; ++ro)
+        for (int ro = 0; ro < R / C::PT; ++ro) {
+            float pm[NCT][4];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float m = Y[ro * C::PT][ct][e];
                     if (C::PT == 2) m = fmaxf(m, Y[ro * C::PT + 1][ct][e]);
-                    m = fmaxf(m, dpp_shl1_zero(m));
-                    if ((f & 1) == 0) p.xout[((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4) + ct * 4 + e) * 64 + j * 16 + posn] = m;
+                    pm[ct][e] = fmaxf(m, dpp_shl1_zero(m));
                 }
+            if ((f & 1) == 0) {                                        // one predicated region per pooled row
+                float* xo = p.xout + ((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4)) * 64 + j * 16 + posn;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xo[(ct * 4 + e) * 64] = pm[ct][e];
+            }
+        }
     }
     if (LAST) {
         static_assert(!LAST || (C::RO == 1 && C::FO == 1 && NCT == 6), "last stage pools to one position, 96 channels");
@@ -573,17 +581,25 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
                 for (int ct = 0; ct < 2; ++ct) { Yf[0][h][ct] = Y1[h][ct]; Yf[1][h][ct] = Y1[2 + h][ct]; }
             }
             // ---- pool 2x2 -> stage B input row q
-            float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64);
+            float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64) + j * 16 + (pos >> 1);
+            float pm[2][2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float m = fmaxf(Y2[h][ct][e], Y2[2 + h][ct][e]);
-                        m = fmaxf(m, dpp_shl1_zero(m));
-                        if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
+                        const float m = fmaxf(Y2[h][ct][e], Y2[2 + h][ct][e]);
+                        pm[h][ct][e] = fmaxf(m, dpp_shl1_zero(m));
                     }
+            if ((pos & 1) == 0) {                                      // one predicated region for all sixteen stores
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xo[(ct * 4 + e) * 64 + h * 8] = pm[h][ct][e];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
