@@ -98,6 +98,12 @@ void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                     }
 }
 
+// the f16 halves of 2^8 * w must stay finite: |w| < 255 (trained conv / linear weights are orders of magnitude below)
+bool hx_in_range(const float* w, size_t n) {
+    for (size_t i = 0; i < n; ++i) if (!(std::fabs(w[i]) * owh::WSCALE < 65000.f)) return false;
+    return true;
+}
+
 // fp16-split operand order (owwhip_hx.h): blocks [oct][tap][ks][part hi/lo] of 64 lanes x 8 halves; lane (i, g), half q
 // <-> weight of input channel 16*(2ks + q/4) + 4g + q%4 and output channel 16oct + i, pre-scaled by 2^8
 void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
@@ -705,7 +711,11 @@ int oww_commit(oww_ctx* h) {
             const LayerDef& L = kLayers[l];
             const size_t nw = (size_t)L.kh * L.kw * L.cin * L.cout;
             if (!h->mfma) o_conv[l] = hb.add(q, nw);
-            else if (h->hx) { if (l == 0) pack_hx_conv0(q, pk); else pack_hx(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
+            else if (h->hx) {
+                if (!hx_in_range(q, nw)) return fail(OWW_EINVAL, "conv layer %d: weight magnitude too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1", l);
+                if (l == 0) pack_hx_conv0(q, pk); else pack_hx(q, 3, L.cin, L.cout, pk);
+                o_conv[l] = hb.add(pk);
+            }
             else if (h->rr && l > 0) { pack_rr(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
             else if (l == 0) {
                 // conv0: K = 9 taps padded to 12 -> three k-steps; lane (i, j) of k-step s holds w[k = 4s+j][cout = 16ct+i]
@@ -772,9 +782,13 @@ int oww_commit(oww_ctx* h) {
         pack_mfma(wcat.data(), g.T, 96, g.NH, pk);
         GOff go{hb.add(pk), hb.add(bcat), 0, {}};
         if (h->hx) {
+            if (!hx_in_range(wcat.data(), wcat.size())) return fail(OWW_EINVAL, "head weights too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1");
             pack_hx_w1(wcat.data(), (int)K, g.NH, pk);
             go.w1hx = hb.add(pk);
-            for (int gi = 0; gi < g.n_nets; ++gi) { pack_hx(h->nets[g.nets[gi]].w2, 1, 64, 64, pk); go.w2hx.push_back(hb.add(pk)); }
+            for (int gi = 0; gi < g.n_nets; ++gi) {
+                if (!hx_in_range(h->nets[g.nets[gi]].w2, 64 * 64)) return fail(OWW_EINVAL, "head weights too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1");
+                pack_hx(h->nets[g.nets[gi]].w2, 1, 64, 64, pk); go.w2hx.push_back(hb.add(pk));
+            }
         }
         goff.push_back(go);
     }
