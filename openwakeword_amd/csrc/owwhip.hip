@@ -391,19 +391,19 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
         Timed t(h, 2);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xB, h->d_xC, 7, 4, 5, RC::SPT);
         Timed t(h, 3);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xC, h->d_xD, 11, 6, 7, RD::SPT);
         Timed t(h, 4);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
@@ -411,7 +411,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.hist19 = h->d_state[10]; p.w19 = h->d_conv[19]; p.feat = h->d_feat; p.emb = h->d_emb; p.nfeat = h->d_nfeat; p.TR = h->TR;
         p.dbg_off[4] = dbg_off[19];
         Timed t(h, 5);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     HIPCHK(hipGetLastError());
@@ -507,7 +507,10 @@ int launch_mel(oww_ctx* h, const int16_t* d_pcm, int n_streams, int n_samples, i
     p.pcm = d_pcm; p.n_samples = n_samples; p.n_frames = n_frames; p.streaming = streaming;
     p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.out = out; p.smax = smax;
     p.hann = h->d_hann; p.mel_start = h->d_mstart; p.mel_taps = h->d_taps; p.S = n_streams;
-    const int grid = std::min(n_streams, 256 * 8);
+#ifndef OWK_MEL_WGS
+#define OWK_MEL_WGS 6      // resident mel workgroups per CU (24 KB LDS each); the grid is persistent: one full wave of workgroups
+#endif
+    const int grid = std::min(n_streams, 256 * OWK_MEL_WGS);
     Timed t(h, 0);
     hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(MEL_NT), 0, h->stream, p);
     HIPCHK(hipGetLastError());

@@ -26,6 +26,35 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float WSCALE = 256.0f;            // weights are stored as f16 halves of 2^8 * w
 constexpr float WUNSCALE = 1.0f / 256.0f;
 
+// Optional (OWH_PKF32=1, off): BatchNorm + activation and the masked tap combine on register pairs with v_pk_fma_f32 /
+// v_pk_mul_f32.  17 % fewer VALU instructions in stage C, but measured 1-2 % SLOWER per step: a packed fp32 instruction
+// occupies the VALU for two passes on this part, and the extra DPP hazard nops cost more than the saved issue slots.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef OWH_PKF32
+#define OWH_PKF32 0
+#endif
+template <bool BN>
+__device__ __forceinline__ f32x4 bn_act(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift,
+                                        int oct, int j) {
+    if (!BN) return v;
+#if OWH_PKF32
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + oct * 16 + 4 * j);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + oct * 16 + 4 * j);
+    f32x4 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 y = __builtin_elementwise_fma(f32x2{v[2 * h], v[2 * h + 1]}, f32x2{sc[2 * h], sc[2 * h + 1]},
+                                                  f32x2{sh[2 * h], sh[2 * h + 1]});
+        const f32x2 t = y * 0.2f;
+        r[2 * h] = fmaxf(fmaxf(t[0], y[0]), -0.4f);
+        r[2 * h + 1] = fmaxf(fmaxf(t[1], y[1]), -0.4f);
+    }
+    return r;
+#else
+    return owr::bn_act<BN>(v, scale, shift, oct, j);
+#endif
+}
+
 // operand pair (hi, lo) of one k-step of one position tile
 struct Op { f16x8 h, l; };
 
@@ -85,6 +114,9 @@ __device__ __forceinline__ f16x8 lds_h(const float* buf, int blk, int lane) {
     return *reinterpret_cast<const f16x8*>(buf + (blk * 64 + lane) * 4);
 }
 
+#ifndef OWH_WG
+#define OWH_WG 4           // waves per workgroup of stages B..E (they share one weight chunk stream through LDS)
+#endif
 #ifndef OWH_WPS_A
 #define OWH_WPS_A 3
 #endif
@@ -126,14 +158,16 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
-    const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
+    // 0/1 multipliers instead of selects: the DPP shift then folds into the multiply / fused multiply-add (v_mul_f32_dpp,
+    // v_fmac_f32_dpp): one VALU instruction per shifted value (VALU time is not hidden behind 16-cycle MFMAs)
+    const float mfirst = (pos & (F - 1)) == 0 ? 0.f : 1.f, mlast = (pos & (F - 1)) == F - 1 ? 0.f : 1.f;
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
         const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
         float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
-        if (oct + 1 < NCTO) issue_chunk<NBLK>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+        if (oct + 1 < NCTO) issue_chunk<NBLK, OWH_WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, OWH_WG>(w_next, nxt, wave, lane);
         f32x4 res[NT], accs[2][NT];
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
@@ -144,7 +178,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && first) ? 0.f : l; }
+                    for (int e = 0; e < 4; ++e) acc[t][e] = F < 16 ? dpp_shr1_zero(accs[0][t][e]) * mfirst : dpp_shr1_zero(accs[0][t][e]);
                 }
             }
 #pragma unroll
@@ -163,7 +197,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 if (ti < 2) accs[ti][t] = acc[t];
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float hh = dpp_shl1_zero(accs[1][t][e]); res[t][e] = acc[t][e] + ((F < 16 && last) ? 0.f : hh); }
+                    for (int e = 0; e < 4; ++e)
+                        res[t][e] = F < 16 ? fmaf(dpp_shl1_zero(accs[1][t][e]), mlast, acc[t][e]) : acc[t][e] + dpp_shl1_zero(accs[1][t][e]);
                 }
             }
         }
@@ -198,8 +233,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
         if (oct < NCTO) {
             const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
             float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
-            if (oct + 1 < NCTO) issue_chunk<NBLK>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
+            if (oct + 1 < NCTO) issue_chunk<NBLK, OWH_WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, OWH_WG>(w_next, nxt, wave, lane);
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -249,7 +284,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
 // stages B..E (parameters, geometry and memory layouts: owr::RStageParams / owr::RCfg, channel tiles NOT re-packed)
 // ------------------------------------------------------------------------------------------------
 template <class C, bool LAST, bool DBG>
-__global__ __launch_bounds__(256, C::WPS) void hstage_kernel(owr::RStageParams p) {
+__global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
@@ -258,13 +293,13 @@ __global__ __launch_bounds__(256, C::WPS) void hstage_kernel(owr::RStageParams p
     static_assert(NB * 256 <= WBUF_FLOATS, "chunk fits the LDS buffer");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int g = blockIdx.x * C::WAVES + wave;
+    int g = blockIdx.x * OWH_WG + wave;
     __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
     __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
-    issue_chunk<NBA>(p.w[0], wbuf, wave, lane);
-    for (int i = threadIdx.x; i < 4 * NCT * 16; i += 256) {
+    issue_chunk<NBA, OWH_WG>(p.w[0], wbuf, wave, lane);
+    for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * OWH_WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
         sbn[l][0][c] = p.scale[l][c];
         sbn[l][1][c] = p.shift[l][c];

@@ -662,13 +662,50 @@ constexpr int MEL_PBINS = 120;          // FFT bins 2..121 are the only ones the
 // compiler must not move accesses across this point
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// The 672(+8) samples wave `wave` needs for frames 2*wave, 2*wave+1 of group g of stream s, as raw int16 in registers
+// (lane l: samples 8l..8l+7 and, lanes < 21, 512+8l..): virtual index c of [tail(hist) ; pcm], zero beyond the input.
+// Issued one loop iteration ahead of its use so the HBM latency overlaps the previous FFT.
+__device__ __forceinline__ void mel_fetch(const MelParams& p, int s, int g, int wave, int lane, int hist, int4 (&raw)[2]) {
+    const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
+    const int16_t* tail = p.tail + (size_t)s * 480;
+    const int c0 = g * 1280 + 320 * wave;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = lane * 8 + u * 512;
+        if (i >= MEL_WX) continue;
+        const int c = c0 + i;
+        if (c + 8 <= hist) {
+            raw[u] = *reinterpret_cast<const int4*>(tail + c);
+        } else if (c >= hist && c - hist + 8 <= p.n_samples && ((reinterpret_cast<uintptr_t>(pcm + (c - hist)) & 15) == 0)) {
+            raw[u] = *reinterpret_cast<const int4*>(pcm + (c - hist));
+        } else {
+            alignas(16) int16_t h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int cc = c + e;
+                int16_t x = 0;
+                if (cc < hist) x = tail[cc];
+                else if (cc - hist < p.n_samples) x = pcm[cc - hist];
+                h[e] = x;
+            }
+            raw[u] = *reinterpret_cast<const int4*>(h);
+        }
+    }
+}
+
 // One workgroup (4 waves) per stream-step; wave w owns frames 2w and 2w+1 of every 8-frame group from the PCM samples to
 // the log-mel values (its own LDS regions, no workgroup barrier); the waves only meet once per call for the clamp maximum.
 __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
-    __shared__ float s_x[4][MEL_WX];
     __shared__ float s_hann[400];
-    __shared__ float s_re[4][576];
-    __shared__ float s_im[4][576];
+#ifndef OWK_MEL_NOALIAS
+    // a wave's PCM samples are dead once the windowed values are in registers: they share the LDS of the FFT transposes
+    // (re and im planes, contiguous per wave) -- 24 KB instead of 35 KB per workgroup, six resident workgroups per CU
+    __shared__ float s_z[4][2 * 576];
+    static_assert(MEL_WX <= 2 * 576, "sample window fits the transpose planes");
+#else
+    __shared__ float s_x[4][MEL_WX];
+    __shared__ float s_z[4][2 * 576];
+#endif
     __shared__ float s_pow[8][MEL_PBINS + 8];
     __shared__ float s_red[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -689,12 +726,18 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     for (int t = 0; t < 16; ++t) taps[t] = p.mel_taps[mbin * 16 + t];
     const int n_groups = (p.n_frames + 7) / 8;
     const int hist = p.streaming ? 480 : 0;
+#ifndef OWK_MEL_NOALIAS
+    float* sx = s_z[wave];
+#else
     float* sx = s_x[wave];
-    float* xr = s_re[wave];
-    float* xi = s_im[wave];
+#endif
+    float* xr = s_z[wave];
+    float* xi = s_z[wave] + 576;
     __syncthreads();                             // s_hann
 
     int it = 0;
+    int4 raw[2] = {};
+    if ((int)blockIdx.x < p.S) mel_fetch(p, blockIdx.x, 0, wave, lane, hist, raw);
     for (int s = blockIdx.x; s < p.S; s += gridDim.x, ++it) {
         const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
         const int16_t* tail = p.tail + (size_t)s * 480;
@@ -702,35 +745,26 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
         float vmax = -INFINITY;
         float last_db = 0.f;
         for (int g = 0; g < n_groups; ++g) {
-            // ---- this wave's samples: virtual index c0 + i of [tail(hist) ; pcm], c0 = first sample of frame 2*wave
-            const int c0 = g * 1280 + 320 * wave;
+            // ---- this wave's samples (fetched one iteration ahead, see mel_fetch): int16 -> float into the wave's LDS window
             wave_sync();                         // previous group's readers of sx / s_pow (same wave) are done
-            for (int i = lane * 8; i < MEL_WX; i += 64 * 8) {
-                const int c = c0 + i;
-                float v[8];
-                if (c + 8 <= hist) {
-                    const int4 raw = *reinterpret_cast<const int4*>(tail + c);
-                    const int16_t* h = reinterpret_cast<const int16_t*>(&raw);
+#ifdef OWK_MEL_NOPREFETCH
+            mel_fetch(p, s, g, wave, lane, hist, raw);
+#endif
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
-                } else if (c >= hist && c - hist + 8 <= p.n_samples &&
-                           ((reinterpret_cast<uintptr_t>(pcm + (c - hist)) & 15) == 0)) {
-                    const int4 raw = *reinterpret_cast<const int4*>(pcm + (c - hist));
-                    const int16_t* h = reinterpret_cast<const int16_t*>(&raw);
+            for (int u = 0; u < 2; ++u) {
+                const int i = lane * 8 + u * 512;
+                if (i < MEL_WX) {
+                    const int16_t* h = reinterpret_cast<const int16_t*>(&raw[u]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int cc = c + e;
-                        float x = 0.f;
-                        if (cc < hist) x = (float)tail[cc];
-                        else if (cc - hist < p.n_samples) x = (float)pcm[cc - hist];
-                        v[e] = x;
-                    }
+                    for (int e = 0; e < 8; ++e) sx[i + e] = (float)h[e];
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sx[i + e] = v[e];
+            }
+            {   // the next unit of work of this wave: next group of this stream, else group 0 of the workgroup's next stream
+                const bool same = g + 1 < n_groups;
+                const int sn = same ? s : s + (int)gridDim.x, gn = same ? g + 1 : 0;
+#ifndef OWK_MEL_NOPREFETCH
+                if (sn < p.S) mel_fetch(p, sn, gn, wave, lane, hist, raw);
+#endif
             }
             wave_sync();
             // ---- one complex FFT per wave: z = frame_a + i * frame_b (frames 2*wave and 2*wave + 1 of this group)

@@ -247,7 +247,7 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
     return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
 }
 
-template <int NBLK>
+template <int NBLK, int WG_WAVES = owr::WG_WAVES>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
     const float* base = uniform_ptr(gsrc + wave * 256);
     const unsigned voff = lane * 4;
