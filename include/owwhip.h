@@ -118,6 +118,15 @@ int  oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db
  * the clips of a batch (utils.py:243-290, embed_clips / feature extraction for training, utils.py:542-601) */
 int  oww_mel_clips(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db);
 int  oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float* out);
+/* AudioFeatures.embed_clips (utils.py:354-385; the feature extractor behind compute_features_from_generator,
+ * utils.py:542-601): int16 clips [B][n] -> embeddings [B][n_out][96], n_out = (F-76)/8 + 1 with F = (n-512)/160 + 1
+ * mel frames per clip.  Everything stays on the device: per-clip mel (one clamp floor per clip, x/10+2), then the
+ * incremental CNN walks each clip in steps of 8 mel rows (4 lead-in rows + 9 warm-up steps, then one embedding per
+ * step) -- 7.5x fewer flops than evaluating every 76-row window on its own, same results.  `pcm` / `out` are host
+ * pointers unless the matching *_on_device flag is set.  Requires B <= n_streams, F >= 76; CLOBBERS the streaming
+ * state of streams [0,B) like oww_embed. */
+int  oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32_t B, int32_t n,
+                     float* out, int32_t out_on_device);
 int  oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out);
 
 /* ---- introspection ------------------------------------------------------------------------------ */

@@ -41,6 +41,7 @@ SYMBOLS = {
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_mel_clips": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_embed": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "oww_embed_clips": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     "oww_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     "oww_get_features": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "oww_get_mel": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),

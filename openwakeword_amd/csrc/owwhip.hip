@@ -241,6 +241,7 @@ struct oww_ctx {
     float* d_tmpl[N_STATE] = {};
     float *d_xA = nullptr, *d_xB = nullptr, *d_xC = nullptr, *d_xD = nullptr;
     float *d_mel = nullptr, *d_feat = nullptr, *d_emb = nullptr, *d_raw = nullptr, *d_scores = nullptr, *d_ring = nullptr;
+    const float* mel_src = nullptr;   // when set: the CNN reads its mel rows from here instead of d_mel (oww_embed_clips)
     float* d_featinit = nullptr;
     float* d_dbg = nullptr;
     long long* d_prof = nullptr;     // [4 stages][16 waves][16 marks], allocated when OWW_PROF_BLOCK is set
@@ -315,7 +316,7 @@ int run_cnn_t(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     for (int l = 0; l < 20; ++l) { dbg_off[l] = off; off += kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2]; }
     {
         StageAParams p{};
-        p.mel = h->d_mel; p.mel_stride = mel_stride; p.mel_off = mel_off;
+        p.mel = h->mel_src ? h->mel_src : h->d_mel; p.mel_stride = mel_stride; p.mel_off = mel_off;
         p.hist_mel = h->d_state[0]; p.hist2 = h->d_state[1];
         p.w0 = h->d_conv[0]; p.w1 = h->d_conv[1]; p.w2 = h->d_conv[2];
         for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
@@ -368,7 +369,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     for (int l = 0; l < 20; ++l) { dbg_off[l] = off; off += kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2]; }
     {
         RAParams p{};
-        p.mel = h->d_mel; p.mel_stride = mel_stride; p.mel_off = mel_off;
+        p.mel = h->mel_src ? h->mel_src : h->d_mel; p.mel_stride = mel_stride; p.mel_off = mel_off;
         p.hist_mel = h->d_state[0]; p.hist2 = h->d_state[1];
         p.w0 = h->d_conv[0]; p.w1 = h->d_conv[1]; p.w2 = h->d_conv[2];
         for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
@@ -1061,6 +1062,53 @@ int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float*
         }
     }
     return OWW_OK;
+}
+
+int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32_t B, int32_t n, float* out, int32_t out_on_device) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_embed_clips: handle not committed");
+    if (!pcm || !out || B < 1 || B > h->Spad || n < 512) return fail(OWW_EINVAL, "oww_embed_clips: bad argument (B=%d n=%d, need B<=%d)", B, n, h->Spad);
+    const int F = (n - 512) / 160 + 1;
+    if (F < 76) return fail(OWW_EINVAL, "oww_embed_clips: %d samples give %d mel frames, one embedding window needs 76", n, F);
+    if ((int64_t)F * 32 > INT32_MAX / 2) return fail(OWW_EINVAL, "oww_embed_clips: clip too long");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int n_out = (F - 76) / 8 + 1;
+    const int n_steps = 9 + n_out;                      // step it consumes mel rows [8 it - 4, 8 it + 4) of every clip
+    const int Bp = std::min(h->Spad, (B + 7) / 8 * 8);   // run_cnn covers whole groups of 8 streams: their (zero) mel rows must exist
+    const size_t lead = 4 * 32;                         // four lead-in rows in front of clip 0 (other clips: the previous clip's tail;
+                                                        // their content never reaches a returned embedding)
+    int16_t* d_in = nullptr; float* d_mel = nullptr; float* d_max = nullptr; float* d_out = nullptr;
+    int rc = 0;
+    do {
+        if (!pcm_on_device) {
+            if (hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
+            if (hipMemcpyAsync(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: H2D failed"); break; }
+        }
+        if (hipMalloc(&d_mel, (lead + (size_t)Bp * F * 32) * sizeof(float)) != hipSuccess ||
+            hipMalloc(&d_max, (size_t)B * sizeof(float)) != hipSuccess ||
+            (!out_on_device && hipMalloc(&d_out, (size_t)B * n_out * 96 * sizeof(float)) != hipSuccess)) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
+        float* o = out_on_device ? out : d_out;
+        if (hipMemsetAsync(d_mel, 0, lead * sizeof(float), h->stream) != hipSuccess ||
+            (Bp > B && hipMemsetAsync(d_mel + lead + (size_t)B * F * 32, 0, (size_t)(Bp - B) * F * 32 * sizeof(float), h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_embed_clips: memset failed"); break; }
+        if ((rc = launch_mel(h, pcm_on_device ? pcm : d_in, B, n, F, 0, d_mel + lead, d_max))) break;
+        hipLaunchKernelGGL(clamp_transform_rows_kernel, dim3((F * 32 + 255) / 256, B), dim3(256), 0, h->stream, d_mel + lead, F * 32, d_max);
+        h->mel_src = d_mel + lead;
+        for (int it = 0; it < n_steps && !rc; ++it) {
+            rc = run_cnn(h, B, F * 32, (it * 8 - 4) * 32);
+            if (rc) break;
+            hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+            if (it >= 9 && hipMemcpy2DAsync(o + (size_t)(it - 9) * 96, (size_t)n_out * 96 * sizeof(float), h->d_emb, 96 * sizeof(float),
+                                            96 * sizeof(float), B, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+                rc = fail(OWW_EHIP, "oww_embed_clips: gather failed");
+        }
+        h->mel_src = nullptr;
+        if (rc) break;
+        if (!out_on_device && hipMemcpyAsync(out, d_out, (size_t)B * n_out * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: D2H failed"); break; }
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: device error: %s", hipGetErrorString(hipGetLastError())); break; }
+    } while (0);
+    h->mel_src = nullptr;
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_in); (void)hipFree(d_mel); (void)hipFree(d_max); (void)hipFree(d_out);
+    return rc;
 }
 
 int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out) {

@@ -883,6 +883,12 @@ __global__ void clamp_db_rows_kernel(float* x, int per_clip, const float* smax) 
     if (i < per_clip) { float* q = x + (size_t)blockIdx.y * per_clip + i; *q = fmaxf(*q, smax[blockIdx.y] - 80.0f); }
 }
 
+// per-clip clamp + the host transform of utils.py:180,206 (x/10 + 2): what embed_clips feeds the embedding model
+__global__ void clamp_transform_rows_kernel(float* x, int per_clip, const float* smax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < per_clip) { float* q = x + (size_t)blockIdx.y * per_clip + i; *q = fmaxf(*q, smax[blockIdx.y] - 80.0f) / 10.0f + 2.0f; }
+}
+
 __global__ void clamp_db_kernel(float* x, size_t n, float floor_db) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = fmaxf(x[i], floor_db);

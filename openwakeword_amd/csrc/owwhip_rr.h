@@ -386,14 +386,22 @@ __device__ __forceinline__ void load_tile(f32x4 (&t)[NCT], const float* __restri
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
+#ifdef OWR_EXP_NOLOAD            // (timing experiment: how much of a stage is exposed state / input load latency)
+        for (int e = 0; e < 4; ++e) t[ct][e] = (float)(lane + ct * 4 + e) * 1e-3f;
+#else
         for (int e = 0; e < 4; ++e) t[ct][e] = base[(ct * 4 + e) * 64 + lane];
+#endif
 }
 template <int NCT>
 __device__ __forceinline__ void store_tile(const f32x4 (&t)[NCT], float* __restrict__ base, int lane) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
+#ifdef OWR_EXP_NOSTORE
+        for (int e = 0; e < 4; ++e) if (t[ct][e] == 12345.678f) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
+#else
         for (int e = 0; e < 4; ++e) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
+#endif
 }
 
 // debug: dense [rows][F][C] dump of a tile row for the streams it holds (tests only)

@@ -206,6 +206,26 @@ class StreamEngine:
         _lib.check(self._lib.oww_mel_clips(self._h, _ptr(pcm), B, n, _ptr(out)))
         return out
 
+    def embed_clips(self, pcm: np.ndarray) -> np.ndarray:
+        """AudioFeatures.embed_clips on the device (utils.py:354-385): int16 [B, n] -> [B, n_windows, 96], mel, window
+        walk and CNN without leaving HBM.  Clobbers the streaming state of streams [0, B)."""
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype != np.int16 or pcm.ndim != 2:
+            raise ValueError("embed_clips expects a 2-D int16 array [B, samples]")
+        B, n = pcm.shape
+        if B > self.n_streams_padded:
+            raise ValueError(f"at most {self.n_streams_padded} clips per call (the handle's stream count)")
+        F = (n - 512) // 160 + 1
+        if n < 512 or F < 76:
+            raise ValueError("clips are shorter than one 76-frame embedding window (12512 samples, 782 ms)")
+        out = np.empty((B, (F - 76) // 8 + 1, EMB_DIM), dtype=np.float32)
+        _lib.check(self._lib.oww_embed_clips(self._h, _ptr(pcm), 0, B, n, _ptr(out), 0))
+        return out
+
+    def embed_clips_device(self, pcm_ptr: int, B: int, n: int, out_ptr: int) -> None:
+        """The same on device buffers (int16 [B, n] -> f32 [B, n_windows, 96]); pointers are raw device addresses."""
+        _lib.check(self._lib.oww_embed_clips(self._h, C.c_void_p(pcm_ptr), 1, int(B), int(n), C.c_void_p(out_ptr), 1))
+
     def embed(self, mel_rows: np.ndarray) -> np.ndarray:
         """embedding_model_predict over sliding windows (utils.py:229-236): [B, 76+8j, 32] -> [B, j+1, 96].
         Clobbers the streaming state of streams [0, B)."""

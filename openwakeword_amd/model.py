@@ -96,25 +96,29 @@ class AudioFeatures:
         out = self.engine.embed(spec[None, : 76 + 8 * (n_win - 1)].astype(np.float32))[0]
         return out
 
+    def get_embedding_shape(self, audio_length: float, sr: int = 16000):
+        """Shape of `_get_embeddings` for a clip of `audio_length` seconds (utils.py:238-241), from the frame arithmetic
+        instead of a trial run: F = (n-512)//160 + 1 mel frames, (F-76)//8 + 1 windows."""
+        n = int(audio_length * sr + 1e-6)           # (the float product of an exact sample count may land just below it)
+        frames = (n - 512) // 160 + 1 if n >= 512 else 0
+        return (max((frames - 76) // 8 + 1, 0), EMB_DIM)
+
     def embed_clips(self, x: np.ndarray, batch_size: int = 128, ncpu: int = 1) -> np.ndarray:
         """Embeddings of N equally long clips, `[N, samples] int16 -> [N, n_windows, 96]` (utils.py:354-385: mel per clip,
-        76-row windows every 8 rows, the embedding model over all windows).  `ncpu` is accepted for signature
-        compatibility; batching is by the handle's stream count.  Runs the streaming kernels from a zero state per clip
-        and therefore clobbers the streaming state of the streams it borrows: call reset() before streaming again."""
+        76-row windows every 8 rows, the embedding model over all windows) -- one `oww_embed_clips` call per batch, PCM in,
+        embeddings out, nothing else crosses the bus.  `ncpu` is accepted for signature compatibility; `batch_size` is
+        capped by the handle's stream count.  Borrows the streaming state of the first streams: both the engine and this
+        object are reset afterwards."""
         x = np.asarray(x)
         if x.ndim != 2 or x.dtype != np.int16:
             raise ValueError("embed_clips expects a 2-D int16 array [N, samples]")
-        cap = min(int(batch_size), self.engine.n_streams_padded)
-        out = []
-        for o in range(0, x.shape[0], cap):
-            spec = self.engine.mel_clips(x[o:o + cap]) / 10.0 + 2.0
-            n_win = (spec.shape[1] - 76) // 8 + 1
-            if n_win < 1:
-                raise ValueError("clips are shorter than one 76-frame embedding window (775 ms)")
-            out.append(self.engine.embed(np.ascontiguousarray(spec[:, : 76 + 8 * (n_win - 1)], dtype=np.float32)))
+        if x.shape[1] < 512 or (x.shape[1] - 512) // 160 + 1 < 76:          # utils.py:313-314
+            raise ValueError("Embedding model requires the input melspectrograms to have at least 76 frames")
+        cap = max(1, min(int(batch_size), self.engine.n_streams_padded))
+        out = [self.engine.embed_clips(x[o:o + cap]) for o in range(0, x.shape[0], cap)]
         self.engine.reset()                 # borrowed streams back to the start-up state ...
         self.reset()                        # ... and this object's stream re-seeded like a fresh AudioFeatures
-        return np.concatenate(out, axis=0)
+        return np.concatenate(out, axis=0) if out else np.zeros((0, 0, EMB_DIM), np.float32)
 
     def reset(self):
         """utils.py:172-178: the feature ring restarts from the embeddings of 4 s of random audio."""

@@ -1,0 +1,101 @@
+"""
+Bulk feature extraction on the device: the `openwakeword.utils` functions that sit on `AudioFeatures.embed_clips`
+(SURVEY.md section 8f rank 1).  `compute_features_from_generator` is the training pipeline's feature writer
+(/root/reference/openwakeword/utils.py:542-601): clips from a generator -> embeddings -> one `.npy` file of shape
+(N, n_windows, 96) float32 written through a memory map, trimmed to the rows actually produced
+(/root/reference/openwakeword/data.py:856-892).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterator, Optional
+
+import numpy as np
+from numpy.lib.format import open_memmap
+
+from .model import AudioFeatures  # noqa: F401  (re-export: the reference exposes it from this module)
+from .engine import EMB_DIM, StreamEngine
+
+
+def trim_mmap(mmap_path: str, n_rows: Optional[int] = None) -> int:
+    """Drop the unused rows at the end of a feature file (data.py:856-892: the rows after the last one that is not all
+    zero, or everything after `n_rows` when the writer knows its count).  The file is rewritten through a second map in
+    blocks, then renamed over the original.  Returns the number of rows kept."""
+    src = np.load(mmap_path, mmap_mode="r")
+    if n_rows is None:
+        n_rows = src.shape[0]
+        while n_rows > 0 and not src[n_rows - 1].any():
+            n_rows -= 1
+    n_rows = int(min(max(n_rows, 0), src.shape[0]))
+    if n_rows == src.shape[0]:
+        return n_rows
+    tmp = mmap_path[:-4] + ".trim.npy" if mmap_path.endswith(".npy") else mmap_path + ".trim"
+    dst = open_memmap(tmp, mode="w+", dtype=src.dtype, shape=(n_rows,) + src.shape[1:])
+    for lo in range(0, n_rows, 1024):
+        dst[lo:min(lo + 1024, n_rows)] = src[lo:min(lo + 1024, n_rows)]
+    dst.flush()
+    del dst, src
+    os.replace(tmp, mmap_path)
+    return n_rows
+
+
+def _embedding_weights(weights: Optional[str]) -> dict:
+    """The embedding model's parameters: the .onnx file where the reference keeps it, else (opt-in) synthetic ones."""
+    from . import weights as W
+    from .model import FEATURE_MODELS
+    path = FEATURE_MODELS["embedding"]["model_path"]
+    if os.path.exists(path):
+        from . import onnx_ingest
+        return onnx_ingest.load_embedding(path)
+    if weights == "synthetic":
+        return W.synthetic_embedding(1234)
+    raise ValueError(f"{path} does not exist; pass weights='synthetic' for random-init weights of the same architecture")
+
+
+def compute_features_from_generator(generator: Iterator[np.ndarray], n_total: int, clip_duration: int, output_file: str,
+                                    device: str = "gpu", ncpu: int = 1, engine: Optional[StreamEngine] = None,
+                                    weights: Optional[str] = None) -> int:
+    """utils.py:542-601 with the embedding work on the MI355X.
+
+    `generator` yields int16 arrays [batch, clip_duration]; the first batch fixes the batch size (ValueError when it
+    exceeds `n_total`, utils.py:581-583); rows beyond `n_total` are dropped; the file is trimmed to the rows written.
+    `device` / `ncpu` exist for signature compatibility (there is no CPU path here).  `engine`: an existing
+    `StreamEngine` to run on; otherwise one is created with as many streams as the batch (`weights='synthetic'` opts
+    into random-init embedding weights when the model file is absent, like `Model`).  Returns the rows written."""
+    n_cols = AudioFeatures.get_embedding_shape(None, clip_duration / 16000)
+    if n_cols[0] < 1:
+        raise ValueError("clips are shorter than one 76-frame embedding window (12512 samples, 782 ms)")
+    fp = open_memmap(output_file, mode="w+", dtype=np.float32, shape=(int(n_total), n_cols[0], n_cols[1]))
+    own = None
+    rows = 0
+    try:
+        first = True
+        for audio in generator:
+            audio = np.asarray(audio)
+            if first:
+                first = False
+                if audio.shape[0] > n_total:
+                    raise ValueError(f"The value of 'n_total' ({n_total}) is less than the batch size ({audio.shape[0]})."
+                                     " Please increase 'n_total' to be >= batch size.")
+                if engine is None:
+                    own = engine = StreamEngine(max(int(audio.shape[0]), 1), {}, _embedding_weights(weights))
+            if rows >= n_total:
+                break
+            if audio.dtype != np.int16 or audio.ndim != 2:
+                raise ValueError("the generator must yield 2-D int16 arrays [batch, samples]")
+            cap = engine.n_streams_padded
+            for lo in range(0, audio.shape[0], cap):
+                feats = engine.embed_clips(audio[lo:lo + cap])[: n_total - rows]
+                fp[rows:rows + feats.shape[0]] = feats
+                rows += feats.shape[0]
+                if rows >= n_total:
+                    break
+            fp.flush()
+    finally:
+        del fp
+        if own is not None:
+            own.close()
+        elif engine is not None:
+            engine.reset()
+    trim_mmap(output_file, rows)
+    return rows

@@ -1,0 +1,117 @@
+"""bulk clip embedding (`embed_clips`, `compute_features_from_generator`) on the device path.
+Reference behaviour: /root/reference/openwakeword/utils.py:238-385, 542-601; data.py:856-892."""
+import os
+
+import numpy as np
+import pytest
+
+from openwakeword_amd import weights as W
+
+gpu = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- CPU: host-side arithmetic and file handling
+def test_get_embedding_shape_arithmetic():
+    from openwakeword_amd.model import AudioFeatures
+    for n, want in ((16000, 3), (32000, 16), (12512, 1), (12511, 0), (400, 0), (24123, 10)):
+        frames = (n - 512) // 160 + 1 if n >= 512 else 0
+        assert AudioFeatures.get_embedding_shape(None, n / 16000) == (max((frames - 76) // 8 + 1, 0), 96)
+        assert AudioFeatures.get_embedding_shape(None, n / 16000)[0] == want
+
+
+def test_trim_mmap(tmp_path):
+    from numpy.lib.format import open_memmap
+    from openwakeword_amd.utils import trim_mmap
+    path = str(tmp_path / "feats.npy")
+    fp = open_memmap(path, mode="w+", dtype=np.float32, shape=(3000, 3, 96))
+    fp[:2500] = np.random.default_rng(0).standard_normal((2500, 3, 96)).astype(np.float32)
+    keep = np.array(fp[:2500])
+    fp.flush()
+    del fp
+    assert trim_mmap(path) == 2500                       # data.py:867-873: rows after the last non-zero one go
+    got = np.load(path)
+    assert got.shape == (2500, 3, 96) and np.array_equal(got, keep)
+    assert trim_mmap(path) == 2500                       # idempotent
+    assert trim_mmap(path, 10) == 10 and np.array_equal(np.load(path), keep[:10])
+
+
+# ---------------------------------------------------------------- GPU
+def _oracle_clips(emb, x):
+    from oracle import oww_oracle as O
+    oracle = O.OracleAudioFeatures(emb, init_noise=np.zeros(64000, np.int16))
+    return np.stack([np.asarray(oracle.clip_embeddings(c)).reshape(-1, 96) for c in x])
+
+
+@gpu
+@pytest.mark.parametrize("B,n", [(5, 24123), (13, 16000), (1, 12512), (3, 40000)])
+def test_device_embed_clips_matches_oracle_and_window_path(B, n):
+    """PCM -> embeddings without leaving the device == oracle == the stage-by-stage path (oww_mel_clips + oww_embed);
+    ragged batch sizes, lengths that are not a multiple of the hop, the one-window minimum."""
+    from openwakeword_amd.engine import StreamEngine
+    emb = W.synthetic_embedding(1234)
+    x = W.synthetic_pcm(B, n, seed=100 + B)
+    x[0, : n // 2] = 0                                    # a clip with digital silence: the per-clip clamp floor matters
+    eng = StreamEngine(16, {"alexa": W.synthetic_head("alexa", 1234)}, emb)
+    try:
+        got = eng.embed_clips(x)
+        want = _oracle_clips(emb, x)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+        spec = eng.mel_clips(x) / 10.0 + 2.0
+        n_win = (spec.shape[1] - 76) // 8 + 1
+        ref = eng.embed(np.ascontiguousarray(spec[:, : 76 + 8 * (n_win - 1)], dtype=np.float32))
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        # deterministic and independent of what the borrowed streams held before
+        np.testing.assert_array_equal(got, eng.embed_clips(x))
+    finally:
+        eng.close()
+
+
+@gpu
+def test_device_embed_clips_errors():
+    from openwakeword_amd.engine import StreamEngine
+    eng = StreamEngine(4, {"alexa": W.synthetic_head("alexa", 1234)}, W.synthetic_embedding(1234))
+    try:
+        with pytest.raises(ValueError):
+            eng.embed_clips(np.zeros((2, 12511), np.int16))            # 75 frames: no window (utils.py:313-314)
+        with pytest.raises(ValueError):
+            eng.embed_clips(np.zeros((2, 16000), np.float32))
+        with pytest.raises(ValueError):
+            eng.embed_clips(np.zeros((eng.n_streams_padded + 1, 16000), np.int16))
+    finally:
+        eng.close()
+
+
+@gpu
+def test_compute_features_from_generator(tmp_path):
+    """utils.py:542-601: generator of [batch, samples] int16 -> (N, windows, 96) float32 .npy, cut at n_total, trimmed
+    when the generator runs dry; a batch larger than n_total is an error."""
+    from openwakeword_amd.engine import StreamEngine
+    from openwakeword_amd.utils import compute_features_from_generator
+    emb = W.synthetic_embedding(1234)
+    clips = W.synthetic_pcm(22, 32000, seed=5)
+
+    def gen(bs):
+        for lo in range(0, clips.shape[0], bs):
+            yield clips[lo:lo + bs]
+
+    eng = StreamEngine(8, {}, emb)                          # a handle without heads is enough for feature extraction
+    try:
+        want = np.concatenate([eng.embed_clips(clips[lo:lo + 8]) for lo in range(0, 22, 8)])
+        path = str(tmp_path / "f.npy")
+        assert compute_features_from_generator(gen(8), n_total=20, clip_duration=32000, output_file=path, engine=eng) == 20
+        got = np.load(path)
+        assert got.shape == (20, 16, 96) and got.dtype == np.float32
+        np.testing.assert_array_equal(got, want[:20])
+        # n_total larger than what the generator yields: file trimmed to the 22 rows written
+        assert compute_features_from_generator(gen(6), n_total=40, clip_duration=32000, output_file=path, engine=eng) == 22
+        np.testing.assert_array_equal(np.load(path), want)
+        with pytest.raises(ValueError):
+            compute_features_from_generator(gen(8), n_total=4, clip_duration=32000, output_file=path, engine=eng)
+    finally:
+        eng.close()
+    # engine created on demand (synthetic weights: the model file is not in the checkout)
+    assert compute_features_from_generator(gen(11), n_total=22, clip_duration=32000, output_file=path, weights="synthetic") == 22
+    np.testing.assert_allclose(np.load(path), want, rtol=0, atol=1e-6)
+    assert _oracle_clips(emb, clips[:2]).shape == (2, 16, 96)
+    np.testing.assert_allclose(np.load(path)[:2], _oracle_clips(emb, clips[:2]), rtol=0, atol=2e-4)
