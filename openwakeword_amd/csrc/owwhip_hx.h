@@ -33,6 +33,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef OWH_PKF32
 #define OWH_PKF32 0
 #endif
+#ifndef OWH_MASKSEL
+#define OWH_MASKSEL 1      // stream-boundary masks of the 1x3 tap combine as selects; 0: as 0/1 multipliers (v_mul / v_fma: one VALU
+                           // instruction fewer per value, yet stage D measured 18 % and stage E 3 % SLOWER -- kept as an A/B switch)
+#endif
 template <bool BN>
 __device__ __forceinline__ f32x4 bn_act(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift,
                                         int oct, int j) {
@@ -158,8 +162,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
-    // 0/1 multipliers instead of selects: the DPP shift then folds into the multiply / fused multiply-add (v_mul_f32_dpp,
-    // v_fmac_f32_dpp): one VALU instruction per shifted value (VALU time is not hidden behind 16-cycle MFMAs)
+    // stream-boundary masks as 0/1 values (used as select conditions, or as multipliers with OWH_MASKSEL=0)
     const float mfirst = (pos & (F - 1)) == 0 ? 0.f : 1.f, mlast = (pos & (F - 1)) == F - 1 ? 0.f : 1.f;
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
@@ -178,7 +181,11 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 else {
 #pragma unroll
+#if OWH_MASKSEL
+                    for (int e = 0; e < 4; ++e) { const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && mfirst == 0.f) ? 0.f : l; }
+#else
                     for (int e = 0; e < 4; ++e) acc[t][e] = F < 16 ? dpp_shr1_zero(accs[0][t][e]) * mfirst : dpp_shr1_zero(accs[0][t][e]);
+#endif
                 }
             }
 #pragma unroll
@@ -197,8 +204,14 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 if (ti < 2) accs[ti][t] = acc[t];
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e) {
+#if OWH_MASKSEL
+                        const float hh = dpp_shl1_zero(accs[1][t][e]);
+                        res[t][e] = acc[t][e] + ((F < 16 && mlast == 0.f) ? 0.f : hh);
+#else
                         res[t][e] = F < 16 ? fmaf(dpp_shl1_zero(accs[1][t][e]), mlast, acc[t][e]) : acc[t][e] + dpp_shl1_zero(accs[1][t][e]);
+#endif
+                    }
                 }
             }
         }
