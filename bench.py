@@ -78,7 +78,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--pcm-pool", type=int, default=4, help="distinct PCM buffers cycled through")
     ap.add_argument("--host-pcm", action="store_true", help="PCIe-inclusive variant (NOT the headline number): PCM handed over as pinned "
-                    "host buffers and scores returned to the host every step through the blocking oww_step(host, host) path")
+                    "host buffers and scores returned to the host every step through the pipelined oww_submit / oww_collect path "
+                    "(upload of step t+1 overlaps the kernels of step t)")
+    ap.add_argument("--host-pcm-blocking", action="store_true", help="the same through the blocking oww_step(host, host) call (no overlap)")
     args = ap.parse_args()
 
     rank0 = int(os.environ.get("RANK", "0")) == 0
@@ -125,19 +127,31 @@ def main():
     from openwakeword_amd.shard import ScoreGather
     gatherer = ScoreGather(S * world, NL, dev) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
 
-    if args.host_pcm:
+    host = args.host_pcm or args.host_pcm_blocking
+    if host:
         host_pool = [torch.empty(S, 1280, dtype=torch.int16, pin_memory=True).copy_(t).numpy() for t in pool]
         host_scores = torch.empty(S, NL, dtype=torch.float32, pin_memory=True).numpy()
+    inflight = [0]
 
     def one_step(i):
-        if args.host_pcm:
+        if args.host_pcm_blocking:
             eng.step(host_pool[i % len(host_pool)], out=host_scores)     # H2D + kernels + D2H, blocking
+            return
+        if args.host_pcm:
+            eng.submit(host_pool[i % len(host_pool)])                    # step i's upload overlaps step i-1's kernels
+            inflight[0] += 1
+            if inflight[0] == 2:
+                eng.collect(host_scores)
+                inflight[0] -= 1
             return
         eng.step_device(pool[i % len(pool)].data_ptr(), 1, scores.data_ptr())
         if world > 1:
             gatherer.gather(scores)                    # RCCL over xGMI: the path's only exchange
 
     def fence():
+        while inflight[0]:
+            eng.collect(host_scores)
+            inflight[0] -= 1
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -159,7 +173,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    if args.host_pcm:
+    if host:
         scores = torch.from_numpy(host_scores).to(dev)
     ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item())
 
@@ -176,7 +190,8 @@ def main():
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
                        "collective": "RCCL gather of scores per step" if world > 1 else "none",
-                       "pcm": "pinned host buffers, PCIe-inclusive (not the headline configuration)" if args.host_pcm else "resident in HBM",
+                       "pcm": ("pinned host buffers, PCIe-inclusive, " + ("blocking oww_step" if args.host_pcm_blocking else "pipelined oww_submit/oww_collect") +
+                               " (not the headline configuration)") if host else "resident in HBM",
                        "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_rr_fp32" if args.fp32 else "mfma_rr_f16x3")), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
             "realtime_streams": round(value / 12.5, 1),
             "frames_per_sec_per_gpu": round(value / world, 1),

@@ -99,6 +99,19 @@ int  oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshol
 int  oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks,
               float* scores, int scores_on_device);
 int  oww_sync(oww_ctx* h);
+
+/* ---- host-fed pipeline: the same step with PCM arriving in host memory every 80 ms (the serving edge of
+ *      examples/web/streaming_server.py:32-70 and detect_from_microphone.py: audio is produced on the host) ----------
+ * oww_submit enqueues  H2D(pcm) -> step -> D2H(scores)  and returns at once: the upload runs on its own stream, so the
+ * PCM of step t+1 crosses PCIe while the kernels of step t execute; oww_collect blocks until the OLDEST submitted step
+ * has delivered and copies its fp32 [S][n_labels] scores to `scores` (host).  At most two steps may be in flight
+ * (submit, submit, collect, submit, collect, ...); a third submit returns OWW_ESTATE.  `pcm` must stay valid and
+ * unmodified until the matching oww_collect returns; use page-locked memory (oww_host_alloc, hipHostMalloc,
+ * torch pin_memory) -- pageable memory works but makes the upload synchronous.  Results are identical to oww_step. */
+int  oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks);
+int  oww_collect(oww_ctx* h, float* scores);
+int  oww_host_alloc(void** out, size_t nbytes);   /* page-locked host memory for PCM / score buffers */
+int  oww_host_free(void* p);
 const float* oww_scores_dev(const oww_ctx* h);     /* device [S][n_labels], valid until the next step */
 /* raw head outputs of the last step, BEFORE post-processing (what model_prediction_function returned,
  * model.py:313-317; max over chunks for n_chunks > 1): host fp32 [S][n_labels].  Blocking.  Lets a host

@@ -36,6 +36,10 @@ SYMBOLS = {
     "oww_set_postproc": (C.c_int, [_P, _P, _P, C.c_int32]),
     "oww_step": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P, C.c_int]),
     "oww_sync": (C.c_int, [_P]),
+    "oww_submit": (C.c_int, [_P, _P, C.c_int32]),
+    "oww_collect": (C.c_int, [_P, _P]),
+    "oww_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "oww_host_free": (C.c_int, [_P]),
     "oww_scores_dev": (_P, [_P]),
     "oww_get_raw": (C.c_int, [_P, _P]),
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),

@@ -241,6 +241,14 @@ struct oww_ctx {
     float* d_tmpl[N_STATE] = {};
     float *d_xA = nullptr, *d_xB = nullptr, *d_xC = nullptr, *d_xD = nullptr;
     float *d_mel = nullptr, *d_feat = nullptr, *d_emb = nullptr, *d_raw = nullptr, *d_scores = nullptr, *d_ring = nullptr;
+    // host-fed pipeline (oww_submit / oww_collect): two steps in flight, uploads and score downloads on their own streams
+    struct IngestSlot {
+        int16_t* d_pcm = nullptr; float* d_scores = nullptr; float* h_scores = nullptr;
+        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        bool busy = false;
+    } slot[2];
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    uint64_t n_submit = 0, n_collect = 0;
     const float* mel_src = nullptr;   // when set: the CNN reads its mel rows from here instead of d_mel (oww_embed_clips)
     float* d_featinit = nullptr;
     float* d_dbg = nullptr;
@@ -548,6 +556,14 @@ void free_all(oww_ctx* h) {
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
     fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail);
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold);
+    for (auto& sl : h->slot) {
+        fr(sl.d_pcm); fr(sl.d_scores);
+        if (sl.h_scores) { (void)hipHostFree(sl.h_scores); sl.h_scores = nullptr; }
+        for (hipEvent_t* e : {&sl.up, &sl.done, &sl.down}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        sl.busy = false;
+    }
+    if (h->up_stream) { (void)hipStreamDestroy(h->up_stream); h->up_stream = nullptr; }
+    if (h->down_stream) { (void)hipStreamDestroy(h->down_stream); h->down_stream = nullptr; }
     for (auto& e : h->ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->ev.clear();
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -617,6 +633,8 @@ int oww_destroy(oww_ctx* h) {
     if (!h) return OWW_OK;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->up_stream) (void)hipStreamSynchronize(h->up_stream);
+    if (h->down_stream) (void)hipStreamSynchronize(h->down_stream);
     free_all(h);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -979,6 +997,69 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
         if (nb) HIPCHK(hipMemcpyAsync(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
         if (!scores_on_device) HIPCHK(hipStreamSynchronize(h->stream));
     }
+    return OWW_OK;
+}
+
+static int ensure_ingest(oww_ctx* h) {
+    if (h->up_stream) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->down_stream, hipStreamNonBlocking));
+    const size_t nb = (size_t)h->S * std::max(h->NL, 1) * sizeof(float);
+    for (auto& sl : h->slot) {
+        HIPCHK(hipMalloc(&sl.d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax * sizeof(int16_t)));
+        HIPCHK(hipMalloc(&sl.d_scores, nb));
+        HIPCHK(hipHostMalloc((void**)&sl.h_scores, nb, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_submit: handle not committed");
+    if (!pcm) return fail(OWW_EINVAL, "oww_submit: pcm is null");
+    if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_submit: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (int rc = ensure_ingest(h)) return rc;
+    auto& sl = h->slot[h->n_submit & 1];
+    if (sl.busy) return fail(OWW_ESTATE, "oww_submit: two steps already in flight, call oww_collect first");
+    const size_t n_pcm = (size_t)h->S * OWW_CHUNK * n_chunks;
+    HIPCHK(hipMemcpyAsync(sl.d_pcm, pcm, n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, h->up_stream));
+    HIPCHK(hipEventRecord(sl.up, h->up_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, sl.up, 0));
+    if (int rc = launch_step(h, sl.d_pcm, n_chunks)) return rc;
+    const size_t nb = (size_t)h->S * h->NL * sizeof(float);
+    if (nb) HIPCHK(hipMemcpyAsync(sl.d_scores, h->d_scores, nb, hipMemcpyDeviceToDevice, h->stream));   // d_scores is rewritten by the next step
+    HIPCHK(hipEventRecord(sl.done, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->down_stream, sl.done, 0));
+    if (nb) HIPCHK(hipMemcpyAsync(sl.h_scores, sl.d_scores, nb, hipMemcpyDeviceToHost, h->down_stream));
+    HIPCHK(hipEventRecord(sl.down, h->down_stream));
+    sl.busy = true;
+    ++h->n_submit;
+    return OWW_OK;
+}
+
+int oww_collect(oww_ctx* h, float* scores) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_collect: handle not committed");
+    auto& sl = h->slot[h->n_collect & 1];
+    if (h->n_collect == h->n_submit || !sl.busy) return fail(OWW_ESTATE, "oww_collect: no step in flight");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipEventSynchronize(sl.down));
+    if (scores) memcpy(scores, sl.h_scores, (size_t)h->S * h->NL * sizeof(float));
+    sl.busy = false;
+    ++h->n_collect;
+    return OWW_OK;
+}
+
+int oww_host_alloc(void** out, size_t nbytes) {
+    if (!out || !nbytes) return fail(OWW_EINVAL, "oww_host_alloc: bad argument");
+    if (hipHostMalloc(out, nbytes, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(OWW_ENOMEM, "oww_host_alloc: %zu bytes of page-locked memory not available", nbytes); }
+    return OWW_OK;
+}
+
+int oww_host_free(void* p) {
+    if (p) HIPCHK(hipHostFree(p));
     return OWW_OK;
 }
 

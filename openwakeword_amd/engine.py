@@ -83,6 +83,7 @@ class StreamEngine:
                  feature_ring: int = 0, hip_stream: int = 0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
+        self._inflight: List[np.ndarray] = []
         self.n_streams = int(n_streams)
         self.max_chunks = int(max_chunks)
         self.head_names = list(heads.keys())
@@ -175,6 +176,39 @@ class StreamEngine:
         """Asynchronous step on device pointers (e.g. torch tensors' data_ptr())."""
         _lib.check(self._lib.oww_step(self._h, C.c_void_p(pcm_dev_ptr), 1, int(n_chunks),
                                       C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None, 1))
+
+    # ---- host-fed pipeline: upload of step t+1 overlaps the kernels of step t (oww_submit / oww_collect) ----
+    def submit(self, pcm: np.ndarray) -> None:
+        """Enqueue one step on host PCM int16 [S, 1280*k] and return at once.  At most two steps in flight; the array
+        must stay alive and unmodified until the matching collect() (use `pinned_empty` buffers for an asynchronous
+        upload).  Same results as step()."""
+        if not isinstance(pcm, np.ndarray) or pcm.dtype != np.int16 or not pcm.flags["C_CONTIGUOUS"]:
+            raise ValueError("submit expects a C-contiguous int16 ndarray")
+        if pcm.ndim != 2 or pcm.shape[0] != self.n_streams or pcm.shape[1] % CHUNK or pcm.shape[1] == 0:
+            raise ValueError(f"pcm must be [n_streams={self.n_streams}, 1280*k], got {pcm.shape}")
+        _lib.check(self._lib.oww_submit(self._h, _ptr(pcm), pcm.shape[1] // CHUNK))
+        self._inflight.append(pcm)                      # keeps the buffer alive until collected
+
+    def collect(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Scores fp32 [S, n_labels] of the oldest submitted step (blocks until they have arrived)."""
+        if out is None:
+            out = np.empty((self.n_streams, self.n_labels), dtype=np.float32)
+        _lib.check(self._lib.oww_collect(self._h, _ptr(out)))
+        if self._inflight:
+            self._inflight.pop(0)
+        return out
+
+    def pinned_empty(self, shape, dtype=np.int16) -> np.ndarray:
+        """A page-locked host array (hipHostMalloc) for PCM / score buffers; freed when the array is collected."""
+        import weakref
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        _lib.check(self._lib.oww_host_alloc(C.byref(p), max(nbytes, 1)))
+        buf = (C.c_byte * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        weakref.finalize(buf, self._lib.oww_host_free, C.c_void_p(p.value))
+        return arr
 
     def sync(self):
         _lib.check(self._lib.oww_sync(self._h))

@@ -451,5 +451,16 @@ class BatchedModel:
             raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
         return self.engine.step(pcm)[:, self._keep]
 
+    def submit_batch(self, pcm: np.ndarray) -> None:
+        """Pipelined `predict_batch` for host-fed serving: enqueue one step (upload on its own stream) and return; the
+        scores come back from `collect_batch()` in submission order, at most two steps in flight.  Page-locked buffers
+        (`engine.pinned_empty`) make the upload overlap the previous step's kernels."""
+        if not isinstance(pcm, np.ndarray):
+            raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
+        self.engine.submit(pcm)
+
+    def collect_batch(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        return self.engine.collect(out)[:, self._keep]
+
     def close(self):
         self.engine.close()

@@ -292,3 +292,47 @@ def test_large_batch_properties(emb, heads):
     finally:
         big.close()
         small.close()
+
+
+def test_host_fed_pipeline_matches_blocking_steps(emb, heads):
+    """oww_submit / oww_collect (upload of step t+1 overlapping the kernels of step t, two steps in flight) deliver
+    exactly the scores of the blocking oww_step sequence, post-processing included; order errors are reported."""
+    from openwakeword_amd._lib import OwwError
+    S, T = 96, 12
+    pcm = W.synthetic_pcm(S, 1280 * T, seed=321)
+    ref = StreamEngine(S, heads, emb)
+    eng = StreamEngine(S, heads, emb)
+    try:
+        for e in (ref, eng):
+            e.set_postproc([0] * e.n_labels, [0.3] * e.n_labels, 4)
+        want = [ref.step(np.ascontiguousarray(pcm[:, 1280 * t: 1280 * (t + 1)])) for t in range(T)]
+        with pytest.raises(OwwError):
+            eng.collect()                                               # nothing in flight
+        bufs = [eng.pinned_empty((S, 1280), np.int16) for _ in range(2)]
+        got = []
+        for t in range(T):
+            bufs[t % 2][:] = pcm[:, 1280 * t: 1280 * (t + 1)]
+            eng.submit(bufs[t % 2])
+            if t >= 1:
+                got.append(eng.collect().copy())
+            if t == 0:
+                continue
+        # two in flight is the limit
+        bufs[T % 2][:] = 0
+        eng.submit(bufs[T % 2])
+        with pytest.raises(OwwError):
+            eng.submit(bufs[(T + 1) % 2])
+        got.append(eng.collect().copy())
+        eng.collect()
+        for t in range(T):
+            np.testing.assert_array_equal(got[t], want[t])
+        # pageable memory works too, and the blocking call still interleaves with the pipeline
+        x = np.ascontiguousarray(pcm[:, :1280])
+        eng.submit(x)
+        a = eng.collect()
+        b = ref.step(np.zeros((S, 1280), np.int16))
+        b = ref.step(x)
+        np.testing.assert_array_equal(a, b)
+    finally:
+        ref.close()
+        eng.close()
