@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float m = Y[ro * C::PT][ct][e];
-                    if (C::PT == 2) m = fmaxf(m, Y[ro * C::PT + 1][ct][e]);
-                    pm[ct][e] = fmaxf(m, dpp_shl1_zero(m));
+                    if (C::PT == 2) m = fmax_nc(m, Y[ro * C::PT + 1][ct][e]);
+                    pm[ct][e] = fmax_nc(m, dpp_shl1_zero(m));
                 }
             if ((f & 1) == 0) {                                        // one predicated region per pooled row
                 float* xo = p.xout + ((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4)) * 64 + j * 16 + posn;
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float m = fmaxf(Y[0][ct][e], Y[1][ct][e]);
-                m = fmaxf(m, dpp_shl1_zero(m));
+                float m = fmax_nc(Y[0][ct][e], Y[1][ct][e]);
+                m = fmax_nc(m, dpp_shl1_zero(m));
                 Pl[ct][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, m)));
             }
         float* h19 = p.hist19 + (size_t)g * (2 * NCT * 4 * 64);
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
                     acc = OWH_MFMA(ah, b.l, acc);
                     acc = OWH_MFMA(al, b.h, acc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+                    for (int e = 0; e < 4; ++e) acc[e] = fmax_nc(acc[e], 0.f);
                     Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
                     pin(Y0[oct]);
                 }
@@ -637,8 +637,8 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float m = fmaxf(Y2[h][ct][e], Y2[2 + h][ct][e]);
-                        pm[h][ct][e] = fmaxf(m, dpp_shl1_zero(m));
+                        const float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
+                        pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m));
                     }
             if ((pos & 1) == 0) {                                      // one predicated region for all sixteen stores
 #pragma unroll
@@ -721,7 +721,7 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[ct][e] = fmaxf(h[ct][e], 0.f);
+            for (int e = 0; e < 4; ++e) h[ct][e] = owr::fmax_nc(h[ct][e], 0.f);
     }
 }
 

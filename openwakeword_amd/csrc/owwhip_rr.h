@@ -36,6 +36,18 @@ namespace owr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float leaky_clamp(float x) { return fmaxf(fmaxf(0.2f * x, x), -0.4f); }
+// max(a, b) as v_med3_f32(a, b, +inf): fmaxf() follows IEEE maxNum, for which LLVM first quiets every input it cannot prove
+// canonical (values coming out of an MFMA, a DPP move or an opaque asm) with an extra "v_max_f32 x, x, x" -- 12 % of stage A's
+// VALU instructions were such no-ops.  NaNs are not expected here (they would already have poisoned the convolution).
+// (+inf comes from an opaque scalar move: with a literal the optimiser rewrites the median back into maxNum.)
+__device__ __forceinline__ float fmax_nc(float a, float b) {
+#ifdef OWR_FMAX_IEEE
+    return fmaxf(a, b);
+#endif
+    float inf;
+    asm("s_mov_b32 %0, 0x7f800000" : "=s"(inf));
+    return __builtin_amdgcn_fmed3f(a, b, inf);
+}
 
 // ---- DPP helpers: shifts inside the 16-lane rows (= the 16 positions of a tile; j groups shift alike) ----------
 __device__ __forceinline__ float dpp_shr1_zero(float x) {      // lane p <- x[p-1], lane 0 <- 0
@@ -501,8 +513,8 @@ __device__ __forceinline__ void pool_store(const f32x4 (&y)[C::RP][C::NCT], floa
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float m = y[ro * C::PT][ct][e];
-                if (C::PT == 2) m = fmaxf(m, y[ro * C::PT + 1][ct][e]);
-                m = fmaxf(m, dpp_shl1_zero(m));            // pair (f, f+1); valid on even f
+                if (C::PT == 2) m = fmax_nc(m, y[ro * C::PT + 1][ct][e]);
+                m = fmax_nc(m, dpp_shl1_zero(m));            // pair (f, f+1); valid on even f
                 if (writer) xout[((size_t)(gn * RO + ro0 + ro) * (NCT * 4) + ct * 4 + e) * 64 + j * 16 + posn] = m;
             }
 }
@@ -599,8 +611,8 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float m = fmaxf(Yd[0][ct][e], Yd[1][ct][e]);
-                m = fmaxf(m, dpp_shl1_zero(m));
+                float m = fmax_nc(Yd[0][ct][e], Yd[1][ct][e]);
+                m = fmax_nc(m, dpp_shl1_zero(m));
                 Pl[0][ct][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, m)));
             }
         float* h19 = p.hist19 + (size_t)g * (2 * NCT * 4 * 64);
@@ -730,7 +742,7 @@ __global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
 #pragma unroll
                     for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W0[oct][ks], b[ks], acc, 0, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+                    for (int e = 0; e < 4; ++e) acc[e] = fmax_nc(acc[e], 0.f);
                     Y0[t][oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
                     pin(Y0[t][oct]);
                 }
@@ -834,8 +846,8 @@ __global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int e = 0; e < (ct ? 2 : 4); ++e) {
-                        float m = fmaxf(Y2[h][ct][e], Y2[2 + h][ct][e]);
-                        m = fmaxf(m, dpp_shl1_zero(m));
+                        float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
+                        m = fmax_nc(m, dpp_shl1_zero(m));
                         if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
                     }
         }
