@@ -88,6 +88,8 @@ class StreamEngine:
         self.max_chunks = int(max_chunks)
         self.head_names = list(heads.keys())
         self.heads = heads
+        self._embedding = embedding
+        self._cfg = dict(device=int(device), use_mfma=int(use_mfma))
         cfg = _lib.Config(int(device), self.n_streams, self.max_chunks, int(feature_ring), int(use_mfma),
                           int(bool(debug_layers)), C.c_void_p(hip_stream) if hip_stream else None)
         _lib.check(self._lib.oww_create(C.byref(cfg), C.byref(self._h)))
@@ -209,6 +211,49 @@ class StreamEngine:
         arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
         weakref.finalize(buf, self._lib.oww_host_free, C.c_void_p(p.value))
         return arr
+
+    def self_test(self, n_frames: int = 24, pcm: Optional[np.ndarray] = None, tol: float = 1e-3) -> Dict[str, float]:
+        """Deploy-time check of the default f16-split kernels against the exact-fp32 family on THIS engine's weights.
+
+        The f16-split family carries activations as f16 hi/lo pairs; a network whose activations leave the f16 range
+        (|x| > 65504) would not fail loudly -- max/ReLU stages swallow the resulting NaNs -- it would silently score
+        differently.  This runs `n_frames` frames of 32 probe streams (silence, quiet and full-scale noise, full-scale
+        square waves, or the rows of `pcm` [32, 1280*n]) through a scratch engine of this family and one with
+        use_mfma=1 and compares raw scores and embeddings.  Returns the maxima; raises OwwError beyond `tol`
+        (the north-star score tolerance).  Does not touch this engine's streams."""
+        S = 32
+        if pcm is None:
+            r = np.random.default_rng(2024)
+            pcm = np.zeros((S, CHUNK * n_frames), np.int16)
+            for i in range(1, S):
+                amp = (30, 300, 3000, 12000, 32767)[i % 5]
+                if i % 3 == 0:
+                    t = np.arange(CHUNK * n_frames)
+                    pcm[i] = np.where((t // (8 << (i % 4))) % 2, amp, -amp)
+                else:
+                    pcm[i] = np.clip(np.round(r.normal(0.0, amp, CHUNK * n_frames)), -32768, 32767)
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        if pcm.shape[0] != S or pcm.shape[1] % CHUNK:
+            raise ValueError("self_test expects pcm [32, 1280*n]")
+        outs = []
+        for fam in (self._cfg["use_mfma"], 1):
+            eng = StreamEngine(S, self.heads, self._embedding, device=self._cfg["device"], use_mfma=fam,
+                               feature_ring=self.feature_ring)
+            try:
+                raw = [eng.step_raw(pcm[:, CHUNK * t: CHUNK * (t + 1)]) for t in range(pcm.shape[1] // CHUNK)]
+                feats = np.stack([eng.get_features(s, 16) for s in range(S)])
+                outs.append((np.stack(raw), feats))
+            finally:
+                eng.close()
+        res = {"max_abs_score_diff": float(np.max(np.abs(outs[0][0] - outs[1][0]))) if outs[0][0].size else 0.0,
+               "max_abs_embedding_diff": float(np.max(np.abs(outs[0][1] - outs[1][1]))),
+               "max_abs_embedding": float(np.max(np.abs(outs[1][1])))}
+        bad = not np.isfinite(outs[0][1]).all() or res["max_abs_score_diff"] > tol or \
+            res["max_abs_embedding_diff"] > tol * max(1.0, res["max_abs_embedding"])
+        if bad:
+            raise _lib.OwwError(f"kernel family {self._cfg['use_mfma']} disagrees with the exact-fp32 family on these weights "
+                                f"({res}): create the engine with use_mfma=1")
+        return res
 
     def sync(self):
         _lib.check(self._lib.oww_sync(self._h))

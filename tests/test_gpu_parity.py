@@ -336,3 +336,31 @@ def test_host_fed_pipeline_matches_blocking_steps(emb, heads):
     finally:
         ref.close()
         eng.close()
+
+
+def test_self_test_catches_f16_range_overflow(emb, heads):
+    """StreamEngine.self_test: the deploy-time comparison of the f16-split family with the exact-fp32 family passes on
+    the normal weights and raises on a network whose activations leave the f16 range (one BatchNorm shift of 3e5: the
+    ReLU / max stages swallow the NaNs, so nothing else would flag it)."""
+    import copy
+    from openwakeword_amd._lib import OwwError
+    eng = StreamEngine(4, heads, emb)
+    try:
+        res = eng.self_test(n_frames=12)
+        assert res["max_abs_score_diff"] < 1e-4 and res["max_abs_embedding_diff"] < 2e-4 * max(1.0, res["max_abs_embedding"])
+    finally:
+        eng.close()
+    big = copy.deepcopy(emb)
+    gamma, beta, mean, var = big["bn"][10]                              # weights.synthetic_embedding: Keras order
+    big["bn"][10] = (gamma, np.full_like(beta, 3.0e5), mean, var)
+    eng = StreamEngine(4, heads, big)
+    try:
+        with pytest.raises(OwwError, match="use_mfma=1"):
+            eng.self_test(n_frames=12)
+    finally:
+        eng.close()
+    eng = StreamEngine(4, heads, big, use_mfma=1)                       # the exact family agrees with itself
+    try:
+        assert eng.self_test(n_frames=12)["max_abs_score_diff"] == 0.0
+    finally:
+        eng.close()
