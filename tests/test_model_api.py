@@ -169,3 +169,85 @@ def test_embed_clips_matches_oracle(golden):
         assert set(out) == {"alexa"}
     finally:
         m.close()
+
+
+# ----------------------------------------------------------------------------- the rest of the reference's test list
+# (/root/reference/tests/test_models.py: custom verifier 114-128, names with spaces 130-137, label mapping 139-149,
+#  parent lookup 318-321, positive frames 323-330, VAD 259-285)
+class _Verifier:
+    """Stands in for the pickled scikit-learn pipeline of custom_verifier_model.py:95-113."""
+
+    def predict_proba(self, feats):
+        assert feats.shape == (1, 16, 96)
+        v = float(np.tanh(np.abs(feats).mean()))
+        return np.array([[1.0 - v, v]])
+
+
+@gpu
+def test_custom_verifier_rescoring(tmp_path, golden):
+    """model.py:320-328: a verifier re-scores frames whose base score reaches custom_verifier_threshold, from the same
+    last-16-rows features the head saw; keys that match no model are an error (model.py:189-195)."""
+    import pickle
+    from openwakeword_amd import Model
+    path = str(tmp_path / "verifier.pkl")
+    pickle.dump(_Verifier(), open(path, "wb"))
+    w = _weights(["alexa"])
+    with pytest.raises(ValueError, match="not matched"):
+        Model(wakeword_models=["alexa"], weights=w, custom_verifier_models={"nope": path})
+    np.random.seed(cases.SEED_NP)
+    plain = Model(wakeword_models=["alexa"], weights=w)
+    np.random.seed(cases.SEED_NP)
+    ver = Model(wakeword_models=["alexa"], weights=w, custom_verifier_models={"alexa": path}, custom_verifier_threshold=0.0)
+    try:
+        clip = golden["pcm/alexa_test"]
+        for o in range(0, 1280 * 12, 1280):
+            a = plain.predict(clip[o:o + 1280])["alexa"]
+            b = ver.predict(clip[o:o + 1280])["alexa"]
+            if len(plain.prediction_buffer["alexa"]) <= 5:
+                assert a == 0.0 and b == 0.0                            # first-five zeroing comes after the verifier
+            else:
+                want = _Verifier().predict_proba(ver.preprocessor.get_features(16))[0][-1]
+                assert b == pytest.approx(want, abs=1e-6) and b != a
+    finally:
+        plain.close()
+        ver.close()
+
+
+@gpu
+def test_names_label_mapping_parent_lookup_and_positive_frames(tmp_path, golden):
+    import wave
+    from openwakeword_amd import Model
+    w = _weights(["alexa", "hey_mycroft", "timer"])
+    # names with spaces resolve like the reference's substring match and stay the keys the user passed (model.py:84-100)
+    m = Model(wakeword_models=["alexa", "hey mycroft"], weights=w | {"heads": {}, "seed": cases.SEED_WEIGHTS})
+    try:
+        out = m.predict(np.random.randint(-1000, 1000, 1280).astype(np.int16))
+        assert set(out) == {"alexa", "hey mycroft"}
+    finally:
+        m.close()
+    # a caller-provided class mapping replaces the label (model.py:177-182), multiclass parents resolve (215-224)
+    m = Model(wakeword_models=["alexa", "timer"], weights=w, class_mapping_dicts=[{"alexa": {"0": "positive"}}])
+    try:
+        assert m.class_mapping["alexa"] == {"alexa": {"0": "positive"}}     # the reference stores the whole entry (model.py:177-178)
+        assert m.get_parent_model_from_label("1_minute_timer") == "timer"
+        assert m.get_parent_model_from_label("alexa") == "alexa"
+        assert m.get_parent_model_from_label("no such label") == ""
+        out = m.predict(np.zeros(1280, np.int16))
+        assert "alexa" in out and "1_hour_timer" in out and len(out) == 1 + 6      # class 0 of `timer` carries no label
+        # _get_positive_prediction_frames (model.py:428-479): with threshold 0 every fed frame qualifies
+        path = str(tmp_path / "clip.wav")
+        with wave.open(path, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes(golden["pcm/hey_jane"][:1280 * 9].tobytes())
+        m.reset()
+        pos = m._get_positive_prediction_frames(path, threshold=0.0)
+        assert pos["alexa"].shape == (8, 16, 96) and pos["1_hour_timer"].shape == (8, 34, 96)
+        m.reset()
+        assert m._get_positive_prediction_frames(path, threshold=2.0) == {}
+        m.reset()
+        aud = m._get_positive_prediction_frames(path, threshold=0.0, return_type="audio")
+        assert aud == {}                                                # less than 4 s of context: nothing collected
+    finally:
+        m.close()
+    with pytest.raises(ValueError, match="silero_vad"):                 # row I is out of scope: refused, not ignored
+        Model(wakeword_models=["alexa"], weights=w, vad_threshold=0.5)
