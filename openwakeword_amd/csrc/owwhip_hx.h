@@ -139,7 +139,10 @@ __device__ __forceinline__ f16x8 lds_h(const float* buf, int blk, int lane) {
 #ifndef OWH_RC_RP
 #define OWH_RC_RP 4
 #endif
-using HB = owr::RCfg<24, 48, 4, 16, 1, 2, 4, OWH_WPS_B>;
+#ifndef OWH_RB_RP
+#define OWH_RB_RP 4
+#endif
+using HB = owr::RCfg<24, 48, 4, 16, 1, 2, OWH_RB_RP, OWH_WPS_B>;
 using HC = owr::RCfg<48, 72, 4, 8, 2, 2, OWH_RC_RP, OWH_WPS_C>;
 using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, OWH_WPS_D>;
 using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
