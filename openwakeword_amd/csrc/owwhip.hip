@@ -400,19 +400,19 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
         Timed t(h, 2);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG, OWH_WG_B>), dim3((p.n_groups + OWH_WG_B - 1) / OWH_WG_B), dim3(64 * OWH_WG_B), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xB, h->d_xC, 7, 4, 5, RC::SPT);
         Timed t(h, 3);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG, OWH_WG_C>), dim3((p.n_groups + OWH_WG_C - 1) / OWH_WG_C), dim3(64 * OWH_WG_C), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xC, h->d_xD, 11, 6, 7, RD::SPT);
         Timed t(h, 4);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG, OWH_WG_D>), dim3((p.n_groups + OWH_WG_D - 1) / OWH_WG_D), dim3(64 * OWH_WG_D), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
@@ -420,7 +420,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.hist19 = h->d_state[10]; p.w19 = h->d_conv[19]; p.feat = h->d_feat; p.emb = h->d_emb; p.nfeat = h->d_nfeat; p.TR = h->TR;
         p.dbg_off[4] = dbg_off[19];
         Timed t(h, 5);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG>), dim3((p.n_groups + OWH_WG - 1) / OWH_WG), dim3(64 * OWH_WG), 0, st, p);
+        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG, OWH_WG_E>), dim3((p.n_groups + OWH_WG_E - 1) / OWH_WG_E), dim3(64 * OWH_WG_E), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     HIPCHK(hipGetLastError());

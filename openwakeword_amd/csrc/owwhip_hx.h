@@ -121,6 +121,18 @@ __device__ __forceinline__ f16x8 lds_h(const float* buf, int blk, int lane) {
 #ifndef OWH_WG
 #define OWH_WG 4           // waves per workgroup of stages B..E (they share one weight chunk stream through LDS)
 #endif
+#ifndef OWH_WG_B
+#define OWH_WG_B OWH_WG
+#endif
+#ifndef OWH_WG_C
+#define OWH_WG_C OWH_WG
+#endif
+#ifndef OWH_WG_D
+#define OWH_WG_D OWH_WG
+#endif
+#ifndef OWH_WG_E
+#define OWH_WG_E OWH_WG
+#endif
 #ifndef OWH_WPS_A
 #define OWH_WPS_A 3
 #endif
@@ -159,7 +171,7 @@ using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
 // chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
 // 1x3 (mel) layer: NT tiles in operand form -> NT fp32 D tiles (BatchNorm + activation applied)
-template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK>
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG>
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
@@ -172,8 +184,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     for (int oct = 0; oct < NCTO; ++oct) {
         const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
         float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
-        if (oct + 1 < NCTO) issue_chunk<NBLK, OWH_WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, OWH_WG>(w_next, nxt, wave, lane);
+        if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
         f32x4 res[NT], accs[2][NT];
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
@@ -235,7 +247,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #ifndef OWH_PIPE_VALU
 #define OWH_PIPE_VALU 2
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane) {
@@ -249,8 +261,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
         if (oct < NCTO) {
             const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
             float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
-            if (oct + 1 < NCTO) issue_chunk<NBLK, OWH_WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, OWH_WG>(w_next, nxt, wave, lane);
+            if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -299,8 +311,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
 // ------------------------------------------------------------------------------------------------
 // stages B..E (parameters, geometry and memory layouts: owr::RStageParams / owr::RCfg, channel tiles NOT re-packed)
 // ------------------------------------------------------------------------------------------------
-template <class C, bool LAST, bool DBG>
-__global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStageParams p) {
+template <class C, bool LAST, bool DBG, int WG = OWH_WG>
+__global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
@@ -309,13 +321,13 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
     static_assert(NB * 256 <= WBUF_FLOATS, "chunk fits the LDS buffer");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int g = blockIdx.x * OWH_WG + wave;
+    int g = blockIdx.x * WG + wave;
     __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
     __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
-    issue_chunk<NBA, OWH_WG>(p.w[0], wbuf, wave, lane);
-    for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * OWH_WG) {
+    issue_chunk<NBA, WG>(p.w[0], wbuf, wave, lane);
+    for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
         sbn[l][0][c] = p.scale[l][c];
         sbn[l][1][c] = p.shift[l][c];
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
     if (pass == 0) chunk_sync();
 
     // conv a: 1x3, CIN -> C
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NB>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NB, WG>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
     for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NB>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane);
+    conv_time_hx<KS, NCT, R, true, NCT, NB, WG>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
     for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB, WG>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
     for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0))>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(64 * OWH_WG, C::WPS) void hstage_kernel(owr::RStage
         Op Po[1][KS];
         to_ops<NCT>(Pl, Po[0]);
         f32x4 E[1][NCT];
-        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane);
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane);
         if (active) {
             store_tile<NCT>(T1, h19, lane);
             store_tile<NCT>(Pl, h19 + NCT * 4 * 64, lane);
