@@ -706,7 +706,9 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     __shared__ float s_x[4][MEL_WX];
     __shared__ float s_z[4][2 * 576];
 #endif
+#ifdef OWK_MEL_NOALIAS
     __shared__ float s_pow[8][MEL_PBINS + 8];
+#endif
     __shared__ float s_red[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -733,6 +735,16 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
 #endif
     float* xr = s_z[wave];
     float* xi = s_z[wave] + 576;
+#ifndef OWK_MEL_NOALIAS
+    // power spectra of the wave's two frames: the last FFT stage leaves xr[128..383] unused (only bins < 128 and >= 384 are
+    // written back), exactly 2 x 128 floats -- 20 KB of LDS per workgroup, seven resident workgroups per CU
+    static_assert(MEL_PBINS + 8 <= 128, "power rows fit the unused middle of the re plane");
+    float* pw0 = xr + 128;
+    float* pw1 = xr + 256;
+#else
+    float* pw0 = s_pow[2 * wave];
+    float* pw1 = s_pow[2 * wave + 1];
+#endif
     __syncthreads();                             // s_hann
 
     int it = 0;
@@ -824,16 +836,17 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 const float zr = xr[k], zi = xi[k], yr = xr[512 - k], yi = xi[512 - k];
                 const float ar = zr + yr, ai = zi - yi;        // 2*A[k]
                 const float br = zi + yi, bi = zr - yr;        // 2*|B[k]| components
-                s_pow[2 * wave][i] = 0.25f * (ar * ar + ai * ai);
-                s_pow[2 * wave + 1][i] = 0.25f * (br * br + bi * bi);
+                pw0[i] = 0.25f * (ar * ar + ai * ai);
+                pw1[i] = 0.25f * (br * br + bi * bi);
             }
             wave_sync();
             // ---- mel + log: thread (fr, mbin), frames of its own wave
             const int frame = g * 8 + fr;
             if (frame < p.n_frames) {
                 float acc = 0.f;
+                const float* pw = (fr & 1) ? pw1 : pw0;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc = fmaf(s_pow[fr][mstart + t], taps[t], acc);
+                for (int t = 0; t < 16; ++t) acc = fmaf(pw[mstart + t], taps[t], acc);
                 float db = 10.0f * logf(fmaxf(acc, 1e-10f)) / 2.302585092994046f;
                 const bool masked = first && frame < 3;
                 if (!masked) vmax = fmaxf(vmax, db);
