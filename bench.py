@@ -77,6 +77,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the cpu_baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--pcm-pool", type=int, default=4, help="distinct PCM buffers cycled through")
+    ap.add_argument("--pcm", choices=("noise", "uniform", "wav"), default="noise",
+                    help="synthetic input (SURVEY 8d): noise = Gaussian RMS 3000 (default); uniform = the reference tests' "
+                         "randint(-1000, 1000) (tests/test_models.py:57); wav = the reference's three fixture clips tiled end to end, "
+                         "stream s starting at sample (s * 997) mod length")
     ap.add_argument("--host-pcm", action="store_true", help="PCIe-inclusive variant (NOT the headline number): PCM handed over as pinned "
                     "host buffers and scores returned to the host every step through the pipelined oww_submit / oww_collect path "
                     "(upload of step t+1 overlaps the kernels of step t)")
@@ -121,8 +125,19 @@ def main():
     # synthetic PCM resident in HBM: Gaussian, RMS 3000, a different seed per rank (independent streams)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xA11CE + rank)
-    pool = [(torch.randn(S, 1280, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
-            for _ in range(max(1, args.pcm_pool))]
+    n_pool = max(1, args.pcm_pool)
+    if args.pcm == "noise":
+        pool = [(torch.randn(S, 1280, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
+                for _ in range(n_pool)]
+    elif args.pcm == "uniform":
+        pool = [torch.randint(-1000, 1000, (S, 1280), device=dev, generator=gen, dtype=torch.int32).to(torch.int16) for _ in range(n_pool)]
+    else:
+        import numpy as np
+        z = np.load(os.path.join(ROOT, "tests", "golden", "ref_streaming.npz"))
+        wav = torch.from_numpy(np.concatenate([z["pcm/" + k] for k in ("alexa_test", "hey_mycroft_test", "hey_jane")])).to(dev)
+        phase = (torch.arange(S, device=dev, dtype=torch.int64) + rank * S) * 997
+        pool = [wav[((phase[:, None] + (i * 1280 + torch.arange(1280, device=dev))[None, :]) % wav.numel())].contiguous()
+                for i in range(n_pool)]
     scores = torch.empty(S, NL, device=dev, dtype=torch.float32)
     from openwakeword_amd.shard import ScoreGather
     gatherer = ScoreGather(S * world, NL, dev) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
@@ -184,12 +199,13 @@ def main():
             "metric": "real-time audio frames/sec (80 ms frame, 3 wakewords), whole job; real-time streams = value/12.5",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("f32" if (args.fp32 or args.valu or args.lds_mfma) else "f32 as 3xf16 split MFMA, fp32 accumulate"), "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f32" if (args.fp32 or args.valu or args.lds_mfma) else "f32 as 3xf16 split MFMA, fp32 accumulate"), "data": "synthetic" if args.pcm != "wav" else "synthetic (reference fixture clips tiled)",
             "config": {"workload": f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), "
                                    "80 ms frames, BASELINE configs[3] per-GPU shard" if S == 131072 else
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
                        "collective": "RCCL gather of scores per step" if world > 1 else "none",
+                       "pcm_distribution": {"noise": "Gaussian, RMS 3000", "uniform": "randint(-1000, 1000)", "wav": "fixture WAVs tiled, phase 997*s"}[args.pcm],
                        "pcm": ("pinned host buffers, PCIe-inclusive, " + ("blocking oww_step" if args.host_pcm_blocking else "pipelined oww_submit/oww_collect") +
                                " (not the headline configuration)") if host else "resident in HBM",
                        "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_rr_fp32" if args.fp32 else "mfma_rr_f16x3")), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
