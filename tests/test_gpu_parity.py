@@ -364,3 +364,35 @@ def test_self_test_catches_f16_range_overflow(emb, heads):
         assert eng.self_test(n_frames=12)["max_abs_score_diff"] == 0.0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_fuzz_kernel_families_agree(emb, seed):
+    """Seeded fuzz over the host-visible degrees of freedom -- stream count (odd, below / above the per-workgroup group
+    sizes), head set (binary, gated, multiclass, wide), chunks per call, partial resets in mid-stream -- comparing the
+    default f16-split family with the LDS-tiled fp32 family, which shares none of its state layouts or stage kernels."""
+    r = np.random.default_rng(seed)
+    S = int(r.choice([1, 5, 31, 33, 97, 130]))
+    names = list(r.choice(["alexa", "hey_mycroft", "hey_jarvis", "timer", "weather", "hey_rhasspy"], size=int(r.integers(1, 4)), replace=False))
+    heads = {n: W.synthetic_head(n, 1234) for n in names}
+    kmax = int(r.integers(1, 4))
+    engs = [StreamEngine(S, heads, emb, use_mfma=m, max_chunks=kmax) for m in (3, 2)]
+    try:
+        for step in range(10):
+            k = int(r.integers(1, kmax + 1))
+            amp = float(r.choice([0.0, 50.0, 3000.0, 20000.0]))
+            pcm = np.clip(np.round(r.normal(0.0, 1.0, (S, 1280 * k)) * amp), -32768, 32767).astype(np.int16)
+            if step in (3, 7) and S > 1:
+                ids = sorted(set(int(i) for i in r.integers(0, S, size=max(1, S // 3))))
+                ring = r.normal(0.0, 1.0, (engs[0].feature_ring, 96)).astype(np.float32)
+                for e in engs:
+                    e.reset(ids, ring)
+            a, b = (e.step(pcm).copy() for e in engs)
+            assert np.isfinite(a).all()
+            np.testing.assert_allclose(a, b, rtol=0, atol=TOL_SCORE, err_msg=f"S={S} heads={names} step={step} k={k}")
+        fa = np.stack([engs[0].get_features(s, 16) for s in range(S)])
+        fb = np.stack([engs[1].get_features(s, 16) for s in range(S)])
+        np.testing.assert_allclose(fa, fb, rtol=0, atol=2e-4)
+    finally:
+        for e in engs:
+            e.close()
