@@ -10,7 +10,8 @@ using it does -- there is no CPU fallback.
 """
 from .model import (MODELS, FEATURE_MODELS, AudioFeatures, BatchedModel, Model, get_pretrained_model_paths,
                     model_class_mappings)
+from .vad import VAD
 
-__all__ = ["Model", "BatchedModel", "AudioFeatures", "MODELS", "FEATURE_MODELS", "model_class_mappings",
+__all__ = ["Model", "BatchedModel", "AudioFeatures", "VAD", "MODELS", "FEATURE_MODELS", "model_class_mappings",
            "get_pretrained_model_paths"]
 __version__ = "0.1.0"

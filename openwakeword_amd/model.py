@@ -179,7 +179,7 @@ class Model:
                  enable_speex_noise_suppression: bool = False, vad_threshold: float = 0,
                  custom_verifier_models: dict = {}, custom_verifier_threshold: float = 0.1,
                  inference_framework: str = "hip", weights: Union[str, dict, None] = None, device: int = 0,
-                 max_chunks: int = 32, wakeword_model_paths: Optional[List[str]] = None, **kwargs):
+                 max_chunks: int = 32, wakeword_model_paths: Optional[List[str]] = None, vad_session=None, **kwargs):
         if wakeword_model_paths is not None:            # deprecated alias (model.py:37)
             wakeword_models = wakeword_model_paths
         if inference_framework != "hip":
@@ -249,9 +249,9 @@ class Model:
         else:
             self.speex_ns = None
         self.vad_threshold = vad_threshold
-        if vad_threshold > 0:
-            raise ValueError("vad_threshold > 0 needs silero_vad.onnx, whose graph is not part of the reference "
-                             "checkout; the VAD gate is not available in this build (DESIGN.md, out of scope)")
+        if vad_threshold > 0:                                                    # model.py:208-210
+            from .vad import VAD
+            self.vad = VAD(session=vad_session)         # raises ValueError without a network (silero_vad.onnx is not in the checkout)
 
         self._engine = StreamEngine(1, heads, embedding, device=device, max_chunks=max_chunks,
                                     feature_ring=AudioFeatures.feature_buffer_max_len)
@@ -352,6 +352,14 @@ class Model:
         self._gate(scores, n_prepared, patience, threshold, debounce_time)
         for label, value in scores.items():                         # model.py:362-363
             self.prediction_buffer[label].append(value)
+        if self.vad_threshold > 0:                                  # model.py:366-381: after the ring append, on the raw x
+            t2 = time.time()
+            self.vad(x)
+            clock["models"]["vad"] = time.time() - t2
+            from .vad import gate_value
+            if gate_value(self.vad.prediction_buffer, self.vad_threshold):
+                for label in scores:
+                    scores[label] = 0.0
         return (scores, clock) if timing else scores
 
     # ---- conveniences on top of predict() --------------------------------------------------------------------------

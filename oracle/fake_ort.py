@@ -13,6 +13,7 @@ Dispatch is on the model file's basename:
     melspectrogram.onnx  -> STAGES['mel'](x f32[B,N])        -> [B,1,F,32]
     embedding_model.onnx -> STAGES['embed'](x f32[B,76,32,1]) -> [B,1,1,96]
     <name>_v0.1.onnx / <name>.onnx -> HEADS[name] = (fn(x f32[1,T,96]) -> [1,n_out], T, n_out)
+    silero_vad.onnx      -> STAGES['vad'].run(None, {'input','h','c','sr'}) -> [out, h, c]   (oracle/pseudo_vad.py)
 """
 from __future__ import annotations
 
@@ -51,6 +52,10 @@ class InferenceSession:
         self._providers = list(providers or ["CPUExecutionProvider"])
         if base.startswith("melspectrogram"):
             self._fn, self._in, self._out = STAGES["mel"], _IO("input", ["batch", "samples"]), _IO("output", ["time", 1, "t", 32])
+        elif base.startswith("silero_vad"):
+            # vad.py:80-81,121-124: four named inputs, three outputs; the network behind it is whatever STAGES['vad'] holds
+            self._vad = STAGES["vad"]
+            self._fn, self._in, self._out = None, _IO("input", [1, "n"]), _IO("output", [1, 1])
         elif base.startswith("embedding_model"):
             self._fn, self._in, self._out = STAGES["embed"], _IO("input_1", ["unk", 76, 32, 1]), _IO("conv2d_19", ["unk", 1, 1, 96])
         else:
@@ -58,6 +63,8 @@ class InferenceSession:
             self._fn, self._in, self._out = fn, _IO("onnx::Flatten_0", [1, T, 96]), _IO(base, [1, n_out])
 
     def run(self, output_names, feeds):
+        if self._fn is None:
+            return self._vad.run(output_names, feeds)
         (x,) = feeds.values()
         return [self._fn(x)]
 

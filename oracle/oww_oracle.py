@@ -415,12 +415,34 @@ class OracleAudioFeatures:
 
 # --------------------------------------------------------------------------------------
 # Rows A, H: Model.predict / predict_clip / reset (openwakeword/model.py:226-426), without
-# Speex, VAD and custom verifiers (out of scope)
+# Speex and custom verifiers; row I: the VAD gate around a pluggable network
 # --------------------------------------------------------------------------------------
+class OracleVad:
+    """openwakeword/vad.py:83-130 around any `session.run(None, {'input','h','c','sr'}) -> [out, h, c]`."""
+
+    def __init__(self, session):
+        self.session = session
+        self.ring: deque = deque(maxlen=125)                       # vad.py:84
+        self.h = np.zeros((2, 1, 64), np.float32)                  # vad.py:92-96
+        self.c = np.zeros((2, 1, 64), np.float32)
+
+    def __call__(self, x):                                         # vad.py:129-130: 640-sample sub-frames
+        outs = []
+        for i in range(0, x.shape[0], 640):                        # vad.py:115-125
+            piece = (x[i:i + 640] / 32767).astype(np.float32)[None]
+            out, self.h, self.c = self.session.run(None, {"input": piece, "h": self.h, "c": self.c,
+                                                          "sr": np.array(16000).astype(np.int64)})
+            outs.append(out[0][0])
+        self.ring.append(np.mean(outs))                            # vad.py:127,130
+
+
 class OracleModel:
     def __init__(self, heads: Dict[str, dict], emb: dict, dtype=np.float32,
                  class_mapping: Optional[Dict[str, Dict[str, str]]] = None,
-                 head_fns: Optional[Dict[str, Callable]] = None, **feature_kwargs):
+                 head_fns: Optional[Dict[str, Callable]] = None, vad_threshold: float = 0.0, vad_session=None,
+                 **feature_kwargs):
+        self.vad_threshold = vad_threshold
+        self.vad = OracleVad(vad_session) if vad_threshold > 0 else None      # model.py:208-210; survives reset()
         self.heads = heads
         self.dtype = dtype
         self.model_inputs = {k: int(h["T"]) for k, h in heads.items()}
@@ -506,6 +528,12 @@ class OracleModel:
                             out[label] = 0.0
         for label in out:                                          # model.py:362-363
             self._ring(label).append(out[label])
+        if self.vad_threshold > 0:                                 # model.py:366-381, on the raw x, after the ring append
+            self.vad(x)
+            window = list(self.vad.ring)[-7:-4]                    # frames 0.4 .. 0.56 s before this one
+            if (np.max(window) if len(window) > 0 else 0) < self.vad_threshold:
+                for label in out:
+                    out[label] = 0.0
         return out
 
     def predict_clip(self, clip: np.ndarray, padding: int = 1, chunk_size: int = 1280, **kw):

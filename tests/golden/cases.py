@@ -23,3 +23,13 @@ CLIP_CASES = [
     ("timer", ["timer"], "hey_mycroft_test", dict(chunk_size=1280)),
     ("timer2560", ["timer"], "hey_mycroft_test", dict(chunk_size=2560)),
 ]
+
+# VAD-gated cases (row I): (case id, heads, clip, predict_clip kwargs, vad_threshold).  The network behind the reference's VAD
+# class is oracle/pseudo_vad.py (the real silero_vad.onnx is not available); chunk sizes are multiples of the 640-sample VAD frame.
+VAD_CASES = [
+    ("vad03", ["alexa", "hey_mycroft"], "alexa_test", dict(chunk_size=1280), 0.3),
+    ("vad07", ["alexa", "hey_mycroft"], "hey_jane", dict(chunk_size=1280), 0.7),
+    ("vad2560", ["alexa"], "hey_mycroft_test", dict(chunk_size=2560), 0.5),
+    ("vad640", ["alexa"], "alexa_test", dict(chunk_size=640), 0.5),
+    ("vadnp", ["hey_mycroft"], "hey_mycroft_test", dict(chunk_size=1280, padding=0), 0.5),
+]

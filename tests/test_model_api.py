@@ -249,5 +249,37 @@ def test_names_label_mapping_parent_lookup_and_positive_frames(tmp_path, golden)
         assert aud == {}                                                # less than 4 s of context: nothing collected
     finally:
         m.close()
-    with pytest.raises(ValueError, match="silero_vad"):                 # row I is out of scope: refused, not ignored
+    with pytest.raises(ValueError, match="vad_session"):                # no VAD network available: refused, not ignored
         Model(wakeword_models=["alexa"], weights=w, vad_threshold=0.5)
+
+
+@gpu
+@pytest.mark.parametrize("case", cases.VAD_CASES, ids=[c[0] for c in cases.VAD_CASES])
+def test_vad_gate_matches_reference_golden(golden, case):
+    """Row I, the part that can be pinned: `Model(vad_threshold=..., vad_session=...)` against the reference's own Model with
+    the same pseudo VAD network behind its VAD class (tests/golden/make_golden_vad.py): gated scores, the VAD ring, the
+    ungated score ring, and reset() leaving the VAD alone."""
+    import os
+    from oracle.pseudo_vad import PseudoVadSession
+    from openwakeword_amd import Model
+    gv = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vad.npz")))
+    cid, head_names, clip, kw, thr = case
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=list(head_names), weights=_weights(head_names), vad_threshold=thr, vad_session=PseudoVadSession())
+    try:
+        preds = m.predict_clip(golden["pcm/" + clip], **kw)
+        labels = list(gv[f"{cid}/labels"])
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, gv[f"{cid}/scores"], rtol=0, atol=TOL_SCORE)
+        np.testing.assert_allclose(np.array(m.vad.prediction_buffer), gv[f"{cid}/vad"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(np.array([list(m.prediction_buffer[k]) for k in labels]), gv[f"{cid}/ring"], rtol=0, atol=TOL_SCORE)
+        if cid == "vad03":
+            np.random.seed(cases.SEED_NP + 1)
+            m.reset()
+            preds = m.predict_clip(golden["pcm/hey_mycroft_test"], chunk_size=1280)
+            got = np.array([[float(p[k]) for k in labels] for p in preds])
+            np.testing.assert_allclose(got, gv["vadreset/scores"], rtol=0, atol=TOL_SCORE)
+            _, timing = m.predict(np.zeros(1280, np.int16), timing=True)
+            assert "vad" in timing["models"]
+    finally:
+        m.close()

@@ -87,3 +87,60 @@ def test_cnn_is_time_fully_convolutional():
     for k in range(4):
         one = O.embedding_stage(strip[:, 8 * k: 8 * k + 76], emb, np.float64).reshape(96)
         np.testing.assert_allclose(full[k], one, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------- row I: the VAD gate
+@pytest.fixture(scope="module")
+def golden_vad():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vad.npz")))
+
+
+@pytest.mark.parametrize("case", cases.VAD_CASES, ids=[c[0] for c in cases.VAD_CASES])
+def test_vad_gate_restatement_matches_reference(golden, golden_vad, case):
+    """The reference's own VAD class + gate (vad.py:54-130, model.py:366-381) ran on the pseudo network of
+    oracle/pseudo_vad.py (tests/golden/make_golden_vad.py); the oracle's restatement must give the same gated scores, the same
+    VAD ring and the same (ungated) score ring."""
+    from oracle.pseudo_vad import PseudoVadSession
+    cid, head_names, clip, kw, thr = case
+    emb = W.synthetic_embedding(cases.SEED_WEIGHTS)
+    heads = {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in head_names}
+    np.random.seed(cases.SEED_NP)
+    mdl = O.OracleModel(heads, emb, vad_threshold=thr, vad_session=PseudoVadSession())
+    preds = mdl.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(golden_vad[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    np.testing.assert_allclose(got, golden_vad[f"{cid}/scores"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.array(mdl.vad.ring), golden_vad[f"{cid}/vad"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.array([list(mdl.prediction_buffer[k]) for k in labels]), golden_vad[f"{cid}/ring"], rtol=0, atol=2e-6)
+    if cid == "vad03":
+        np.random.seed(cases.SEED_NP + 1)
+        mdl.reset()                                                   # leaves the VAD state and ring alone
+        preds = mdl.predict_clip(golden["pcm/hey_mycroft_test"], chunk_size=1280)
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, golden_vad["vadreset/scores"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.array(mdl.vad.ring), golden_vad["vadreset/vad"], rtol=0, atol=1e-6)
+
+
+def test_vad_wrapper_of_the_package_matches_reference(golden, golden_vad):
+    """openwakeword_amd.VAD (sub-framing, /32767 scaling, state carry, mean, 125-deep ring) on the calls predict_clip makes:
+    depends on the audio only, so it is pinned on the CPU."""
+    from oracle.pseudo_vad import PseudoVadSession
+    from openwakeword_amd.vad import VAD, gate_value
+    for cid, _heads, clip, kw, thr in cases.VAD_CASES:
+        data = golden["pcm/" + clip]
+        if kw.get("padding", 1):
+            z = np.zeros(16000, np.int16)
+            data = np.concatenate((z, data, z))
+        v = VAD(session=PseudoVadSession())
+        cs = kw["chunk_size"]
+        gates = []
+        for o in range(0, data.shape[0] - cs, cs):
+            v(data[o:o + cs])
+            gates.append(gate_value(v.prediction_buffer, thr))
+        np.testing.assert_allclose(np.array(v.prediction_buffer), golden_vad[f"{cid}/vad"], rtol=0, atol=1e-6)
+        # a gated frame is all zeros in the reference's output
+        sc = golden_vad[f"{cid}/scores"]
+        assert all((sc[i] == 0).all() for i, g in enumerate(gates) if g)
+    with pytest.raises(ValueError, match="vad_session"):
+        VAD()                                                          # no network, no onnxruntime: refused, not ignored
