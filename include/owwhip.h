@@ -90,6 +90,17 @@ int  oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* in
  * patience[i] <= 0 and debounce_frames <= 0 disable the respective rule for label i. */
 int  oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold, int32_t debounce_frames);
 
+/* ---- VAD gate of Model.predict (model.py:366-381) for the batched path -------------------------------------------------
+ * The voice-activity NETWORK is not part of this library (silero_vad.onnx is a release asset whose graph is not in the reference
+ * checkout): the caller supplies one VAD score per stream and step -- the mean over the step's 640-sample sub-frames that
+ * VAD.__call__ appends (vad.py:98-130) -- and the library keeps the per-stream score ring and applies the gate: when the largest
+ * of the scores pushed 5..7 steps ago (ring[-7:-4]; nothing during the first four steps) is below `threshold`, every label of
+ * that stream reads 0 for the step (the 30-deep score ring keeps the ungated value, as in the reference).  threshold <= 0
+ * switches the gate off (default).  Call oww_push_vad BEFORE the oww_step / oww_submit of the same frame; vad_scores is
+ * fp32 [S], host or device.  Like Model.reset(), oww_reset leaves the VAD ring alone. */
+int  oww_set_vad_threshold(oww_ctx* h, float threshold);
+int  oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device);
+
 /* ---- the hot loop: one Model.predict per stream (model.py:232-386) --------------------------------
  * pcm: int16 [S][n_chunks*1280], stream-major.  scores: fp32 [S][n_labels] or NULL.
  * *_on_device: 0 = host pointer (copied on the handle's stream), 1 = device pointer.

@@ -40,6 +40,8 @@ SYMBOLS = {
     "oww_collect": (C.c_int, [_P, _P]),
     "oww_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "oww_host_free": (C.c_int, [_P]),
+    "oww_set_vad_threshold": (C.c_int, [_P, C.c_float]),
+    "oww_push_vad": (C.c_int, [_P, _P, C.c_int]),
     "oww_scores_dev": (_P, [_P]),
     "oww_get_raw": (C.c_int, [_P, _P]),
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),

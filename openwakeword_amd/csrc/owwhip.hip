@@ -255,6 +255,7 @@ struct oww_ctx {
     long long* d_prof = nullptr;     // [4 stages][16 waves][16 marks], allocated when OWW_PROF_BLOCK is set
     int prof_block = -1;
     uint32_t *d_nfeat = nullptr, *d_npred = nullptr;
+    float* d_vadring = nullptr; uint32_t* d_nvad = nullptr; float* d_vadin = nullptr; float vad_threshold = 0.f;   // VAD gate (oww_push_vad)
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
     int* d_ids = nullptr;
     int ids_cap = 0;
@@ -554,7 +555,7 @@ void free_all(oww_ctx* h) {
     for (auto& g : h->groups) fr(g.d_nets);
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
-    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail);
+    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin);
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold);
     for (auto& sl : h->slot) {
         fr(sl.d_pcm); fr(sl.d_scores);
@@ -586,6 +587,7 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
     pp.raw = h->d_raw; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred;
     pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
     pp.NL = h->NL; pp.S = h->Spad;
+    pp.vad_ring = h->d_vadring; pp.n_vad = h->d_nvad; pp.vad_threshold = h->vad_threshold;
     {
         Timed t(h, 7);
         hipLaunchKernelGGL(postproc_kernel, dim3((h->Spad + 127) / 128), dim3(128), 0, h->stream, pp);
@@ -874,6 +876,9 @@ int oww_commit(oww_ctx* h) {
     if (int rc = dalloc(&h->d_featinit, (size_t)h->TR * 96)) return rc;
     if (int rc = dalloc(&h->d_nfeat, SP)) return rc;
     if (int rc = dalloc(&h->d_npred, SP)) return rc;
+    if (int rc = dalloc(&h->d_vadring, SP * 8)) return rc;
+    if (int rc = dalloc(&h->d_nvad, SP)) return rc;
+    if (int rc = dalloc(&h->d_vadin, SP)) return rc;
     if (int rc = dalloc(&h->d_tail, SP * 480)) return rc;
     if (int rc = dalloc(&h->d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax)) return rc;
     if (int rc = dalloc(&h->d_patience, (size_t)std::max(h->NL, 1))) return rc;
@@ -1060,6 +1065,29 @@ int oww_host_alloc(void** out, size_t nbytes) {
 
 int oww_host_free(void* p) {
     if (p) HIPCHK(hipHostFree(p));
+    return OWW_OK;
+}
+
+int oww_set_vad_threshold(oww_ctx* h, float threshold) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_set_vad_threshold: handle not committed");
+    if (!(threshold == threshold)) return fail(OWW_EINVAL, "oww_set_vad_threshold: NaN");
+    h->vad_threshold = threshold;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }     // the threshold is a kernel argument
+    return OWW_OK;
+}
+
+int oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_push_vad: handle not committed");
+    if (!vad_scores) return fail(OWW_EINVAL, "oww_push_vad: null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const float* src = vad_scores;
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(h->d_vadin, vad_scores, (size_t)h->S * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        src = h->d_vadin;
+    }
+    hipLaunchKernelGGL(push_vad_kernel, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_vadring, h->d_nvad, src, h->S);
+    HIPCHK(hipGetLastError());
+    if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));          // the caller's buffer may be reused at once
     return OWW_OK;
 }
 

@@ -1163,6 +1163,10 @@ struct PostParams {
     const float* threshold;  // [NL]  (NaN = no threshold for this label)
     int debounce_frames;
     int NL, S;
+    // VAD gate (model.py:366-381): per-stream ring of the caller-supplied voice-activity scores, 8 deep
+    const float* vad_ring;   // [S][8]
+    const uint32_t* n_vad;   // [S] scores pushed so far
+    float vad_threshold;     // <= 0: gate off
 };
 
 __global__ void postproc_kernel(PostParams p) {
@@ -1193,6 +1197,26 @@ __global__ void postproc_kernel(PostParams p) {
         p.scores[(size_t)s * p.NL + l] = sc;
     }
     p.npred[s] = cnt + 1u;
+    if (p.vad_threshold > 0.0f) {
+        // model.py:375-381: the score ring above keeps the ungated values; the returned scores of this step are zeroed when the
+        // largest VAD score of ring[-7:-4] (entries L-7 .. L-5 of the L pushed so far; none while L < 5) is below the threshold
+        const uint32_t L = p.n_vad[s];
+        float vmax = 0.0f;
+        if (L >= 5u) {
+            vmax = -INFINITY;
+            for (uint32_t i = (L >= 7u ? L - 7u : 0u); i + 5u <= L; ++i) vmax = fmaxf(vmax, p.vad_ring[(size_t)s * 8 + (i & 7u)]);
+        }
+        if (vmax < p.vad_threshold)
+            for (int l = 0; l < p.NL; ++l) p.scores[(size_t)s * p.NL + l] = 0.0f;
+    }
+}
+
+__global__ void push_vad_kernel(float* ring, uint32_t* n_vad, const float* scores, int S) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t L = n_vad[s];
+    ring[(size_t)s * 8 + (L & 7u)] = scores[s];
+    n_vad[s] = L + 1u;
 }
 
 __global__ void advance_kernel(uint32_t* nfeat, int S) {

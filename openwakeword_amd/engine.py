@@ -255,6 +255,17 @@ class StreamEngine:
                                 f"({res}): create the engine with use_mfma=1")
         return res
 
+    def set_vad_threshold(self, threshold: float) -> None:
+        """VAD gate of model.py:366-381 on the device (0 = off); the scores come from push_vad()."""
+        _lib.check(self._lib.oww_set_vad_threshold(self._h, float(threshold)))
+
+    def push_vad(self, vad_scores: np.ndarray) -> None:
+        """One voice-activity score per stream for the frame about to be stepped (what VAD.__call__ appends, vad.py:129-130)."""
+        v = np.ascontiguousarray(vad_scores, dtype=np.float32)
+        if v.shape != (self.n_streams,):
+            raise ValueError(f"need one VAD score per stream ({self.n_streams})")
+        _lib.check(self._lib.oww_push_vad(self._h, _ptr(v), 0))
+
     def sync(self):
         _lib.check(self._lib.oww_sync(self._h))
 

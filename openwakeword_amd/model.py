@@ -459,6 +459,15 @@ class BatchedModel:
             raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
         return self.engine.step(pcm)[:, self._keep]
 
+    def set_vad_threshold(self, threshold: float) -> None:
+        """The VAD gate of `Model(vad_threshold=...)` (model.py:366-381) for every stream; 0 switches it off."""
+        self.engine.set_vad_threshold(threshold)
+
+    def push_vad(self, vad_scores: np.ndarray) -> None:
+        """Voice-activity score of each stream for the frame about to be predicted (the value `VAD.__call__` appends to its
+        ring, vad.py:98-130); the network that produces it is the caller's (see openwakeword_amd.vad)."""
+        self.engine.push_vad(vad_scores)
+
     def submit_batch(self, pcm: np.ndarray) -> None:
         """Pipelined `predict_batch` for host-fed serving: enqueue one step (upload on its own stream) and return; the
         scores come back from `collect_batch()` in submission order, at most two steps in flight.  Page-locked buffers

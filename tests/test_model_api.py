@@ -283,3 +283,49 @@ def test_vad_gate_matches_reference_golden(golden, case):
             assert "vad" in timing["models"]
     finally:
         m.close()
+
+
+@gpu
+def test_batched_vad_gate_matches_single_stream_models(golden):
+    """The device-side gate (oww_push_vad / oww_set_vad_threshold) on S streams == S reference-style Models with the VAD
+    wrapper, fed the same audio; the per-stream VAD scores come from the same pseudo network on the host."""
+    from oracle.pseudo_vad import PseudoVadSession
+    from openwakeword_amd import Model, BatchedModel, VAD
+    names = ["alexa", "hey_mycroft"]
+    w = _weights(names)
+    clips = [golden["pcm/alexa_test"], golden["pcm/hey_jane"], golden["pcm/hey_mycroft_test"]]
+    steps = 26
+    S = len(clips)
+    pcm = np.zeros((S, 1280 * steps), np.int16)
+    for i, c in enumerate(clips):                                         # staggered starts, silence around the speech
+        o = 1280 * (2 + 3 * i)
+        n = min(len(c), pcm.shape[1] - o)
+        pcm[i, o:o + n] = c[:n]
+    singles, vads = [], []
+    for s in range(S):
+        np.random.seed(cases.SEED_NP + s)
+        singles.append(Model(wakeword_models=names, weights=w, vad_threshold=0.5, vad_session=PseudoVadSession()))
+        vads.append(VAD(session=PseudoVadSession()))
+    bm = BatchedModel(S, names, weights=w)
+    try:
+        for s in range(S):                                                # same feature-ring seeds as the single models
+            bm.reset([s], singles[s].preprocessor.get_features(bm.engine.feature_ring)[0])
+        bm.set_vad_threshold(0.5)
+        gated = 0
+        for t in range(steps):
+            x = np.ascontiguousarray(pcm[:, 1280 * t: 1280 * (t + 1)])
+            for s in range(S):
+                vads[s](x[s])
+            bm.push_vad(np.array([v.prediction_buffer[-1] for v in vads], np.float32))
+            got = bm.predict_batch(x)
+            for s in range(S):
+                want = singles[s].predict(x[s])
+                np.testing.assert_allclose(got[s], [want[k] for k in bm.labels], rtol=0, atol=TOL_SCORE)
+                gated += int(all(v == 0.0 for v in want.values()) and t >= 5)
+        assert gated > 0
+        bm.set_vad_threshold(0.0)                                         # gate off: scores flow again
+        assert bm.predict_batch(np.ascontiguousarray(pcm[:, :1280])).shape == (S, 2)
+    finally:
+        bm.close()
+        for m in singles:
+            m.close()
