@@ -99,3 +99,78 @@ def compute_features_from_generator(generator: Iterator[np.ndarray], n_total: in
             engine.reset()
     trim_mmap(output_file, rows)
     return rows
+
+
+def bulk_predict(file_paths, wakeword_models, prediction_function: str = "predict_clip", ncpu: int = 1,
+                 inference_framework: str = "hip", **kwargs) -> dict:
+    """`openwakeword.utils.bulk_predict` (utils.py:466-536) with the GPU as the pool of workers.
+
+    The reference forks `ncpu` processes, each streaming its share of the files through one `Model`; here every file is one
+    stream of a `BatchedModel` and all files advance together, 80 ms per device step (equivalent to the reference with one
+    fresh process per file: no state is carried from one clip to the next).  `predict_clip` keyword arguments (`padding`,
+    `chunk_size` -- a multiple of 1280 --, `patience`, `threshold`, `debounce_time`) and `Model` keyword arguments
+    (`weights`, `device`) are taken from **kwargs like the reference filters them by name.  Other prediction functions, or
+    chunk sizes that are not whole 80 ms frames, run file by file through a single `Model`.
+    Returns {file path: value of the prediction function}, for `predict_clip` a list of {label: score} per chunk."""
+    import wave
+    from .model import BatchedModel, Model
+    if inference_framework != "hip":
+        raise ValueError("openwakeword_amd only provides inference_framework='hip'")
+    file_paths = list(file_paths)
+    model_kw = {k: v for k, v in kwargs.items() if k in ("weights", "device", "class_mapping_dicts", "vad_threshold", "vad_session",
+                                                         "custom_verifier_models", "custom_verifier_threshold",
+                                                         "enable_speex_noise_suppression")}
+    chunk = int(kwargs.get("chunk_size", 1280))
+    batched_ok = prediction_function == "predict_clip" and chunk % 1280 == 0 and chunk > 0 and \
+        not (set(model_kw) - {"weights", "device"})
+    if not batched_ok:
+        mdl = Model(wakeword_models=wakeword_models, **model_kw)
+        try:
+            fn = getattr(mdl, prediction_function)
+            names = fn.__code__.co_varnames
+            takes_kw = bool(fn.__code__.co_flags & 0x08)
+            out = {}
+            for f in file_paths:
+                out[f] = fn(f, **{k: v for k, v in kwargs.items() if (k in names or takes_kw) and k not in model_kw})
+                mdl.reset()
+            return out
+        finally:
+            mdl.close()
+
+    padding = int(kwargs.get("padding", 1))
+    clips = []
+    for f in file_paths:
+        with wave.open(f, mode="rb") as w:
+            data = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        if padding:
+            z = np.zeros(16000 * padding, dtype=np.int16)
+            data = np.concatenate((z, data, z))
+        clips.append(data)
+    if not clips:
+        return {}
+    k = chunk // 1280
+    n_calls = [len(range(0, c.shape[0] - chunk, chunk)) for c in clips]              # model.py:421-426
+    S = len(clips)
+    bm = BatchedModel(S, list(wakeword_models), weights=model_kw.get("weights", "synthetic"),
+                      device=int(model_kw.get("device", 0)), max_chunks=k)
+    try:
+        seed_stream = AudioFeatures(bm.engine, 0)                                     # seeds a feature ring like a fresh Model
+        init = seed_stream.get_features(bm.engine.feature_ring)[0]
+        ring = np.zeros((bm.engine.feature_ring, EMB_DIM), np.float32)
+        ring[ring.shape[0] - init.shape[0]:] = init
+        bm.reset(None, ring)
+        bm.set_postproc(kwargs.get("patience", {}), kwargs.get("threshold", {}), float(kwargs.get("debounce_time", 0.0)), chunk)
+        results = [[] for _ in range(S)]
+        pcm = np.zeros((S, chunk), np.int16)
+        for t in range(max(n_calls)):
+            pcm[:] = 0
+            for s, c in enumerate(clips):
+                if t < n_calls[s]:
+                    pcm[s] = c[t * chunk:(t + 1) * chunk]
+            scores = bm.predict_batch(pcm)
+            for s in range(S):
+                if t < n_calls[s]:
+                    results[s].append({lab: scores[s, i] for i, lab in enumerate(bm.labels)})
+        return {f: results[s] for s, f in enumerate(file_paths)}
+    finally:
+        bm.close()

@@ -115,3 +115,41 @@ def test_compute_features_from_generator(tmp_path):
     np.testing.assert_allclose(np.load(path), want, rtol=0, atol=1e-6)
     assert _oracle_clips(emb, clips[:2]).shape == (2, 16, 96)
     np.testing.assert_allclose(np.load(path)[:2], _oracle_clips(emb, clips[:2]), rtol=0, atol=2e-4)
+
+
+@gpu
+def test_bulk_predict_matches_predict_clip_per_file(tmp_path):
+    """utils.bulk_predict (utils.py:466-536) with every file as one stream of a BatchedModel == Model.predict_clip on each
+    file with a fresh Model (clips of different lengths, 80 ms and 160 ms calls, debounce)."""
+    import wave
+    from openwakeword_amd import Model
+    from openwakeword_amd.utils import bulk_predict
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_streaming.npz"))
+    files = []
+    for name in ("alexa_test", "hey_mycroft_test", "hey_jane"):
+        path = str(tmp_path / (name + ".wav"))
+        with wave.open(path, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes(z["pcm/" + name].tobytes())
+        files.append(path)
+    names = ["alexa", "hey_mycroft"]
+    w = {"embedding": W.synthetic_embedding(1234), "heads": {n: W.synthetic_head(n, 1234) for n in names}}
+    for kw in (dict(chunk_size=1280), dict(chunk_size=2560, padding=0), dict(chunk_size=1280, debounce_time=0.3, threshold={"alexa": 0.4, "hey_mycroft": 0.5})):
+        np.random.seed(11)
+        got = bulk_predict(files, names, weights=w, **kw)
+        assert list(got) == files
+        for f in files:
+            np.random.seed(11)
+            m = Model(wakeword_models=names, weights=w)
+            try:
+                want = m.predict_clip(f, **kw)
+            finally:
+                m.close()
+            assert len(got[f]) == len(want)
+            a = np.array([[p[k] for k in names] for p in got[f]])
+            b = np.array([[p[k] for k in names] for p in want])
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    # anything else goes file by file through a Model
+    np.random.seed(11)
+    other = bulk_predict(files[:1], names, weights=w, chunk_size=1024)
+    assert len(other[files[0]]) == len(range(0, len(z["pcm/alexa_test"]) + 32000 - 1024, 1024))
