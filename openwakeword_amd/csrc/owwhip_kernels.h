@@ -752,7 +752,6 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     if ((int)blockIdx.x < p.S) mel_fetch(p, blockIdx.x, 0, wave, lane, hist, raw);
     for (int s = blockIdx.x; s < p.S; s += gridDim.x, ++it) {
         const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
-        const int16_t* tail = p.tail + (size_t)s * 480;
         const bool first = p.streaming && (p.nfeat[s] == 0);
         float vmax = -INFINITY;
         float last_db = 0.f;
