@@ -474,13 +474,13 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                     o.w2hx = g.d_w2hx[i]; o.b1 = d.b1; o.ln1g = d.ln1g; o.ln1b = d.ln1b; o.b2 = d.b2; o.ln2g = d.ln2g; o.ln2b = d.ln2b;
                     o.w3 = d.w3; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
                 }
-                const dim3 grid((n_active + 127) / 128);
-                const int lds = 2 * g.n_nets * 8 * 1024;
+                const dim3 grid((n_active + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
+                const int lds = owh::HX_NBUF * g.n_nets * 8 * 1024;
                 switch (g.n_nets) {
-                    case 1: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, dim3(256), lds, st, q); break;
-                    case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<2>, grid, dim3(256), lds, st, q); break;
-                    case 3: hipLaunchKernelGGL(owh::heads_hx_kernel<3>, grid, dim3(256), lds, st, q); break;
-                    default: hipLaunchKernelGGL(owh::heads_hx_kernel<4>, grid, dim3(256), lds, st, q); break;
+                    case 1: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;
+                    case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<2>, grid, block, lds, st, q); break;
+                    case 3: hipLaunchKernelGGL(owh::heads_hx_kernel<3>, grid, block, lds, st, q); break;
+                    default: hipLaunchKernelGGL(owh::heads_hx_kernel<4>, grid, block, lds, st, q); break;
                 }
                 continue;
             }
@@ -891,10 +891,10 @@ int oww_commit(oww_ctx* h) {
     if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
     if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
-    if (int rc = set_lds(owh::heads_hx_kernel<1>, 2 * 1 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<2>, 2 * 2 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<3>, 2 * 3 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<4>, 2 * 4 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<1>, owh::HX_NBUF * 1 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<2>, owh::HX_NBUF * 2 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<3>, owh::HX_NBUF * 3 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<4>, owh::HX_NBUF * 4 * 8 * 1024)) return rc;
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stageA_kernel<false>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stage_kernel<CfgB, true, false>, CfgB::LDS_BYTES)) return rc;

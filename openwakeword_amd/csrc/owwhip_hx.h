@@ -740,17 +740,35 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
     }
 }
 
+// Waves per workgroup and weight chunks in the LDS ring.  The first layer is a K = 96 T GEMM whose weights (NN x 8 KB per k-step
+// of 32 features) stream L2 -> LDS once per workgroup.  Defaults: 4 waves (128 streams), double buffer.  A deeper pipeline --
+// 8 waves = 256 streams per chunk and a ring of 3 or 4 chunks with a counted s_waitcnt vmcnt(n) in front of the barrier, so
+// that two or three chunks stay in flight -- measured the same or 2 % slower (0.353 vs 0.347 ms): the waves' wait time (59 % of
+// their cycles, PMC) is the LDS read of the A operands (32 KB per wave and k-step for 96 MFMAs), not the DMA latency.
+#ifndef OWH_HEADS_WG
+#define OWH_HEADS_WG 4
+#endif
+#ifndef OWH_HEADS_NBUF
+#define OWH_HEADS_NBUF 2
+#endif
+constexpr int HX_WG = OWH_HEADS_WG, HX_NBUF = OWH_HEADS_NBUF;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int NN>
-__global__ __launch_bounds__(256, 2) void heads_hx_kernel(HeadHxParams p) {
+__global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p) {
     using namespace owr;
     constexpr int NCT = NN * 4;                 // hidden tiles of 16
     constexpr int NBLK = NCT * 2;               // 1 KB blocks per k-step chunk
     constexpr int CHUNK = NBLK * 256;           // floats
-    extern __shared__ __attribute__((aligned(16))) float hbuf[];      // 2 x CHUNK
+    constexpr int LPT = (NBLK + HX_WG - 1) / HX_WG;       // DMA instructions per thread and chunk
+    constexpr int D = HX_NBUF - 1;              // chunks in flight ahead of the one being consumed
+    extern __shared__ __attribute__((aligned(16))) float hbuf[];      // HX_NBUF x CHUNK
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KST = p.T * 3;
-    issue_chunk<NBLK>(p.w1hx, hbuf, wave, lane);
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < KST) issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)c * CHUNK, hbuf + c * CHUNK, wave, lane);
 
     // this lane's streams (two tiles of 16) and the address of ring row t
     int s[2];
@@ -758,31 +776,37 @@ __global__ __launch_bounds__(256, 2) void heads_hx_kernel(HeadHxParams p) {
     uint32_t slot0[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        s[t] = min((blockIdx.x * 4 + wave) * 32 + t * 16 + pos, p.S - 1);
+        s[t] = min((blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos, p.S - 1);
         if (p.ext) { frow[t] = p.feat + (size_t)s[t] * p.T * 96; slot0[t] = 0; }
         else { frow[t] = p.feat + (size_t)s[t] * p.TR * 96; slot0[t] = p.nfeat[s[t]] + (uint32_t)(2 * p.TR - p.T + 1); }
     }
-    auto load_b = [&](int ks, Op (&b)[2]) {
+    // features of k-step ks as loaded (two 16-byte pieces per tile); the f16 split happens one iteration later, so that
+    // waiting for them never waits for the weight chunk issued after them
+    auto load_raw = [&](int ks, f32x4 (&r)[2][2]) {
         const int tr = ks / 3, c0 = (ks % 3) * 32 + 8 * j;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint32_t slot = p.ext ? (uint32_t)tr : (slot0[t] + (uint32_t)tr) % (uint32_t)p.TR;
             const float* src = frow[t] + (size_t)slot * 96 + c0;
-            b[t] = split_pair<false>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));   // (the asm form is slower here)
+            r[t][0] = *reinterpret_cast<const f32x4*>(src);
+            r[t][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
     };
     f32x4 acc[NCT][2];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    Op bcur[2], bnxt[2];
-    load_b(0, bcur);
-    chunk_sync();
+    Op bcur[2];
+    f32x4 raw[2][2];
+    load_raw(0, raw);
+    bcur[0] = split_pair<false>(raw[0][0], raw[0][1]);
+    bcur[1] = split_pair<false>(raw[1][0], raw[1][1]);          // (vmcnt(0): also the first chunks have landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int ks = 0; ks < KST; ++ks) {
-        const float* cur = hbuf + (ks & 1) * CHUNK;
-        if (ks + 1 < KST) {
-            issue_chunk<NBLK>(p.w1hx + (size_t)(ks + 1) * CHUNK, hbuf + ((ks + 1) & 1) * CHUNK, wave, lane);
-            load_b(ks + 1, bnxt);
-        }
+        const float* cur = hbuf + (ks % HX_NBUF) * CHUNK;
+        if (ks + 1 < KST) load_raw(ks + 1, raw);                // older than the chunk issued next
+        if (ks + D < KST)                                       // slot of chunk ks-1: every wave passed the last barrier
+            issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hbuf + ((ks + D) % HX_NBUF) * CHUNK, wave, lane);
 #pragma unroll
         for (int c2 = 0; c2 < NCT; c2 += 2) {
             const f16x8 ah0 = lds_h(cur, c2 * 2 + 0, lane), al0 = lds_h(cur, c2 * 2 + 1, lane);
@@ -796,7 +820,14 @@ __global__ __launch_bounds__(256, 2) void heads_hx_kernel(HeadHxParams p) {
                 }
             }
         }
-        if (ks + 1 < KST) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; chunk_sync(); }
+        if (ks + 1 < KST) {
+            bcur[0] = split_pair<false>(raw[0][0], raw[0][1]);
+            bcur[1] = split_pair<false>(raw[1][0], raw[1][1]);
+            // chunk ks+1 must have landed; the chunks ks+2 .. ks+D issued after it may stay in flight
+            if (ks + D < KST) wait_vmcnt<(D - 1) * LPT>();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
     // ---- per net: bias, LayerNorm, ReLU, 64x64, bias, LayerNorm, ReLU, dot, sigmoid
     float score[NN][2];
@@ -839,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void heads_hx_kernel(HeadHxParams p) {
     if (j == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int st = (blockIdx.x * 4 + wave) * 32 + t * 16 + pos;
+            const int st = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
             if (st >= p.S) continue;
 #pragma unroll
             for (int n = 0; n < NN; ++n) {
