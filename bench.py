@@ -12,15 +12,26 @@ configs[3] "8 GPU, 1M streams, 3 heads"; configs[2] is --streams 65536, configs[
 --streams 4096 --heads hey_jarvis), 3 heads (alexa, hey_mycroft, hey_jarvis), synthetic Gaussian PCM
 (RMS 3000) already resident in HBM, random-init weights of the reference's shapes (no model files exist
 offline).  Streams are sharded by contiguous range over ranks (weak scaling: fixed streams per GPU);
-the only collective is the per-step gather of fp32 scores [S, n_labels] to rank 0 over RCCL.
+the only collective is the gather of fp32 scores [S, n_labels] to rank 0 over RCCL (every step, or every
+--gather-every K steps).
+
+The JSON line carries, next to the contract fields:
+  parity       64 probe streams x 16 frames placed at random ids of the SAME full-size engine, compared with the CPU
+               oracle before the timed region (oracle/parity_sample.py; the timed configuration carries its own parity evidence)
+  roofline     dominant kernel, from hipEvents on the library's stream during the timed steps
+  cpu_baseline the reference's algorithm on the host cores (torch-CPU port), N = 1 only
+  sustained    100 warm-up + 250 timed steps of the same configuration (N = 1 only)
+  fp32_exact   the same workload on the exact-fp32 kernel family (use_mfma = 1), the reference's arithmetic type
+  resident_1m  1,048,576 streams resident in ONE handle on one GPU (run in a child process): ms per step must stay < 80
 
   python bench.py --gpus 1 --steps 50 --warmup 10
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus 8 --steps 50 --warmup 10
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,6 +48,7 @@ PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
 # f16 MFMAs (v_mfma_f32_16x16x32_f16, 16384 flop each) the fp16-split kernels execute per stream-step, channel padding included
 HX_MFMAS = {"stageA": 672, "stageB": 756, "stageC": 990, "stageD": 324, "stageE": 182}
 PEAK_HBM_GBS = 8000.0
+REALTIME_STEPS_PER_S = 12.5  # one 80 ms frame per stream every 80 ms
 
 
 def head_flops(heads) -> int:
@@ -48,16 +60,129 @@ def head_flops(heads) -> int:
 
 
 def pmc_traffic(kernel: str, streams: int, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, produced by
-    tools/pmc.sh on the same workload: FETCH_SIZE x2 + WRITE_SIZE); None when no pass matches this configuration."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, produced by
+    tools/pmc.sh on the same workload; newest round first); None when no pass matches this configuration."""
     if args.valu or args.lds_mfma or streams != 131072:
         return None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        key = kernel + ("_rr" if args.fp32 else "_hx")
-        return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
-    except Exception:
-        return None
+    key = kernel + ("_rr" if args.fp32 else "_hx")
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+        except Exception:
+            continue
+    return None
+
+
+def make_pcm_pool(torch, dev, S, n_pool, kind, gen, rank):
+    """Synthetic PCM int16 [S, 1280] x n_pool resident in HBM (generated in row blocks: S may be a million)."""
+    pool = []
+    if kind == "wav":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "ref_streaming.npz"))
+        wav = torch.from_numpy(np.concatenate([z["pcm/" + k] for k in ("alexa_test", "hey_mycroft_test", "hey_jane")])).to(dev)
+        phase = (torch.arange(S, device=dev, dtype=torch.int64) + rank * S) * 997
+    for i in range(n_pool):
+        buf = torch.empty(S, 1280, device=dev, dtype=torch.int16)
+        for lo in range(0, S, 131072):
+            hi = min(S, lo + 131072)
+            if kind == "noise":
+                buf[lo:hi] = (torch.randn(hi - lo, 1280, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
+            elif kind == "uniform":
+                buf[lo:hi] = torch.randint(-1000, 1000, (hi - lo, 1280), device=dev, generator=gen, dtype=torch.int32).to(torch.int16)
+            else:
+                buf[lo:hi] = wav[((phase[lo:hi, None] + (i * 1280 + torch.arange(1280, device=dev))[None, :]) % wav.numel())]
+        pool.append(buf)
+    return pool
+
+
+def timed_run(torch, dist, eng, pool, scores, steps, warmup, dev, world, gatherer=None, timing=True):
+    """`warmup` untimed + exactly `steps` timed device-resident steps, barrier + synchronize either side; max over ranks.
+    Returns (seconds, kernel_times or None)."""
+    def one(i):
+        eng.step_device(pool[i % len(pool)].data_ptr(), 1, scores.data_ptr())
+        if gatherer is not None:
+            gatherer.gather(scores)                    # RCCL over xGMI: the path's only exchange
+
+    def fence():
+        if gatherer is not None:
+            gatherer.flush()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(warmup):
+        one(i)
+    fence()
+    if timing:
+        eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    fence()
+    dt = time.perf_counter() - t0
+    kt = eng.kernel_times() if timing else None
+    eng.enable_timing(False)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), kt
+
+
+def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank):
+    """The oracle-sampled parity check on the engine that is about to be timed: the 64 probe streams replace random rows
+    of the synthetic batch for 16 frames (oracle/parity_sample.py); max |score - oracle| over the 1,024 (stream, step) pairs."""
+    from oracle import parity_sample as PS
+    S = eng.n_streams
+    ids = PS.probe_stream_ids(S, seed=7 + rank)
+    ids_t = torch.from_numpy(ids).to(dev)
+    pcm = torch.from_numpy(PS.probe_pcm()).to(dev)
+    cols = [list(PS.HEADS3).index(h) for h in head_names]
+    want = torch.from_numpy(ref["scores"][:, :, cols]).to(dev)
+    eng.reset(None, ref["init_features"][-eng.feature_ring:])
+    worst = 0.0
+    finite = True
+    for t in range(PS.N_FRAMES):
+        buf = pool[t % len(pool)].clone()
+        buf[ids_t] = pcm[:, t * 1280:(t + 1) * 1280]
+        eng.step_device(buf.data_ptr(), 1, scores.data_ptr())
+        torch.cuda.synchronize(dev)
+        got = scores[ids_t].double()
+        finite = finite and bool(torch.isfinite(scores).all().item())
+        worst = max(worst, float((got - want[:, t]).abs().max().item()))
+    eng.reset()
+    return {"n_pairs": int(PS.N_PROBE * PS.N_FRAMES), "max_abs_err": worst, "tolerance": 1e-4, "ok": bool(worst <= 1e-4 and finite),
+            "streams_in_batch": S, "checker": "oracle/parity_sample.py: 64 probe streams (fixture WAVs, silence, LSB / full-scale noise, "
+            "square waves, Gaussian RMS 30..12000) at random stream ids of this engine x 16 frames vs OracleModel (numpy fp32)"}
+
+
+def leg_resident_1m(args):
+    """Child-process leg: 1,048,576 streams resident in one handle on one GPU (north star: >= 1 M concurrent streams on a
+    node; this shows the whole million also FITS one GPU and what a step of it costs)."""
+    import torch
+    from openwakeword_amd import weights as W
+    from openwakeword_amd.engine import StreamEngine
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    S = args.streams
+    free0, total = torch.cuda.mem_get_info(dev)
+    heads = {n: W.synthetic_head(n, 1234) for n in args.heads.split(",") if n}
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    eng = StreamEngine(S, heads, W.synthetic_embedding(1234), device=0, use_mfma=3, hip_stream=stream.cuda_stream)
+    eng.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xA11CE)
+    pool = make_pcm_pool(torch, dev, S, 2, "noise", gen, 0)
+    scores = torch.empty(S, eng.n_labels, device=dev, dtype=torch.float32)
+    dt, _ = timed_run(torch, None, eng, pool, scores, args.steps, args.warmup, dev, 1, timing=False)
+    free1, _ = torch.cuda.mem_get_info(dev)
+    ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item())
+    ms = 1e3 * dt / args.steps
+    print(json.dumps({"streams": S, "heads": list(heads), "handles": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(ms, 3), "value": round(S * args.steps / dt, 1), "unit": "frames/s",
+                      "realtime": bool(ms < 80.0), "realtime_budget_ms": 80.0,
+                      "device_memory_used_gb": round((free0 - free1) / 2**30, 2), "device_memory_total_gb": round(total / 2**30, 1),
+                      "scores_valid": ok}))
 
 
 def main():
@@ -76,6 +201,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the cpu_baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle-sampled parity check of the timed engine")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sustained / fp32_exact / resident_1m records")
+    ap.add_argument("--sustained-steps", type=int, default=250)
+    ap.add_argument("--sustained-warmup", type=int, default=100)
+    ap.add_argument("--gather-every", type=int, default=1, help="N > 1: gather scores to rank 0 every K steps (one K-times larger collective)")
+    ap.add_argument("--vad", action="store_true", help="BASELINE configs[4]: the voice-activity stand-in network + gate fused into the step")
+    ap.add_argument("--leg", default="", help="(internal) run one extra record in this process and print its JSON: resident_1m")
     ap.add_argument("--pcm-pool", type=int, default=4, help="distinct PCM buffers cycled through")
     ap.add_argument("--pcm", choices=("noise", "uniform", "wav"), default="noise",
                     help="synthetic input (SURVEY 8d): noise = Gaussian RMS 3000 (default); uniform = the reference tests' "
@@ -87,21 +219,32 @@ def main():
     ap.add_argument("--host-pcm-blocking", action="store_true", help="the same through the blocking oww_step(host, host) call (no overlap)")
     args = ap.parse_args()
 
-    rank0 = int(os.environ.get("RANK", "0")) == 0
+    if args.leg == "resident_1m":
+        return leg_resident_1m(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank0 = rank == 0
+    head_names = [n for n in args.heads.split(",") if n]
     cpu_base = None
     if rank0 and args.gpus == 1 and not args.no_cpu_baseline:
         # forked single-threaded workers: must run before this process touches HIP
         from oracle import cpu_baseline
-        cpu_base = cpu_baseline.run([n for n in args.heads.split(",") if n], budget_s=args.cpu_seconds)
+        cpu_base = cpu_baseline.run(head_names, budget_s=args.cpu_seconds)
+    parity_ref = None
+    family_ok = not (args.valu or args.lds_mfma)
+    want_parity = (not args.no_parity and family_ok and set(head_names) <= {"alexa", "hey_mycroft", "hey_jarvis"}
+                   and not (args.host_pcm or args.host_pcm_blocking))
+    if want_parity and rank0:
+        from oracle import parity_sample as PS
+        parity_ref = PS.oracle_reference()              # computed once by a child interpreter, cached under $TMPDIR
 
     import torch
     import torch.distributed as dist
     from openwakeword_amd import weights as W
     from openwakeword_amd.engine import StreamEngine
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # (testing aid: OWW_BENCH_ONE_GPU=1 puts every rank on device 0 with the gloo backend, to exercise the N > 1 code path on a
@@ -117,88 +260,114 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if want_parity:
+            dist.barrier()                               # rank 0 wrote the cache file before it joined
+            if not rank0:
+                from oracle import parity_sample as PS
+                parity_ref = PS.oracle_reference()
 
     S = args.streams
     emb = W.synthetic_embedding(1234)
-    heads = {n: W.synthetic_head(n, 1234) for n in args.heads.split(",") if n}
+    heads = {n: W.synthetic_head(n, 1234) for n in head_names}
     # one side stream carries the engine's kernels AND the RCCL gather, so they are ordered without host syncs
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=(0 if args.valu else 2 if args.lds_mfma else 1 if args.fp32 else 3), hip_stream=stream.cuda_stream)
+    family = 0 if args.valu else 2 if args.lds_mfma else 1 if args.fp32 else 3
+    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=family, hip_stream=stream.cuda_stream)
     NL = eng.n_labels
     eng.reset()
+    if args.vad:
+        eng.enable_vad(W.synthetic_vad(1234), threshold=0.5)
     if args.graph:
         eng.use_graph(True)
 
-    # synthetic PCM resident in HBM: Gaussian, RMS 3000, a different seed per rank (independent streams)
+    # synthetic PCM resident in HBM: a different seed per rank (independent streams)
     gen = torch.Generator(device=dev)
     gen.manual_seed(0xA11CE + rank)
-    n_pool = max(1, args.pcm_pool)
-    if args.pcm == "noise":
-        pool = [(torch.randn(S, 1280, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
-                for _ in range(n_pool)]
-    elif args.pcm == "uniform":
-        pool = [torch.randint(-1000, 1000, (S, 1280), device=dev, generator=gen, dtype=torch.int32).to(torch.int16) for _ in range(n_pool)]
-    else:
-        import numpy as np
-        z = np.load(os.path.join(ROOT, "tests", "golden", "ref_streaming.npz"))
-        wav = torch.from_numpy(np.concatenate([z["pcm/" + k] for k in ("alexa_test", "hey_mycroft_test", "hey_jane")])).to(dev)
-        phase = (torch.arange(S, device=dev, dtype=torch.int64) + rank * S) * 997
-        pool = [wav[((phase[:, None] + (i * 1280 + torch.arange(1280, device=dev))[None, :]) % wav.numel())].contiguous()
-                for i in range(n_pool)]
+    pool = make_pcm_pool(torch, dev, S, max(1, args.pcm_pool), args.pcm, gen, rank)
     scores = torch.empty(S, NL, device=dev, dtype=torch.float32)
     from openwakeword_amd.shard import ScoreGather
-    gatherer = ScoreGather(S * world, NL, dev) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
+    gatherer = ScoreGather(S * world, NL, dev, every=args.gather_every) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
+
+    parity = None
+    if parity_ref is not None:
+        parity = parity_check(torch, eng, pool, scores, dev, head_names, parity_ref, rank)
+        if world > 1:
+            t = torch.tensor([parity["max_abs_err"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            parity["max_abs_err"] = float(t.item())
+            parity["n_pairs"] *= world
+            parity["ok"] = bool(parity["max_abs_err"] <= parity["tolerance"])
 
     host = args.host_pcm or args.host_pcm_blocking
+    timing = not args.no_kernel_timing and not args.graph
     if host:
         host_pool = [torch.empty(S, 1280, dtype=torch.int16, pin_memory=True).copy_(t).numpy() for t in pool]
         host_scores = torch.empty(S, NL, dtype=torch.float32, pin_memory=True).numpy()
-    inflight = [0]
+        inflight = [0]
 
-    def one_step(i):
-        if args.host_pcm_blocking:
-            eng.step(host_pool[i % len(host_pool)], out=host_scores)     # H2D + kernels + D2H, blocking
-            return
-        if args.host_pcm:
-            eng.submit(host_pool[i % len(host_pool)])                    # step i's upload overlaps step i-1's kernels
+        def one_step(i):
+            if args.host_pcm_blocking:
+                eng.step(host_pool[i % len(host_pool)], out=host_scores)     # H2D + kernels + D2H, blocking
+                return
+            eng.submit(host_pool[i % len(host_pool)])                        # step i's upload overlaps step i-1's kernels
             inflight[0] += 1
             if inflight[0] == 2:
                 eng.collect(host_scores)
                 inflight[0] -= 1
-            return
-        eng.step_device(pool[i % len(pool)].data_ptr(), 1, scores.data_ptr())
-        if world > 1:
-            gatherer.gather(scores)                    # RCCL over xGMI: the path's only exchange
 
-    def fence():
-        while inflight[0]:
-            eng.collect(host_scores)
-            inflight[0] -= 1
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def fence():
+            while inflight[0]:
+                eng.collect(host_scores)
+                inflight[0] -= 1
+            torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    if not args.no_kernel_timing and not args.graph:
-        eng.enable_timing(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    ktimes = eng.kernel_times() if (not args.no_kernel_timing and not args.graph) else None
-    eng.enable_timing(False)
-
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
-    if host:
+        for i in range(args.warmup):
+            one_step(i)
+        fence()
+        if timing:
+            eng.enable_timing(True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i)
+        fence()
+        dt_max = time.perf_counter() - t0
+        ktimes = eng.kernel_times() if timing else None
+        eng.enable_timing(False)
         scores = torch.from_numpy(host_scores).to(dev)
+    else:
+        dt_max, ktimes = timed_run(torch, dist, eng, pool, scores, args.steps, args.warmup, dev, world, gatherer, timing)
     ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item())
+    range_flag = eng.range_status() if family == 3 else False
+
+    extras = {}
+    if rank0 and world == 1 and not args.no_extras and not host:
+        # ---- sustained: the same configuration for 100 warm-up + 250 timed steps (the part is power-limited: a 20-step burst reads low)
+        dt_s, _ = timed_run(torch, dist, eng, pool, scores, args.sustained_steps, args.sustained_warmup, dev, 1, None, timing=False)
+        extras["sustained"] = {"steps": args.sustained_steps, "warmup": args.sustained_warmup,
+                               "ms_per_step": round(1e3 * dt_s / args.sustained_steps, 4),
+                               "value": round(S * args.sustained_steps / dt_s, 1), "unit": "frames/s"}
+        # ---- fp32_exact: the reference's own arithmetic type (exact fp32 MFMA family), same workload
+        if family == 3:
+            eng.close()
+            eng32 = StreamEngine(S, heads, emb, device=local_rank, use_mfma=1, hip_stream=stream.cuda_stream)
+            eng32.reset()
+            dt_f, _ = timed_run(torch, dist, eng32, pool, scores, 20, 5, dev, 1, None, timing=False)
+            extras["fp32_exact"] = {"kernels": "mfma_rr_fp32", "steps": 20, "warmup": 5, "ms_per_step": round(1e3 * dt_f / 20, 4),
+                                    "value": round(S * 20 / dt_f, 1), "unit": "frames/s", "dtype": "f32"}
+            eng32.close()
+            eng = None
+        # ---- resident_1m: a million streams in ONE handle on this GPU, in a child process (own 73 GB of state)
+        del pool
+        torch.cuda.empty_cache()
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--leg", "resident_1m", "--streams", str(1 << 20), "--heads", args.heads,
+                   "--steps", "10", "--warmup", "3"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            extras["resident_1m"] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:                      # never let an extra record take the headline down
+            extras["resident_1m"] = {"error": repr(e)[:400]}
 
     if rank == 0:
         total_frames = S * world * args.steps
@@ -207,28 +376,35 @@ def main():
             "metric": "real-time audio frames/sec (80 ms frame, 3 wakewords), whole job; real-time streams = value/12.5",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("f32" if (args.fp32 or args.valu or args.lds_mfma) else "f32 as 3xf16 split MFMA, fp32 accumulate"), "data": "synthetic" if args.pcm != "wav" else "synthetic (reference fixture clips tiled)",
+            "vs_baseline": None, "dtype": ("f32" if family != 3 else "f32 as 3xf16 split MFMA, fp32 accumulate"), "data": "synthetic" if args.pcm != "wav" else "synthetic (reference fixture clips tiled)",
             "config": {"workload": f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), "
                                    "80 ms frames, BASELINE configs[3] per-GPU shard" if S == 131072 else
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
-                       "collective": "RCCL gather of scores per step" if world > 1 else "none",
+                       "collective": (f"RCCL gather of scores every {args.gather_every} step(s)" if not one_gpu else
+                                      f"gloo gather every {args.gather_every} step(s) (OWW_BENCH_ONE_GPU testing aid: all ranks on device 0)") if world > 1 else "none",
                        "pcm_distribution": {"noise": "Gaussian, RMS 3000", "uniform": "randint(-1000, 1000)", "wav": "fixture WAVs tiled, phase 997*s"}[args.pcm],
                        "pcm": ("pinned host buffers, PCIe-inclusive, " + ("blocking oww_step" if args.host_pcm_blocking else "pipelined oww_submit/oww_collect") +
                                " (not the headline configuration)") if host else "resident in HBM",
-                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_rr_fp32" if args.fp32 else "mfma_rr_f16x3")), "graph": bool(args.graph), "weights": "synthetic seed 1234"},
-            "realtime_streams": round(value / 12.5, 1),
+                       "kernels": "valu" if args.valu else ("mfma_lds" if args.lds_mfma else ("mfma_rr_fp32" if args.fp32 else "mfma_rr_f16x3")), "graph": bool(args.graph),
+                       "vad": "stand-in network + gate fused into the step" if args.vad else "off", "weights": "synthetic seed 1234"},
+            "realtime_streams_extrapolated": round(value / REALTIME_STEPS_PER_S, 1),
+            "realtime_streams_note": f"value / 12.5, extrapolated from the measured batch of {S * world} streams; see resident_1m for a resident million",
             "frames_per_sec_per_gpu": round(value / world, 1),
-            "scores_valid": ok,
+            "scores_valid": ok, "f16_range_flag": bool(range_flag),
+            "parity": parity,
         }
         if ktimes:
             per = {k: (v["ms"] / max(v["launches"], 1)) for k, v in ktimes.items()}
             out["kernel_ms"] = {k: round(v, 4) for k, v in per.items()}
+            out["launches_per_step"] = int(round(sum(v["launches"] for v in ktimes.values()) / max(args.steps, 1)))
             dom = max(STAGE_FLOPS, key=lambda k: per[k])
-            f16 = not (args.fp32 or args.valu or args.lds_mfma)
+            f16 = family == 3
             peak = PEAK_F16_TFLOPS if f16 else PEAK_FP32_TFLOPS
 
             def stage_roof(k):
+                if per[k] <= 0:
+                    return None
                 tf = STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12           # algorithmic (fp32-equivalent) flops only
                 r = {"achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / peak, 4)}
                 if f16:
@@ -247,17 +423,20 @@ def main():
                                            "algorithmic fp32 flops once, against the dense f16 MFMA peak; the scheme's own ceiling is peak/3")
             cnn_ms = sum(per[k] for k in STAGE_FLOPS)
             cnn_tf = sum(STAGE_FLOPS.values()) * S / (cnn_ms * 1e-3) / 1e12
-            hf = head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12
+            hf = head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12 if per["heads"] > 0 else 0.0
+            mel_ms = per["mel"] if per["mel"] > 0 else None               # fused into stage A when the mel class has no launches
             out["roofline_all"] = {
                 "cnn_all_stages": {"achieved": round(cnn_tf, 2), "unit": "TFLOP/s", "frac": round(cnn_tf / peak, 4),
                                    "x_fp32_mfma_peak": round(cnn_tf / PEAK_FP32_TFLOPS, 3)},
                 **{k: stage_roof(k) for k in STAGE_FLOPS},
                 "heads": {"achieved": round(hf, 2), "unit": "TFLOP/s", "frac": round(hf / peak, 4)},
-                "mel": {"bound": "hbm", "achieved": round(MEL_BYTES * S / (per["mel"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(MEL_BYTES * S / (per["mel"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                "mel": ({"bound": "hbm", "achieved": round(MEL_BYTES * S / (mel_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(MEL_BYTES * S / (mel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} if mel_ms else
+                        {"fused_into": "stageA", "note": "mel rows never reach HBM (BASELINE configs[2] 'mel+embedding fused')"}),
             }
         else:
             out["roofline"] = None
+        out.update(extras)
         out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if world > 1:

@@ -26,13 +26,14 @@
 extern "C" {
 #endif
 
-#define OWW_ABI_VERSION 1
+#define OWW_ABI_VERSION 2
 
 #define OWW_OK            0
 #define OWW_EINVAL       -1   /* bad argument */
 #define OWW_EHIP         -2   /* HIP runtime error */
 #define OWW_ESTATE       -3   /* call out of order (e.g. step before weights committed) */
 #define OWW_ENOMEM       -4
+#define OWW_ERANGE       -5   /* fp16-split kernels (use_mfma = 3): an activation left the f16 range; sticky, see oww_range_status */
 
 #define OWW_CHUNK        1280 /* samples per 80 ms step          (utils.py:417-434) */
 #define OWW_MEL_BINS       32 /* melspectrogram.onnx output bins (utils.py:271)     */
@@ -110,6 +111,15 @@ int  oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device);
 int  oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks,
               float* scores, int scores_on_device);
 int  oww_sync(oww_ctx* h);
+/* Range guard of the default kernel family (use_mfma = 3 evaluates every fp32 product as three f16 MFMAs on hi/lo-split
+ * operands, so an activation with |x| >= 65520 cannot be represented).  The reference's fp32 graphs have no such limit
+ * (onnxruntime CPU kernels, utils.py:84-93), so instead of scoring silently differently the kernels test one accumulator
+ * per position tile and layer for the NaN such an operand produces and raise a sticky per-handle flag.  Once raised,
+ * oww_step / oww_submit / oww_collect / oww_sync / oww_embed* return OWW_ERANGE (a step issued with device-resident
+ * scores is asynchronous: the error surfaces on the next call that looks).  oww_range_status waits for the handle's
+ * stream and returns OWW_OK or OWW_ERANGE; clear != 0 lowers the flag (after e.g. resetting the offending streams).
+ * The exact-fp32 family (use_mfma = 1) never raises it. */
+int  oww_range_status(oww_ctx* h, int clear);
 
 /* ---- host-fed pipeline: the same step with PCM arriving in host memory every 80 ms (the serving edge of
  *      examples/web/streaming_server.py:32-70 and detect_from_microphone.py: audio is produced on the host) ----------
@@ -134,8 +144,8 @@ int  oww_get_raw(oww_ctx* h, float* out);
  * oww_mel: int16 [B][n] -> dB values [B][F][32], F=(n-512)/160+1, clamp floor shared over the call
  *          exactly like melspec_model_predict (utils.py:87,202).  Requires B <= n_streams.
  * oww_embed: mel rows [B][rows][32] (rows = 76 + 8*(n_out-1)) -> embeddings [B][n_out][96]; the
- *          windows are rows[8i : 8i+76] (utils.py:229-236).  Runs the same incremental kernels on
- *          scratch state and CLOBBERS the streaming state of streams [0,B): reset afterwards.
+ *          windows are rows[8i : 8i+76] (utils.py:229-236).  Runs the same incremental kernels; the
+ *          streaming state of the streams it borrows is parked and put back, so live streams are unaffected.
  * oww_head: features [B][T][96] -> raw outputs [B][n_out] of head `head` (model.py:137-138). */
 int  oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db);
 /* the same with one clamp floor PER CLIP: what the reference's CPU path computes when it maps _get_melspectrogram over
@@ -147,8 +157,8 @@ int  oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float
  * mel frames per clip.  Everything stays on the device: per-clip mel (one clamp floor per clip, x/10+2), then the
  * incremental CNN walks each clip in steps of 8 mel rows (4 lead-in rows + 9 warm-up steps, then one embedding per
  * step) -- 7.5x fewer flops than evaluating every 76-row window on its own, same results.  `pcm` / `out` are host
- * pointers unless the matching *_on_device flag is set.  Requires B <= n_streams, F >= 76; CLOBBERS the streaming
- * state of streams [0,B) like oww_embed. */
+ * pointers unless the matching *_on_device flag is set.  Requires B <= n_streams, F >= 76; like oww_embed it borrows the
+ * streaming machinery of streams [0,B) and restores their state before returning. */
 int  oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32_t B, int32_t n,
                      float* out, int32_t out_on_device);
 int  oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out);
@@ -156,7 +166,7 @@ int  oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float*
 /* ---- introspection ------------------------------------------------------------------------------ */
 /* AudioFeatures.get_features (utils.py:454-460): last T rows of stream sid's feature ring, oldest first */
 int  oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out);
-/* newest 8*n_chunks transformed mel rows (x/10+2) of stream sid from the last step */
+/* newest n_rows (<= 8*n_chunks of the last step) transformed mel rows (x/10+2) of stream sid from the last step */
 int  oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows);
 /* per-layer CNN outputs (new rows only, dense [rows][F][C]) of stream sid from the last chunk processed;
  * layer 0..19; needs cfg.debug_layers.  Returns the number of floats written. */

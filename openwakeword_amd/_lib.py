@@ -8,6 +8,8 @@ import os
 from . import _build
 
 _lib = None
+ABI_VERSION = 2          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
+ERANGE = -5
 
 
 class OwwError(RuntimeError):
@@ -36,6 +38,7 @@ SYMBOLS = {
     "oww_set_postproc": (C.c_int, [_P, _P, _P, C.c_int32]),
     "oww_step": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P, C.c_int]),
     "oww_sync": (C.c_int, [_P]),
+    "oww_range_status": (C.c_int, [_P, C.c_int]),
     "oww_submit": (C.c_int, [_P, _P, C.c_int32]),
     "oww_collect": (C.c_int, [_P, _P]),
     "oww_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
@@ -77,13 +80,19 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.oww_abi_version() != 1:
+    if lib.oww_abi_version() != ABI_VERSION:
         raise OwwError("libowwhip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
+class OwwRangeError(OwwError):
+    """OWW_ERANGE: an activation left the f16 range of the fp16-split kernels (sticky per handle)."""
+
+
 def check(rc: int) -> int:
+    if rc == ERANGE:
+        raise OwwRangeError(f"libowwhip error {rc}: {load().oww_last_error().decode(errors='replace')}")
     if rc < 0:
         raise OwwError(f"libowwhip error {rc}: {load().oww_last_error().decode(errors='replace')}")
     return rc

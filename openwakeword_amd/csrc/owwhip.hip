@@ -257,6 +257,10 @@ struct oww_ctx {
     uint32_t *d_nfeat = nullptr, *d_npred = nullptr;
     float* d_vadring = nullptr; uint32_t* d_nvad = nullptr; float* d_vadin = nullptr; float vad_threshold = 0.f;   // VAD gate (oww_push_vad)
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
+    int* h_range = nullptr;          // sticky f16-range flag: one page-locked, device-mapped word the f16-split kernels raise
+    int* d_range = nullptr;          // the same word as the kernels address it
+    int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
+    float* d_save = nullptr; size_t save_floats = 0;      // streaming state parked by oww_embed / oww_embed_clips
     int* d_ids = nullptr;
     int ids_cap = 0;
     int *d_patience = nullptr;
@@ -384,6 +388,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
         p.xout = h->d_xA; p.n_streams = n_active; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+        p.range_flag = HX ? h->d_range : nullptr;
         const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
         Timed t(h, 1);
         if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 256 * OWH_WPS_A)), dim3(256), 0, st, p);
@@ -397,6 +402,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         }
         p.n_groups = (n_active + spt - 1) / spt; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+        p.range_flag = HX ? h->d_range : nullptr;
     };
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
@@ -467,6 +473,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 owh::HeadHxParams q{};
                 q.feat = base.feat; q.ext = base.ext; q.TR = base.TR; q.T = g.T; q.nfeat = base.nfeat; q.w1hx = g.d_w1hx;
                 q.raw = raw_out; q.NL = h->NL; q.S = n_active; q.accumulate_max = base.accumulate_max;
+                q.range_flag = h->d_range;
                 for (int i = 0; i < g.n_nets; ++i) {
                     const NetHost& n = h->nets[g.nets[i]];
                     const NetDesc d = h->host_descs[g.nets[i]];
@@ -556,7 +563,9 @@ void free_all(oww_ctx* h) {
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
     fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin);
-    fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold);
+    fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
+    h->save_floats = 0;
+    if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
     for (auto& sl : h->slot) {
         fr(sl.d_pcm); fr(sl.d_scores);
         if (sl.h_scores) { (void)hipHostFree(sl.h_scores); sl.h_scores = nullptr; }
@@ -593,6 +602,39 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
         hipLaunchKernelGGL(postproc_kernel, dim3((h->Spad + 127) / 128), dim3(128), 0, h->stream, pp);
     }
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// sticky out-of-range flag of the f16-split kernels (owwhip_hx.h nan_guard): read straight from the mapped host word
+int range_check(oww_ctx* h, const char* where) {
+    if (h->h_range && *(volatile int*)h->h_range)
+        return fail(OWW_ERANGE, "%s: an activation left the f16 range of the fp16-split kernels (use_mfma = 3) -- scores since then are not "
+                    "trustworthy; create the handle with use_mfma = 1 (exact fp32) for these weights, or clear with oww_range_status(h, 1)", where);
+    return 0;
+}
+
+// oww_embed / oww_embed_clips borrow the streaming machinery of the first streams: their state (conv histories, feature ring
+// rows, frame counters) is parked in a scratch buffer for the duration of the call and put back afterwards
+int park_state(oww_ctx* h, int n_streams, bool save) {
+    const size_t n8 = std::min<size_t>(h->Spad, ((size_t)n_streams + 7) / 8 * 8);
+    size_t need = h->Spad + n8 * (size_t)h->TR * 96;
+    for (int a = 0; a < N_STATE; ++a) need += n8 * (size_t)h->state_len[a];
+    if (save && need > h->save_floats) {
+        if (h->d_save) (void)hipFree(h->d_save);
+        h->d_save = nullptr; h->save_floats = 0;
+        if (hipMalloc(&h->d_save, need * sizeof(float)) != hipSuccess) return fail(OWW_ENOMEM, "out of device memory for %zu parked state bytes", need * sizeof(float));
+        h->save_floats = need;
+    }
+    if (!h->d_save || need > h->save_floats) return fail(OWW_ESTATE, "park_state: nothing parked");
+    float* q = h->d_save;
+    auto cp = [&](void* live, size_t nfl) -> int {
+        HIPCHK(hipMemcpyAsync(save ? (void*)q : live, save ? live : (void*)q, nfl * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        q += nfl;
+        return 0;
+    };
+    for (int a = 0; a < N_STATE; ++a) if (int rc = cp(h->d_state[a], n8 * (size_t)h->state_len[a])) return rc;
+    if (int rc = cp(h->d_feat, n8 * (size_t)h->TR * 96)) return rc;
+    if (int rc = cp(h->d_nfeat, h->Spad)) return rc;         // the frame counters of EVERY stream advance with the borrowed steps
     return 0;
 }
 
@@ -856,6 +898,14 @@ int oww_commit(oww_ctx* h) {
         if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
     }
 
+    // ---- sticky range flag of the f16-split kernels: page-locked + device-mapped, so the host reads it without a copy ----
+    {
+        void* dp = nullptr;
+        HIPCHK(hipHostMalloc((void**)&h->h_range, 64, hipHostMallocMapped));
+        *h->h_range = 0;
+        HIPCHK(hipHostGetDevicePointer(&dp, h->h_range, 0));
+        h->d_range = (int*)dp;
+    }
     // ---- state ----
     const size_t SP = h->Spad;
     for (int a = 0; a < N_STATE; ++a) {
@@ -922,6 +972,8 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(hipMemsetAsync(h->d_emb, 0, SP * 96 * sizeof(float), h->stream));
         if (int rc = do_reset(h, nullptr, (int)SP, nullptr)) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
+        // the warm-up already drove the network with an all-ones mel history: weights that overflow the f16 range there are refused now
+        if (int rc = range_check(h, "oww_commit")) return rc;
     }
     h->committed = true;
     return OWW_OK;
@@ -973,7 +1025,9 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step: handle not committed");
     if (!pcm) return fail(OWW_EINVAL, "oww_step: pcm is null");
     if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_step: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
+    if (int rc = range_check(h, "oww_step")) return rc;          // raised by an earlier (asynchronous) step: sticky
     HIPCHK(hipSetDevice(h->cfg.device));
+    h->k_last = n_chunks;
     const size_t n_pcm = (size_t)h->S * OWW_CHUNK * n_chunks;
     const bool graphable = h->want_graph && n_chunks == 1 && !h->timing;
     const int16_t* d_pcm = pcm;
@@ -1000,7 +1054,10 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
     if (scores) {
         const size_t nb = (size_t)h->S * h->NL * sizeof(float);
         if (nb) HIPCHK(hipMemcpyAsync(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
-        if (!scores_on_device) HIPCHK(hipStreamSynchronize(h->stream));
+        if (!scores_on_device) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (int rc = range_check(h, "oww_step")) return rc;
+        }
     }
     return OWW_OK;
 }
@@ -1025,7 +1082,9 @@ int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_submit: handle not committed");
     if (!pcm) return fail(OWW_EINVAL, "oww_submit: pcm is null");
     if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_submit: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
+    if (int rc = range_check(h, "oww_submit")) return rc;
     HIPCHK(hipSetDevice(h->cfg.device));
+    h->k_last = n_chunks;
     if (int rc = ensure_ingest(h)) return rc;
     auto& sl = h->slot[h->n_submit & 1];
     if (sl.busy) return fail(OWW_ESTATE, "oww_submit: two steps already in flight, call oww_collect first");
@@ -1054,6 +1113,7 @@ int oww_collect(oww_ctx* h, float* scores) {
     if (scores) memcpy(scores, sl.h_scores, (size_t)h->S * h->NL * sizeof(float));
     sl.busy = false;
     ++h->n_collect;
+    if (int rc = range_check(h, "oww_collect")) return rc;      // the step is consumed; its scores are suspect
     return OWW_OK;
 }
 
@@ -1095,7 +1155,16 @@ int oww_sync(oww_ctx* h) {
     if (!h) return fail(OWW_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return OWW_OK;
+    return range_check(h, "oww_sync");
+}
+
+int oww_range_status(oww_ctx* h, int clear) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_range_status: handle not committed");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int rc = range_check(h, "oww_range_status");
+    if (clear && h->h_range) *(volatile int*)h->h_range = 0;
+    return rc;
 }
 
 const float* oww_scores_dev(const oww_ctx* h) { return h ? h->d_scores : nullptr; }
@@ -1116,11 +1185,10 @@ static int mel_impl(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float*
     HIPCHK(hipSetDevice(h->cfg.device));
     const int F = (n - 512) / 160 + 1;
     int16_t* d_in = nullptr; float* d_out = nullptr; float* d_max = nullptr;
-    HIPCHK(hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)));
-    HIPCHK(hipMalloc(&d_out, (size_t)B * F * 32 * sizeof(float)));
-    HIPCHK(hipMalloc(&d_max, (size_t)B * sizeof(float)));
     int rc = 0;
     do {
+        if (hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess || hipMalloc(&d_out, (size_t)B * F * 32 * sizeof(float)) != hipSuccess ||
+            hipMalloc(&d_max, (size_t)B * sizeof(float)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_mel: out of device memory"); break; }
         if (hipMemcpyAsync(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: H2D failed"); break; }
         if ((rc = launch_mel(h, d_in, B, n, F, 0, d_out, d_max))) break;
         const size_t tot = (size_t)B * F * 32;
@@ -1151,7 +1219,9 @@ int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float*
     const int n_out = (rows - 76) / 8 + 1;
     const int n_steps = (rows + 4) / 8;                 // 4 lead-in rows + rows, 8 per step
     std::vector<float> slab((size_t)B * 256), emb((size_t)B * 96);
-    for (int it = 0; it < n_steps; ++it) {
+    if (int rc = park_state(h, B, true)) return rc;
+    int rc_all = 0;
+    for (int it = 0; it < n_steps && !rc_all; ++it) {
         for (int b = 0; b < B; ++b)
             for (int r = 0; r < 8; ++r) {
                 const int src = it * 8 + r - 4;
@@ -1159,18 +1229,19 @@ int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float*
                 if (src < 0) memset(d, 0, 32 * sizeof(float));
                 else memcpy(d, mel_rows + ((size_t)b * rows + src) * 32, 32 * sizeof(float));
             }
-        HIPCHK(hipMemcpyAsync(h->d_mel, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        if (int rc = run_cnn(h, B, 256, 0)) return rc;
+        if (hipMemcpyAsync(h->d_mel, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: H2D failed"); break; }
+        if ((rc_all = run_cnn(h, B, 256, 0))) break;
         hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
-        if (it >= 9) {
-            HIPCHK(hipMemcpyAsync(emb.data(), h->d_emb, emb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+        if (it >= 9 && hipMemcpyAsync(emb.data(), h->d_emb, emb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: D2H failed"); break; }
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: device error"); break; }   // slab is reused next iteration
+        if (it >= 9)
             for (int b = 0; b < B; ++b) memcpy(out + ((size_t)b * n_out + (it - 9)) * 96, &emb[(size_t)b * 96], 96 * sizeof(float));
-        } else {
-            HIPCHK(hipStreamSynchronize(h->stream));  // slab is reused next iteration
-        }
     }
-    return OWW_OK;
+    const int rc_restore = park_state(h, B, false);
+    (void)hipStreamSynchronize(h->stream);
+    if (rc_all) return rc_all;
+    if (rc_restore) return rc_restore;
+    return range_check(h, "oww_embed");
 }
 
 int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32_t B, int32_t n, float* out, int32_t out_on_device) {
@@ -1186,7 +1257,8 @@ int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32
     const size_t lead = 4 * 32;                         // four lead-in rows in front of clip 0 (other clips: the previous clip's tail;
                                                         // their content never reaches a returned embedding)
     int16_t* d_in = nullptr; float* d_mel = nullptr; float* d_max = nullptr; float* d_out = nullptr;
-    int rc = 0;
+    int rc = park_state(h, B, true);
+    if (rc) return rc;
     do {
         if (!pcm_on_device) {
             if (hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
@@ -1215,8 +1287,11 @@ int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32
         if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: device error: %s", hipGetErrorString(hipGetLastError())); break; }
     } while (0);
     h->mel_src = nullptr;
+    const int rc_restore = park_state(h, B, false);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(d_in); (void)hipFree(d_mel); (void)hipFree(d_max); (void)hipFree(d_out);
+    if (!rc) rc = rc_restore;
+    if (!rc) rc = range_check(h, "oww_embed_clips");
     return rc;
 }
 
@@ -1227,10 +1302,11 @@ int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* 
     const HeadHost& hh = h->heads[head];
     const size_t nf = (size_t)B * hh.T * 96;
     float* d_f = nullptr; float* d_raw = nullptr;
-    HIPCHK(hipMalloc(&d_f, nf * sizeof(float)));
-    HIPCHK(hipMalloc(&d_raw, (size_t)B * h->NL * sizeof(float)));
     int rc = 0;
     do {
+        if (hipMalloc(&d_f, nf * sizeof(float)) != hipSuccess || hipMalloc(&d_raw, (size_t)B * h->NL * sizeof(float)) != hipSuccess) {
+            rc = fail(OWW_ENOMEM, "oww_head: out of device memory"); break;
+        }
         if (hipMemcpyAsync(d_f, features, nf * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: H2D failed"); break; }
         if (hipMemsetAsync(d_raw, 0, (size_t)B * h->NL * sizeof(float), h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: memset failed"); break; }
         if ((rc = run_heads(h, B, false, d_f, head, d_raw, 0))) break;
@@ -1239,6 +1315,7 @@ int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* 
             hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: D2H failed"); break; }
         for (int b = 0; b < B; ++b)
             for (int o = 0; o < hh.n_out; ++o) out[(size_t)b * hh.n_out + o] = raw[(size_t)b * h->NL + hh.out_col + o];
+        rc = range_check(h, "oww_head");
     } while (0);
     (void)hipFree(d_f); (void)hipFree(d_raw);
     return rc;
@@ -1263,9 +1340,11 @@ int oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out) {
 
 int oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_mel: handle not committed");
-    if (sid < 0 || sid >= h->S || !out || n_rows < 1 || n_rows > 8 * h->kmax) return fail(OWW_EINVAL, "oww_get_mel: bad argument");
+    const int rows_last = 8 * h->k_last;           // the last step wrote [S][8 * n_chunks][32]
+    if (sid < 0 || sid >= h->S || !out || n_rows < 1 || n_rows > rows_last)
+        return fail(OWW_EINVAL, "oww_get_mel: bad argument (sid=%d n_rows=%d; the last step produced %d rows per stream)", sid, n_rows, rows_last);
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpyAsync(out, h->d_mel + (size_t)sid * n_rows * 32, (size_t)n_rows * 32 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->d_mel + ((size_t)sid * rows_last + (rows_last - n_rows)) * 32, (size_t)n_rows * 32 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
 }

@@ -62,6 +62,23 @@ __device__ __forceinline__ f32x4 bn_act(const f32x4 v, const float* __restrict__
 // operand pair (hi, lo) of one k-step of one position tile
 struct Op { f16x8 h, l; };
 
+// Range guard of the f16 split.  An activation beyond the f16 range (|x| >= 65520) splits into hi = inf, lo = -inf (or NaN);
+// in the layer that consumes it every product with it is +-inf or NaN (0 * inf included) and hi + lo contributions cancel to
+// NaN, so EVERY output channel of that position has a NaN accumulator -- which the max()-based activation would then swallow
+// (max3(NaN, NaN, -0.4) = -0.4): a silently wrong answer.  Testing ONE accumulator register per position tile and layer
+// before the activation therefore catches the first overflow anywhere upstream; the lane masks are OR-ed in SGPRs
+// (v_cmp_u_f32 + s_or_b64 per tile) and the wave raises the handle's sticky flag (host-mapped word) at kernel end.
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ void nan_guard(lanemask_t& bad, float x) {
+#ifndef OWH_NO_RANGE_GUARD
+    // (inline asm: with the fcmp builtin the compiler keeps every tile's lane mask alive and ORs them at the end -- +50 SGPRs)
+    asm("v_cmp_u_f32 vcc, %1, %1\n\ts_or_b64 %0, %0, vcc" : "+s"(bad) : "v"(x) : "vcc");
+#endif
+}
+__device__ __forceinline__ void raise_range_flag(lanemask_t bad, int* flag) {
+    if (bad != 0 && flag != nullptr && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
 #ifndef OWH_MIXSPLIT
 #define OWH_MIXSPLIT 1     // residual halves by v_fma_mix{lo,hi}_f16 (f16 source read in place): 1.5 instead of 2.6 VALU ops per value
 #endif
@@ -174,7 +191,8 @@ using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG>
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
-                                            const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
+                                            const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
+                                            lanemask_t& bad) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
     // stream-boundary masks as 0/1 values (used as select conditions, or as multipliers with OWH_MASKSEL=0)
@@ -230,6 +248,12 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 }
             }
         }
+#ifndef OWH_EXP_NOGUARD_MEL
+        if (oct == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) nan_guard(bad, res[t][0]);
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
         OWH_OCT_SB();
@@ -247,10 +271,11 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #ifndef OWH_PIPE_VALU
 #define OWH_PIPE_VALU 2
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
-                                             const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane) {
+                                             const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane,
+                                             lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = 3 * KSI * 2;
@@ -283,6 +308,14 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
                 }
         }
         if (oct > 0) {                                       // epilogue of the previous tile
+#ifdef OWH_EXP_NOGUARD_TIME
+            if (false) {
+#else
+            if (GUARD && oct == 1) {
+#endif
+#pragma unroll
+                for (int r = 0; r < NR; ++r) nan_guard(bad, prev[r][0]);
+            }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 if (BN) out[r][oct - 1] = bn_act<true>(prev[r], scale, shift, oct - 1, j);
@@ -326,6 +359,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
+    lanemask_t bad = 0;
     issue_chunk<NBA, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
@@ -349,7 +383,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if (pass == 0) chunk_sync();
 
     // conv a: 1x3, CIN -> C
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NB, WG>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NB, WG>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
@@ -370,7 +404,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NB, WG>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane);
+    conv_time_hx<KS, NCT, R, true, NCT, NB, WG>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
@@ -379,7 +413,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB, WG>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB, WG>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
@@ -399,7 +433,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
@@ -456,7 +490,8 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         Op Po[1][KS];
         to_ops<NCT>(Pl, Po[0]);
         f32x4 E[1][NCT];
-        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane);
+        // (no guard here: an out-of-range input of conv19 yields a NaN embedding, which the heads kernel's guard reports)
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane, bad);
         if (active) {
             store_tile<NCT>(T1, h19, lane);
             store_tile<NCT>(Pl, h19 + NCT * 4 * 64, lane);
@@ -474,6 +509,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     }
     }   // pass
     if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the chunk the last pass prefetched
+    raise_range_flag(bad, p.range_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,6 +544,7 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
     int goff[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int k = min(8 * j + q, 8); goff[q] = (k / 3) * 34 + (k % 3) + pos; }
+    lanemask_t bad = 0;
 
     for (int s = gw; s < p.n_streams; s += nw) {
         int z = 0;
@@ -595,6 +632,7 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
                         r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
                         r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
                     }
+                    if (oct == 0) { nan_guard(bad, r0[0]); nan_guard(bad, r1[0]); }
                     Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
                     Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
                     pin(Y1[t0][oct]); pin(Y1[t1][oct]);
@@ -627,6 +665,10 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
                             const Op& b = src < 2 ? Yh[src][h][0] : Y1o[(src - 2) * 2 + h][0];
                             acc[t] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[t]);
                         }
+                }
+                if (oct == 0) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j); pin(Y2[t][oct]); }
@@ -670,6 +712,7 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
             for (int h = 0; h < 2; ++h) store_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
         hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
     }
+    raise_range_flag(bad, p.range_flag);
 }
 
 
@@ -695,6 +738,7 @@ struct HeadHxParams {
     HeadHxNet net[4];
     float* raw;             // [S][NL]
     int NL, S, accumulate_max;
+    int* range_flag;        // sticky f16-range flag of the handle (see nan_guard)
 };
 
 __device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
@@ -829,6 +873,9 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
             __syncthreads();
         }
     }
+    lanemask_t bad = 0;
+    nan_guard(bad, acc[0][0][0]);               // a feature beyond the f16 range
+    nan_guard(bad, acc[0][1][0]);
     // ---- per net: bias, LayerNorm, ReLU, 64x64, bias, LayerNorm, ReLU, dot, sigmoid
     float score[NN][2];
 #pragma unroll
@@ -853,6 +900,7 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
                     a2 = OWH_MFMA(wl, ho[k2].h, a2);
                 }
                 h2[oct] = a2;
+                if (oct == 0) nan_guard(bad, a2[0]);
             }
             ln_relu<NN>(h2, net.b2, net.ln2g, net.ln2b, net.has_ln, j);
             float z = 0.f;
@@ -882,6 +930,7 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
             }
         }
     }
+    raise_range_flag(bad, p.range_flag);
 }
 
 }  // namespace owh

@@ -492,6 +492,7 @@ struct RStageParams {
     float* dbg;
     size_t dbg_stride;
     int dbg_off[5];
+    int* range_flag;       // f16-split family: sticky out-of-range flag of the handle (owwhip_hx.h nan_guard); nullptr otherwise
 };
 
 // max-pool PT x PF of the stage output and scatter into the next stage's register-dump layout
@@ -658,6 +659,7 @@ struct RAParams {
     float* dbg;
     size_t dbg_stride;
     int dbg_off[3];
+    int* range_flag;       // see RStageParams::range_flag
 };
 
 #ifndef OWR_WPS_A

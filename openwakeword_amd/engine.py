@@ -269,6 +269,15 @@ class StreamEngine:
     def sync(self):
         _lib.check(self._lib.oww_sync(self._h))
 
+    def range_status(self, clear: bool = False) -> bool:
+        """True when the fp16-split kernels (use_mfma=3) have seen an activation beyond the f16 range since the flag was
+        last cleared (sticky; every step / collect / sync raises `OwwRangeError` while it is up).  Waits for the stream."""
+        rc = self._lib.oww_range_status(self._h, int(bool(clear)))
+        if rc == _lib.ERANGE:
+            return True
+        _lib.check(rc)
+        return False
+
     @property
     def scores_dev_ptr(self) -> int:
         return int(self._lib.oww_scores_dev(self._h) or 0)

@@ -37,47 +37,77 @@ def owner_of(stream_id: int, world: int, total: int) -> Tuple[int, int]:
 
 
 class ScoreGather:
-    """Per-step gather of score blocks to rank 0.
+    """Delivery of score blocks to rank 0: one collective per `every` steps.
 
     `gather(local)` takes this rank's [S_r, n_labels] fp32 tensor (device or CPU, matching the process group's
-    backend) and returns the global [total, n_labels] tensor on rank 0 (None elsewhere), rows in global stream
-    order.  Blocks are padded to the largest shard so that one fixed-size collective is issued per step; the
-    receive buffers are allocated once."""
+    backend).  With every == 1 (default) it returns the global [total, n_labels] tensor on rank 0 (None elsewhere),
+    rows in global stream order.  With every == K > 1 the block is stashed on the device and every K-th call issues
+    ONE K-times larger collective and returns [K, total, n_labels] on rank 0 (None on the other calls and ranks):
+    the exchange is latency- not bandwidth-bound (1.5 MB per GPU and step at 131,072 x 3), so batching K steps
+    amortises the launch + rendezvous cost; `flush()` delivers a partial batch.
+
+    Even shards (total % world == 0) are received straight into the output buffer -- rank 0's receive list is
+    `world` contiguous views of it, no unpack copies; uneven shards are padded to the largest one and unpacked."""
 
     def __init__(self, total_streams: int, n_labels: int, device: torch.device,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, every: int = 1):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.total, self.n_labels = int(total_streams), int(n_labels)
+        self.every = max(1, int(every))
         self.ranges = [stream_range(r, self.world, self.total) for r in range(self.world)]
         self.lo, self.hi = self.ranges[self.rank]
         self.max_rows = max(hi - lo for lo, hi in self.ranges)
-        self._send = torch.zeros(self.max_rows, n_labels, dtype=torch.float32, device=device)
-        self._recv: Optional[List[torch.Tensor]] = None
-        self._out: Optional[torch.Tensor] = None
+        self.even = all(hi - lo == self.max_rows for lo, hi in self.ranges)
+        K = self.every
+        self._send = torch.zeros(K, self.max_rows, n_labels, dtype=torch.float32, device=device)
+        self._fill = 0
+        self._recv: Optional[torch.Tensor] = None        # rank 0: [world, K, max_rows, n_labels], block r contiguous
+        self._out: Optional[torch.Tensor] = None         # rank 0, uneven shards or K > 1: [K, total, n_labels]
+        self.collectives = 0
         if self.rank == 0:
-            self._out = torch.empty(self.total, n_labels, dtype=torch.float32, device=device)
-            if self.world > 1:
-                self._recv = [torch.empty_like(self._send) for _ in range(self.world)]
+            self._recv = torch.empty(self.world, K, self.max_rows, n_labels, dtype=torch.float32, device=device)
+            if not (self.even and K == 1):
+                self._out = torch.empty(K, self.total, n_labels, dtype=torch.float32, device=device)
 
     @property
     def local_streams(self) -> int:
         return self.hi - self.lo
 
+    def _exchange(self, k: int) -> Optional[torch.Tensor]:
+        """One collective over the k (<= every) stashed steps."""
+        self._fill = 0
+        if self.world > 1:
+            recv = [self._recv[r] for r in range(self.world)] if self.rank == 0 else None
+            dist.gather(self._send, recv, dst=0, group=self.group)
+            self.collectives += 1
+        elif self.rank == 0:
+            self._recv[0].copy_(self._send)
+        if self.rank != 0:
+            return None
+        if self.even and self.every == 1:
+            return self._recv.view(self.total, self.n_labels)            # received in place: blocks are already in stream order
+        for r, (lo, hi) in enumerate(self.ranges):
+            self._out[:k, lo:hi].copy_(self._recv[r, :k, : hi - lo])
+        return self._out[0] if self.every == 1 else self._out[:k]
+
     def gather(self, local: torch.Tensor) -> Optional[torch.Tensor]:
         if local.shape != (self.local_streams, self.n_labels):
             raise ValueError(f"expected local scores {(self.local_streams, self.n_labels)}, got {tuple(local.shape)}")
-        if self.world == 1:
-            self._out.copy_(local)
-            return self._out
-        even = all(hi - lo == self.max_rows for lo, hi in self.ranges)
-        send = local if (even and local.is_contiguous()) else self._send
-        if send is self._send:
-            self._send[: self.local_streams].copy_(local)
-        dist.gather(send, self._recv, dst=0, group=self.group)
-        if self.rank != 0:
+        self._send[self._fill, : self.local_streams].copy_(local)
+        self._fill += 1
+        if self._fill < self.every:
             return None
-        for r, (lo, hi) in enumerate(self.ranges):
-            self._out[lo:hi].copy_(self._recv[r][: hi - lo])
-        return self._out
+        return self._exchange(self.every)
+
+    def flush(self) -> Optional[torch.Tensor]:
+        """Deliver the steps stashed since the last collective ([k, total, n_labels] on rank 0); None when there are none.
+        Every rank must call it at the same point."""
+        k = self._fill
+        if k == 0:
+            return None
+        out = self._exchange(k)
+        if out is not None and self.every == 1:
+            out = out[None]
+        return out

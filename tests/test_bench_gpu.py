@@ -1,0 +1,54 @@
+"""bench.py end to end on one GPU box (-m gpu): the JSON contract of the N = 1 line (parity block, roofline, extras
+switched off for speed) and of the N = 2 line.  The N = 2 run uses the OWW_BENCH_ONE_GPU testing aid -- both ranks on
+device 0, gloo instead of RCCL -- so it verifies the launch / sharding / gather-every-K / max-over-ranks code path that the
+driver's multi-GPU run takes; RCCL itself stays unexercised on a 1-GPU box."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _last_json(text: str) -> dict:
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_line_carries_parity_and_roofline():
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--streams", "8192",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["scores_valid"] and out["f16_range_flag"] is False
+    assert out["parity"]["n_pairs"] == 1024 and out["parity"]["ok"] and out["parity"]["max_abs_err"] <= 1e-4
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert abs(out["value"] - 8192 * 6 / (out["ms_per_step"] * 6e-3)) / out["value"] < 1e-3
+
+
+def test_two_rank_line_on_one_gpu():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OWW_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "7", "--warmup", "2", "--streams", "4096",
+           "--gather-every", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 7
+    assert out["config"]["sharding"] == "stream-range x2" and "every 3 step" in out["config"]["collective"]
+    assert abs(out["value"] - 2 * out["frames_per_sec_per_gpu"]) / out["value"] < 1e-6
+    assert abs(out["value"] - 2 * 4096 * 7 / (out["ms_per_step"] * 7e-3)) / out["value"] < 1e-3
+    assert out["parity"]["n_pairs"] == 2048 and out["parity"]["ok"]
+    assert "sustained" not in out and "resident_1m" not in out and out["cpu_baseline"] is None

@@ -343,7 +343,7 @@ def test_self_test_catches_f16_range_overflow(emb, heads):
     the normal weights and raises on a network whose activations leave the f16 range (one BatchNorm shift of 3e5: the
     ReLU / max stages swallow the NaNs, so nothing else would flag it)."""
     import copy
-    from openwakeword_amd._lib import OwwError
+    from openwakeword_amd._lib import OwwRangeError
     eng = StreamEngine(4, heads, emb)
     try:
         res = eng.self_test(n_frames=12)
@@ -353,15 +353,49 @@ def test_self_test_catches_f16_range_overflow(emb, heads):
     big = copy.deepcopy(emb)
     gamma, beta, mean, var = big["bn"][10]                              # weights.synthetic_embedding: Keras order
     big["bn"][10] = (gamma, np.full_like(beta, 3.0e5), mean, var)
-    eng = StreamEngine(4, heads, big)
-    try:
-        with pytest.raises(OwwError, match="use_mfma=1"):
-            eng.self_test(n_frames=12)
-    finally:
-        eng.close()
+    # ... and since ABI 2 the f16-split kernels notice it themselves: the commit-time warm-up on the all-ones mel history already
+    # trips the range guard, so such weights are refused when the handle is created
+    with pytest.raises(OwwRangeError, match="use_mfma = 1"):
+        StreamEngine(4, heads, big)
     eng = StreamEngine(4, heads, big, use_mfma=1)                       # the exact family agrees with itself
     try:
         assert eng.self_test(n_frames=12)["max_abs_score_diff"] == 0.0
+    finally:
+        eng.close()
+
+
+def test_range_guard_is_sticky_and_loud(emb, heads):
+    """An activation beyond the f16 range at run time (here: feature-ring rows of 1e6 handed to the heads) must not score
+    silently: the step that sees it and every later call raise OwwRangeError until the flag is cleared; the exact-fp32
+    family computes the same input without complaint."""
+    from openwakeword_amd._lib import OwwRangeError
+    pcm = W.synthetic_pcm(3, 1280 * 3, seed=77)
+    huge = np.full((16, 96), 1.0e6, np.float32)
+    eng = StreamEngine(3, heads, emb)
+    try:
+        assert eng.range_status() is False
+        eng.step(pcm[:, :1280])
+        eng.reset([1], huge)
+        with pytest.raises(OwwRangeError):
+            eng.step(pcm[:, 1280:2560])
+        with pytest.raises(OwwRangeError):                       # sticky
+            eng.step(pcm[:, 2560:])
+        with pytest.raises(OwwRangeError):
+            eng.sync()
+        assert eng.range_status(clear=True) is True
+        eng.reset()
+        assert eng.range_status() is False
+        out = eng.step(pcm[:, :1280])
+        assert np.isfinite(out).all()
+        with pytest.raises(OwwRangeError):                       # the stage-level entry reports it too
+            eng.head("alexa", np.full((2, 16, 96), 1.0e6, np.float32))
+        eng.range_status(clear=True)
+    finally:
+        eng.close()
+    eng = StreamEngine(3, heads, emb, use_mfma=1)
+    try:
+        eng.reset([1], huge)
+        assert np.isfinite(eng.step(pcm[:, :1280])).all() and eng.range_status() is False
     finally:
         eng.close()
 
