@@ -71,8 +71,11 @@ struct Op { f16x8 h, l; };
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ void nan_guard(lanemask_t& bad, float x) {
 #ifndef OWH_NO_RANGE_GUARD
-    // (inline asm: with the fcmp builtin the compiler keeps every tile's lane mask alive and ORs them at the end -- +50 SGPRs)
-    asm("v_cmp_u_f32 vcc, %1, %1\n\ts_or_b64 %0, %0, vcc" : "+s"(bad) : "v"(x) : "vcc");
+    // v_cmp_u_f32 + s_or_b64.  The compare is the builtin (not inline asm) so that the compiler's hazard recogniser sees a VALU read of
+    // an MFMA result and SCC / VCC stay modelled; the empty asm pins the OR here -- without it every tile's lane mask stays alive
+    // until the end of the kernel (+50 SGPRs).
+    bad |= __builtin_amdgcn_fcmpf(x, x, 8 /* FCMP_UNO */);
+    asm volatile("" : "+s"(bad));
 #endif
 }
 __device__ __forceinline__ void raise_range_flag(lanemask_t bad, int* flag) {

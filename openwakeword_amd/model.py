@@ -70,6 +70,35 @@ def _load_head(path_or_name: str, synthetic_seed: Optional[int]):
     return path_or_name, W.synthetic_head(base, synthetic_seed)
 
 
+def resolve_weights(weights: Union[str, dict, None]):
+    """(seed, embedding or None, given heads) from the `weights` argument shared by Model, BatchedModel and utils.bulk_predict:
+    'synthetic' -> seed 1234; a dict may carry 'embedding', 'heads', 'seed'; None -> real files only."""
+    if weights is None:
+        return None, None, {}
+    if isinstance(weights, str):
+        if weights != "synthetic":
+            raise ValueError("weights must be 'synthetic', a dict {'embedding':..., 'heads':...} or None")
+        return 1234, None, {}
+    if isinstance(weights, dict):
+        return weights.get("seed"), weights.get("embedding"), dict(weights.get("heads", {}))
+    raise ValueError("weights must be 'synthetic', a dict {'embedding':..., 'heads':...} or None")
+
+
+def resolve_embedding(embedding: Optional[dict], seed: Optional[int]) -> dict:
+    """The shared speech-embedding network (utils.py:90-93 loads embedding_model.onnx next to the wake-word models): the
+    caller's weights, else the real file through onnx_ingest, else -- ONLY when synthetic weights were asked for -- the
+    random-init network.  Never silently synthetic: real head files next to a random embedding would score nonsense."""
+    if embedding is not None:
+        return embedding
+    path = FEATURE_MODELS["embedding"]["model_path"]
+    if os.path.exists(path):
+        from . import onnx_ingest
+        return onnx_ingest.load_embedding(path)
+    if seed is not None:
+        return W.synthetic_embedding(seed)
+    raise ValueError(f"{path} does not exist; pass weights='synthetic' for random-init weights of the same architecture")
+
+
 class AudioFeatures:
     """Streaming half of openwakeword.utils.AudioFeatures on one device stream.
 
@@ -153,11 +182,16 @@ class AudioFeatures:
         if n < CHUNK or n % CHUNK:
             return n                                             # nothing processed yet: the caller repeats its last scores
         k = n // CHUNK
-        if k > self.engine.max_chunks:
-            raise ValueError(f"a single call may carry at most {self.engine.max_chunks} x 1280 samples "
-                             f"(max_chunks); got {n}")
-        # one device step: mel over the k chunks (one clamp floor), k embeddings, heads per chunk, max over chunks
-        self.last_scores = self.engine.step_raw(self._pending[None, :])[0]
+        # one device step: mel over the k chunks (one clamp floor), k embeddings, heads per chunk, max over chunks.  A call
+        # longer than max_chunks x 1280 samples (2.56 s by default; the reference takes any length, model.py:287-298) is fed
+        # in slices of max_chunks chunks and the raw scores are max-combined the same way -- the one deviation: the mel clamp
+        # floor (max - 80 dB) is then taken per slice instead of over the whole call.
+        cap = self.engine.max_chunks * CHUNK
+        raw = None
+        for o in range(0, n, cap):
+            part = self.engine.step_raw(self._pending[None, o:o + cap])[0]
+            raw = part if raw is None else np.maximum(raw, part)
+        self.last_scores = raw
         self._n_features = min(self._n_features + k, self.feature_buffer_max_len)
         self._pending = np.empty(0, dtype=np.int16)
         self.accumulated_samples = 0
@@ -185,17 +219,7 @@ class Model:
         if inference_framework != "hip":
             raise ValueError(f"openwakeword_amd only provides inference_framework='hip' (got '{inference_framework}'); "
                              "use the reference package for 'onnx' / 'tflite'")
-        seed = None
-        embedding = None
-        given_heads: Dict[str, dict] = {}
-        if isinstance(weights, str):
-            if weights != "synthetic":
-                raise ValueError("weights must be 'synthetic', a dict {'embedding':..., 'heads':...} or None")
-            seed = 1234
-        elif isinstance(weights, dict):
-            embedding = weights.get("embedding")
-            given_heads = dict(weights.get("heads", {}))
-            seed = weights.get("seed")
+        seed, embedding, given_heads = resolve_weights(weights)
         wakeword_models = list(wakeword_models)
         if wakeword_models == [] and given_heads:
             wakeword_models = list(given_heads)
@@ -208,15 +232,7 @@ class Model:
             else:
                 name, head = _load_head(m, seed)
                 heads[name] = head
-        if embedding is None:
-            if os.path.exists(FEATURE_MODELS["embedding"]["model_path"]):
-                from . import onnx_ingest
-                embedding = onnx_ingest.load_embedding(FEATURE_MODELS["embedding"]["model_path"])
-            elif seed is not None:
-                embedding = W.synthetic_embedding(seed)
-            else:
-                raise ValueError(f"{FEATURE_MODELS['embedding']['model_path']} does not exist; pass weights='synthetic' "
-                                 "for random-init weights of the same architecture")
+        embedding = resolve_embedding(embedding, seed)
 
         self.models: Dict[str, dict] = heads
         self.model_inputs = {n: int(h["T"]) for n, h in heads.items()}          # model.py:156
@@ -402,10 +418,11 @@ class BatchedModel:
     processes for scale-out).  Post-processing (first-5 zeroing, patience, debounce, 30-deep score ring) runs
     on the device per stream; `labels` names the score columns in `Model.predict`'s key order."""
 
-    def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict] = "synthetic",
+    def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict, None] = None,
                  device: int = 0, max_chunks: int = 1, hip_stream: int = 0):
-        seed = 1234 if weights == "synthetic" else (weights.get("seed") if isinstance(weights, dict) else None)
-        given = dict(weights.get("heads", {})) if isinstance(weights, dict) else {}
+        # same weight resolution as Model: real .onnx files (heads AND the shared embedding network) unless synthetic
+        # weights are asked for explicitly -- never a random-init embedding under real heads
+        seed, emb, given = resolve_weights(weights)
         heads = {}
         for m in wakeword_models:
             if m in given:
@@ -413,9 +430,7 @@ class BatchedModel:
             else:
                 name, head = _load_head(m, seed)
                 heads[name] = head
-        emb = weights.get("embedding") if isinstance(weights, dict) else None
-        if emb is None:
-            emb = W.synthetic_embedding(seed if seed is not None else 1234)
+        emb = resolve_embedding(emb, seed)
         self.engine = StreamEngine(n_streams, heads, emb, device=device, max_chunks=max_chunks, hip_stream=hip_stream)
         self.labels: List[str] = []
         self._keep: List[int] = []

@@ -151,7 +151,7 @@ def bulk_predict(file_paths, wakeword_models, prediction_function: str = "predic
     k = chunk // 1280
     n_calls = [len(range(0, c.shape[0] - chunk, chunk)) for c in clips]              # model.py:421-426
     S = len(clips)
-    bm = BatchedModel(S, list(wakeword_models), weights=model_kw.get("weights", "synthetic"),
+    bm = BatchedModel(S, list(wakeword_models), weights=model_kw.get("weights"),
                       device=int(model_kw.get("device", 0)), max_chunks=k)
     try:
         seed_stream = AudioFeatures(bm.engine, 0)                                     # seeds a feature ring like a fresh Model

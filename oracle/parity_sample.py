@@ -25,6 +25,7 @@ N_PROBE = 64
 N_FRAMES = 16
 SEED_WEIGHTS = 1234
 SEED_INIT_NOISE = 3
+PROBE_VERSION = 2           # bump when probe_pcm changes (part of the cache file name)
 HEADS3 = ("alexa", "hey_mycroft", "hey_jarvis")
 _GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_streaming.npz")
 
@@ -48,12 +49,13 @@ def probe_pcm(n_probe: int = N_PROBE, n_frames: int = N_FRAMES) -> np.ndarray:
         elif kind == 4:
             x = r.integers(-1000, 1000, n)          # the reference tests' noise (tests/test_models.py:57)
         elif kind == 5:
-            x = np.zeros(n) if (i // 8) % 2 == 0 else r.integers(-3, 4, n)          # silence / LSB noise
+            x = np.zeros(n) if i == 5 else r.integers(-3, 4, n)                     # silence (once) / LSB noise
         elif kind == 6:
             x = r.integers(-32768, 32768, n)        # full scale noise
         else:
             t = np.arange(n)
-            x = np.where((t // (8 << ((i // 8) % 4))) % 2, 32767, -32768)           # full-scale square waves
+            hi, lo = (32767, -32768) if i // 8 < 4 else (12000, -12000)             # full-scale / loud square waves, four periods
+            x = np.where((t // (8 << ((i // 8) % 4))) % 2, hi, lo)
         rows.append(np.asarray(x, dtype=np.int16))
     return np.stack(rows)
 
@@ -119,7 +121,7 @@ def oracle_reference(n_probe: int = N_PROBE, n_frames: int = N_FRAMES, head_name
     import sys
     import tempfile
     head_names = list(head_names)
-    tag = f"oww_parity_{n_probe}x{n_frames}_{'-'.join(head_names)}_{SEED_WEIGHTS}_{SEED_INIT_NOISE}.npz"
+    tag = f"oww_parity_{n_probe}x{n_frames}_{'-'.join(head_names)}_{SEED_WEIGHTS}_{SEED_INIT_NOISE}_v{PROBE_VERSION}.npz"
     path = os.path.join(tempfile.gettempdir(), tag)
     if not os.path.exists(path):
         root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
