@@ -235,7 +235,7 @@ def main():
     parity_ref = None
     family_ok = not (args.valu or args.lds_mfma)
     want_parity = (not args.no_parity and family_ok and set(head_names) <= {"alexa", "hey_mycroft", "hey_jarvis"}
-                   and not (args.host_pcm or args.host_pcm_blocking))
+                   and not (args.host_pcm or args.host_pcm_blocking) and not args.vad)     # (the probe reference is computed without a VAD gate)
     if want_parity and rank0:
         from oracle import parity_sample as PS
         parity_ref = PS.oracle_reference()              # computed once by a child interpreter, cached under $TMPDIR
@@ -273,11 +273,10 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     family = 0 if args.valu else 2 if args.lds_mfma else 1 if args.fp32 else 3
-    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=family, hip_stream=stream.cuda_stream)
+    vad_kw = dict(vad=W.synthetic_vad(1234), vad_threshold=0.5) if args.vad else {}
+    eng = StreamEngine(S, heads, emb, device=local_rank, use_mfma=family, hip_stream=stream.cuda_stream, **vad_kw)
     NL = eng.n_labels
     eng.reset()
-    if args.vad:
-        eng.enable_vad(W.synthetic_vad(1234), threshold=0.5)
     if args.graph:
         eng.use_graph(True)
 
@@ -350,7 +349,7 @@ def main():
         # ---- fp32_exact: the reference's own arithmetic type (exact fp32 MFMA family), same workload
         if family == 3:
             eng.close()
-            eng32 = StreamEngine(S, heads, emb, device=local_rank, use_mfma=1, hip_stream=stream.cuda_stream)
+            eng32 = StreamEngine(S, heads, emb, device=local_rank, use_mfma=1, hip_stream=stream.cuda_stream, **vad_kw)
             eng32.reset()
             dt_f, _ = timed_run(torch, dist, eng32, pool, scores, 20, 5, dev, 1, None, timing=False)
             extras["fp32_exact"] = {"kernels": "mfma_rr_fp32", "steps": 20, "warmup": 5, "ms_per_step": round(1e3 * dt_f / 20, 4),

@@ -101,6 +101,20 @@ int  oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshol
  * fp32 [S], host or device.  Like Model.reset(), oww_reset leaves the VAD ring alone. */
 int  oww_set_vad_threshold(oww_ctx* h, float threshold);
 int  oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device);
+/* Voice-activity NETWORK on the device (BASELINE configs[4]: "VAD gate fused into the per-frame HIP pipeline").  Silero's graph
+ * is unavailable (see above), so this loads a structural STAND-IN with the interface and state the reference fixes around the
+ * network (vad.py:98-130: 640-sample sub-frames / 32767, recurrent state h, c [2, 1, 64] carried from call to call, one score
+ * per sub-frame, the mean per predict() call appended to the ring): |STFT| (256-sample Hann frames, hop 64, bins 1..128) ->
+ * log(1 + gain |X|) -> 4 x [Conv1d(k=3, pad 1) + ReLU] 128->16 (stride 1), 16->32 (2), 32->32 (2), 32->64 (1) -> 2-layer LSTM(64)
+ * -> ReLU -> Linear(64->1) -> sigmoid, mean over time.  Blob (call before oww_commit): int32 hdr[8] = {1, 256, 64, 128, 64, 0, 0, 0};
+ * float gain; float hann[256]; per conv: w[3][cin][cout], b[cout]; per LSTM layer: w[128][256] (rows x ; h, columns i | f | g | o),
+ * b[256] (= b_ih + b_hh); float wd[64]; float bd.  Once loaded, every oww_step / oww_submit (n_chunks must be 1) runs the network
+ * on the frame's two sub-frames of every stream and pushes the mean score into the stream's ring; oww_push_vad is then refused.
+ * oww_get_vad copies the scores of the last step (host fp32 [S]); oww_reset_vad zeroes recurrent state and score history of the
+ * listed streams (NULL = all) -- oww_reset does not, exactly like Model.reset() leaves Model.vad alone (model.py:226-230). */
+int  oww_load_vad(oww_ctx* h, const void* blob, size_t nbytes);
+int  oww_get_vad(oww_ctx* h, float* out);
+int  oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n);
 
 /* ---- the hot loop: one Model.predict per stream (model.py:232-386) --------------------------------
  * pcm: int16 [S][n_chunks*1280], stream-major.  scores: fp32 [S][n_labels] or NULL.
@@ -177,9 +191,10 @@ int  oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t 
 int  oww_debug_profile(oww_ctx* h, int64_t* out, int32_t cap);
 /* kernel timing: records hipEvents around every kernel of subsequent oww_step calls when enabled;
  * oww_kernel_times fills ms[i] with the accumulated time and n[i] with the launch count of kernel
- * class i (0 mel,1 stageA,2 stageB,3 stageC,4 stageD,5 stageE,6 heads,7 postproc) and clears them. */
+ * class i (0 mel,1 stageA,2 stageB,3 stageC,4 stageD,5 stageE,6 heads,7 postproc,8 vad_front,9 vad_lstm) and clears them. */
+#define OWW_N_KERNEL_CLASSES 10
 int  oww_enable_timing(oww_ctx* h, int on);
-int  oww_kernel_times(oww_ctx* h, double ms[8], int64_t n[8]);
+int  oww_kernel_times(oww_ctx* h, double ms[OWW_N_KERNEL_CLASSES], int64_t n[OWW_N_KERNEL_CLASSES]);
 /* capture the n_chunks==1 device-to-device step into a hipGraph and replay it on later steps */
 int  oww_use_graph(oww_ctx* h, int on);
 

@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "owwhip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("owwhip_kernels.h", "owwhip_rr.h", "owwhip_hx.h")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("owwhip_kernels.h", "owwhip_rr.h", "owwhip_hx.h", "owwhip_vad.h")] + \
        [os.path.join(ROOT, "include", "owwhip.h")]
 LIB = os.path.join(HERE, "libowwhip.so")
 

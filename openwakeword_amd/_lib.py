@@ -45,6 +45,9 @@ SYMBOLS = {
     "oww_host_free": (C.c_int, [_P]),
     "oww_set_vad_threshold": (C.c_int, [_P, C.c_float]),
     "oww_push_vad": (C.c_int, [_P, _P, C.c_int]),
+    "oww_load_vad": (C.c_int, [_P, _P, C.c_size_t]),
+    "oww_get_vad": (C.c_int, [_P, _P]),
+    "oww_reset_vad": (C.c_int, [_P, _P, C.c_int32]),
     "oww_scores_dev": (_P, [_P]),
     "oww_get_raw": (C.c_int, [_P, _P]),
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),

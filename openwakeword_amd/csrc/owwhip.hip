@@ -16,6 +16,7 @@
 #include "owwhip_kernels.h"
 #include "owwhip_rr.h"
 #include "owwhip_hx.h"
+#include "owwhip_vad.h"
 
 using namespace owk;
 
@@ -256,6 +257,12 @@ struct oww_ctx {
     int prof_block = -1;
     uint32_t *d_nfeat = nullptr, *d_npred = nullptr;
     float* d_vadring = nullptr; uint32_t* d_nvad = nullptr; float* d_vadin = nullptr; float vad_threshold = 0.f;   // VAD gate (oww_push_vad)
+    // voice-activity stand-in network on the device (oww_load_vad; owwhip_vad.h)
+    std::vector<float> vad_blob;
+    bool vad = false;
+    const float *d_vad_hann = nullptr, *d_vad_encw = nullptr, *d_vad_encb = nullptr, *d_vad_lstmw = nullptr, *d_vad_lstmb = nullptr, *d_vad_wd = nullptr;
+    float vad_bd = 0.f, vad_gain = 50.f;
+    float *d_vadx = nullptr, *d_vadhc = nullptr, *d_vadlast = nullptr;
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
     int* h_range = nullptr;          // sticky f16-range flag: one page-locked, device-mapped word the f16-split kernels raise
     int* d_range = nullptr;          // the same word as the kernels address it
@@ -270,8 +277,8 @@ struct oww_ctx {
     bool timing = false;
     std::vector<EventRec> ev;
     size_t ev_used = 0;
-    double t_ms[8] = {};
-    int64_t t_n[8] = {};
+    double t_ms[OWW_N_KERNEL_CLASSES] = {};
+    int64_t t_n[OWW_N_KERNEL_CLASSES] = {};
     // graph
     bool want_graph = false;
     hipGraph_t graph = nullptr;
@@ -562,7 +569,7 @@ void free_all(oww_ctx* h) {
     for (auto& g : h->groups) fr(g.d_nets);
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
-    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin);
+    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin); fr(h->d_vadx); fr(h->d_vadhc); fr(h->d_vadlast);
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
     if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
@@ -588,7 +595,33 @@ int step_chunk(oww_ctx* h, int k, int c) {
     return 0;
 }
 
+// voice-activity stand-in network for this step's 1280 new samples of every stream -> one score per stream into the VAD ring
+int launch_vad(oww_ctx* h, const int16_t* d_pcm, int n_samples) {
+    const int G = (h->S + 15) / 16;
+    {
+        owv::VadFrontParams p{};
+        p.pcm = d_pcm; p.n_samples = n_samples; p.S = h->S; p.hann = h->d_vad_hann; p.mag_gain = h->vad_gain;
+        p.w = h->d_vad_encw; p.bias = h->d_vad_encb; p.xout = h->d_vadx; p.range_flag = h->d_range;
+        const int grid = std::min((h->S + owv::V_WG - 1) / owv::V_WG, 256);          // persistent: one 8-wave workgroup per CU
+        Timed t(h, 8);
+        hipLaunchKernelGGL(owv::vad_front_kernel, dim3(grid), dim3(64 * owv::V_WG), owv::V_LDS_BYTES, h->stream, p);
+    }
+    {
+        owv::VadLstmParams p{};
+        p.xin = h->d_vadx; p.hc = h->d_vadhc; p.w = h->d_vad_lstmw; p.bias = h->d_vad_lstmb; p.wd = h->d_vad_wd; p.bd = h->vad_bd;
+        p.ring = h->d_vadring; p.n_vad = h->d_nvad; p.last = h->d_vadlast; p.S = h->S; p.n_groups = G;
+        Timed t(h, 9);
+        hipLaunchKernelGGL(owv::vad_lstm_kernel, dim3((G + owv::L_WG - 1) / owv::L_WG), dim3(64 * owv::L_WG), 0, h->stream, p);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
+    if (h->vad) {
+        if (k != 1) return fail(OWW_EINVAL, "with the on-device VAD network a step carries exactly one 1280-sample chunk per stream (got %d)", k);
+        if (int rc = launch_vad(h, d_pcm, OWW_CHUNK * k)) return rc;
+    }
     if (int rc = launch_mel(h, d_pcm, h->S, OWW_CHUNK * k, 8 * k, 1, h->d_mel, nullptr)) return rc;
     for (int c = 0; c < k; ++c)
         if (int rc = step_chunk(h, k, c)) return rc;
@@ -726,6 +759,29 @@ int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
     return (int)h->heads.size() - 1;
 }
 
+namespace {
+// blob of oww_load_vad (floats after the 8-int header): gain, hann[256], 4 x (w[3][cin][cout], b[cout]), 2 x (w[128][256], b[256]), wd[64], bd
+const int kVadEnc[4][2] = {{128, 16}, {16, 32}, {32, 32}, {32, 64}};
+size_t vad_blob_floats() {
+    size_t n = 1 + 256;
+    for (auto& e : kVadEnc) n += (size_t)3 * e[0] * e[1] + e[1];
+    n += 2 * ((size_t)128 * 256 + 256) + 64 + 1;
+    return n;
+}
+}  // namespace
+
+int oww_load_vad(oww_ctx* h, const void* blob, size_t nbytes) {
+    if (!h || !blob) return fail(OWW_EINVAL, "oww_load_vad: null argument");
+    if (h->committed) return fail(OWW_ESTATE, "weights already committed");
+    const size_t want = 32 + vad_blob_floats() * 4;
+    if (nbytes != want) return fail(OWW_EINVAL, "oww_load_vad: blob is %zu bytes, expected %zu", nbytes, want);
+    const int32_t* hdr = (const int32_t*)blob;
+    if (hdr[0] != 1 || hdr[1] != 256 || hdr[2] != 64 || hdr[3] != 128 || hdr[4] != 64)
+        return fail(OWW_EINVAL, "oww_load_vad: unsupported geometry (version %d, n_fft %d, hop %d, bins %d, hidden %d)", hdr[0], hdr[1], hdr[2], hdr[3], hdr[4]);
+    h->vad_blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
+    return OWW_OK;
+}
+
 int oww_n_labels(const oww_ctx* h) { return h ? h->NL : 0; }
 
 int oww_commit(oww_ctx* h) {
@@ -858,9 +914,49 @@ int oww_commit(oww_ctx* h) {
         }
         goff.push_back(go);
     }
+    // voice-activity stand-in (always fp16-split MFMA kernels, whatever the CNN family)
+    size_t o_vhann = 0, o_vencw = 0, o_vencb = 0, o_vlw = 0, o_vlb = 0, o_vwd = 0;
+    h->vad = !h->vad_blob.empty();
+    if (h->vad) {
+        const float* q = h->vad_blob.data();
+        h->vad_gain = *q++;
+        o_vhann = hb.add(q, 256); q += 256;
+        std::vector<float> encw, encb(4 * 64, 0.f), pk;
+        for (int l = 0; l < 4; ++l) {
+            const int cin = kVadEnc[l][0], cout = kVadEnc[l][1];
+            if (!hx_in_range(q, (size_t)3 * cin * cout)) return fail(OWW_EINVAL, "VAD encoder weights too large for the fp16-split kernels");
+            pack_hx(q, 3, cin, cout, pk);
+            encw.insert(encw.end(), pk.begin(), pk.end());
+            q += (size_t)3 * cin * cout;
+            memcpy(&encb[l * 64], q, cout * sizeof(float)); q += cout;
+        }
+        if (encw.size() != (size_t)owv::V_WFLOATS) return fail(OWW_EINVAL, "internal: VAD encoder image is %zu floats, expected %d", encw.size(), owv::V_WFLOATS);
+        o_vencw = hb.add(encw); o_vencb = hb.add(encb);
+        std::vector<float> lw, lb;
+        for (int l = 0; l < 2; ++l) {
+            if (!hx_in_range(q, (size_t)128 * 256)) return fail(OWW_EINVAL, "VAD LSTM weights too large for the fp16-split kernels");
+            // columns regrouped so that the four gates of hidden tile u are neighbours: column 16 (4u + gate) + i <- gate * 64 + 16u + i
+            std::vector<float> perm((size_t)128 * 256);
+            for (int k = 0; k < 128; ++k)
+                for (int u = 0; u < 4; ++u)
+                    for (int gt = 0; gt < 4; ++gt)
+                        for (int i = 0; i < 16; ++i) perm[(size_t)k * 256 + 16 * (4 * u + gt) + i] = q[(size_t)k * 256 + gt * 64 + 16 * u + i];
+            pack_hx(perm.data(), 1, 128, 256, pk);
+            lw.insert(lw.end(), pk.begin(), pk.end());
+            q += (size_t)128 * 256;
+            lb.insert(lb.end(), q, q + 256); q += 256;
+        }
+        o_vlw = hb.add(lw); o_vlb = hb.add(lb);
+        o_vwd = hb.add(q, 64); q += 64;
+        h->vad_bd = *q;
+    }
     HIPCHK(hipMalloc(&h->d_w, hb.data.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
     h->d_hann = h->d_w + o_hann; h->d_mstart = reinterpret_cast<const int*>(h->d_w + o_start); h->d_taps = h->d_w + o_taps;
+    if (h->vad) {
+        h->d_vad_hann = h->d_w + o_vhann; h->d_vad_encw = h->d_w + o_vencw; h->d_vad_encb = h->d_w + o_vencb;
+        h->d_vad_lstmw = h->d_w + o_vlw; h->d_vad_lstmb = h->d_w + o_vlb; h->d_vad_wd = h->d_w + o_vwd;
+    }
     for (int l = 0; l < 20; ++l) {
         h->d_conv[l] = h->d_w + o_conv[l];
         h->d_scale[l] = l < 19 ? h->d_w + o_scale[l] : nullptr;
@@ -929,6 +1025,13 @@ int oww_commit(oww_ctx* h) {
     if (int rc = dalloc(&h->d_vadring, SP * 8)) return rc;
     if (int rc = dalloc(&h->d_nvad, SP)) return rc;
     if (int rc = dalloc(&h->d_vadin, SP)) return rc;
+    if (h->vad) {
+        const size_t G = (SP + 15) / 16;
+        if (int rc = dalloc(&h->d_vadx, G * 4 * 1024)) return rc;
+        if (int rc = dalloc(&h->d_vadhc, G * 4096)) return rc;
+        if (int rc = dalloc(&h->d_vadlast, SP)) return rc;
+        if (int rc = set_lds(owv::vad_front_kernel, owv::V_LDS_BYTES)) return rc;
+    }
     if (int rc = dalloc(&h->d_tail, SP * 480)) return rc;
     if (int rc = dalloc(&h->d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax)) return rc;
     if (int rc = dalloc(&h->d_patience, (size_t)std::max(h->NL, 1))) return rc;
@@ -1139,6 +1242,7 @@ int oww_set_vad_threshold(oww_ctx* h, float threshold) {
 int oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_push_vad: handle not committed");
     if (!vad_scores) return fail(OWW_EINVAL, "oww_push_vad: null argument");
+    if (h->vad) return fail(OWW_ESTATE, "oww_push_vad: this handle computes its own voice-activity scores (oww_load_vad)");
     HIPCHK(hipSetDevice(h->cfg.device));
     const float* src = vad_scores;
     if (!on_device) {
@@ -1148,6 +1252,44 @@ int oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device) {
     hipLaunchKernelGGL(push_vad_kernel, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_vadring, h->d_nvad, src, h->S);
     HIPCHK(hipGetLastError());
     if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));          // the caller's buffer may be reused at once
+    return OWW_OK;
+}
+
+int oww_get_vad(oww_ctx* h, float* out) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_vad: handle not committed");
+    if (!h->vad) return fail(OWW_ESTATE, "oww_get_vad: no voice-activity network loaded (oww_load_vad)");
+    if (!out) return fail(OWW_EINVAL, "oww_get_vad: null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(out, h->d_vadlast, (size_t)h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return OWW_OK;
+}
+
+int oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_reset_vad: handle not committed");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int* d_ids = nullptr;
+    int count = h->S;
+    if (stream_ids) {
+        if (n < 1) return OWW_OK;
+        for (int i = 0; i < n; ++i)
+            if (stream_ids[i] < 0 || stream_ids[i] >= h->S) return fail(OWW_EINVAL, "oww_reset_vad: stream id %d out of range", stream_ids[i]);
+        if (n > h->ids_cap) {
+            if (h->d_ids) (void)hipFree(h->d_ids);
+            h->d_ids = nullptr; h->ids_cap = 0;
+            HIPCHK(hipMalloc(&h->d_ids, (size_t)n * sizeof(int)));
+            h->ids_cap = n;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_ids, stream_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        d_ids = h->d_ids; count = n;
+    }
+    if (h->vad) {
+        hipLaunchKernelGGL(owv::vad_reset_kernel, dim3(count), dim3(64), 0, h->stream, h->d_vadhc, h->d_vadring, h->d_nvad, h->d_vadlast, d_ids, count);
+    } else {
+        hipLaunchKernelGGL(vad_ring_reset_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->d_vadring, h->d_nvad, d_ids, count);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
 }
 
@@ -1378,11 +1520,11 @@ int oww_enable_timing(oww_ctx* h, int on) {
     return OWW_OK;
 }
 
-int oww_kernel_times(oww_ctx* h, double ms[8], int64_t n[8]) {
+int oww_kernel_times(oww_ctx* h, double ms[OWW_N_KERNEL_CLASSES], int64_t n[OWW_N_KERNEL_CLASSES]) {
     if (!h || !ms || !n) return fail(OWW_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (int rc = flush_events(h)) return rc;
-    for (int i = 0; i < 8; ++i) { ms[i] = h->t_ms[i]; n[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
+    for (int i = 0; i < OWW_N_KERNEL_CLASSES; ++i) { ms[i] = h->t_ms[i]; n[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
     return OWW_OK;
 }
 

@@ -1218,6 +1218,15 @@ __global__ void push_vad_kernel(float* ring, uint32_t* n_vad, const float* score
     n_vad[s] = L + 1u;
 }
 
+// forget the VAD score history of the listed streams (ids == nullptr: streams [0, n)); oww_reset itself leaves it alone (model.py:226-230)
+__global__ void vad_ring_reset_kernel(float* ring, uint32_t* n_vad, const int* ids, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int s = ids ? ids[k] : k;
+    for (int i = 0; i < 8; ++i) ring[(size_t)s * 8 + i] = 0.f;
+    n_vad[s] = 0u;
+}
+
 __global__ void advance_kernel(uint32_t* nfeat, int S) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < S) nfeat[s] += 1u;

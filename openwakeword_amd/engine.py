@@ -24,7 +24,7 @@ _KIND = {"binary": 0, "gated": 1, "multiclass": 2}
 # rows x mel-width x channels that each CNN layer produces per 80 ms step (incremental form)
 LAYER_NEW_SHAPES = ([(8, 32, 24)] * 3 + [(4, 16, 48)] * 4 + [(4, 8, 72)] * 4 + [(2, 4, 96)] * 4 +
                     [(2, 2, 96)] * 4 + [(1, 1, 96)])
-KERNEL_CLASSES = ["mel", "stageA", "stageB", "stageC", "stageD", "stageE", "heads", "postproc"]
+KERNEL_CLASSES = ["mel", "stageA", "stageB", "stageC", "stageD", "stageE", "heads", "postproc", "vad_front", "vad_lstm"]
 
 
 def pack_mel_blob() -> np.ndarray:
@@ -67,6 +67,23 @@ def pack_head_blob(head: dict) -> np.ndarray:
     return np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in parts])
 
 
+def pack_vad_blob(vad: dict) -> np.ndarray:
+    """Blob of oww_load_vad for the voice-activity stand-in network (weights.synthetic_vad layout)."""
+    hdr = np.array([1, W.VAD_N_FFT, W.VAD_HOP, W.VAD_BINS, W.VAD_HID, 0, 0, 0], dtype=np.int32)
+    parts = [hdr.view(np.float32), np.array([W.VAD_MAG_GAIN], np.float32), W.vad_hann()]
+    for (w, b), (cin, cout, _s) in zip(vad["enc"], W.VAD_ENC):
+        if w.shape != (3, cin, cout) or b.shape != (cout,):
+            raise ValueError(f"VAD encoder layer: expected w {(3, cin, cout)}, b {(cout,)}, got {w.shape}, {b.shape}")
+        parts += [w.ravel(), b]
+    for w, b in vad["lstm"]:
+        if w.shape != (2 * W.VAD_HID, 4 * W.VAD_HID) or b.shape != (4 * W.VAD_HID,):
+            raise ValueError("VAD LSTM layer: expected w [128, 256] (rows x ; h, columns i | f | g | o), b [256]")
+        parts += [w.ravel(), b]
+    wd, bd = vad["dec"]
+    parts += [np.asarray(wd, np.float32).ravel(), np.array([bd], np.float32)]
+    return np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in parts])
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -80,7 +97,9 @@ class StreamEngine:
 
     def __init__(self, n_streams: int, heads: Dict[str, dict], embedding: Optional[dict] = None,
                  device: int = 0, max_chunks: int = 1, use_mfma: int = 3, debug_layers: bool = False,
-                 feature_ring: int = 0, hip_stream: int = 0):
+                 feature_ring: int = 0, hip_stream: int = 0, vad: Optional[dict] = None, vad_threshold: float = 0.0):
+        """`vad`: weights of the on-device voice-activity stand-in network (weights.synthetic_vad layout); when given, every
+        step also runs it on the frame's two 640-sample sub-frames and gates the scores with `vad_threshold` (model.py:366-381)."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self._inflight: List[np.ndarray] = []
@@ -105,7 +124,13 @@ class StreamEngine:
                 _lib.check(self._lib.oww_add_head(self._h, _ptr(blob), blob.nbytes))
                 self.head_cols[name] = (col, col + int(head["n_out"]))
                 col += int(head["n_out"])
+            self.has_vad = vad is not None
+            if vad is not None:
+                blob = pack_vad_blob(vad)
+                _lib.check(self._lib.oww_load_vad(self._h, _ptr(blob), blob.nbytes))
             _lib.check(self._lib.oww_commit(self._h))
+            if vad_threshold:
+                _lib.check(self._lib.oww_set_vad_threshold(self._h, float(vad_threshold)))
         except Exception:
             self.close()
             raise
@@ -266,6 +291,18 @@ class StreamEngine:
             raise ValueError(f"need one VAD score per stream ({self.n_streams})")
         _lib.check(self._lib.oww_push_vad(self._h, _ptr(v), 0))
 
+    def get_vad(self) -> np.ndarray:
+        """Voice-activity scores [S] the on-device network pushed for the last step (what VAD.__call__ appended, vad.py:129-130)."""
+        out = np.empty(self.n_streams, dtype=np.float32)
+        _lib.check(self._lib.oww_get_vad(self._h, _ptr(out)))
+        return out
+
+    def reset_vad(self, stream_ids: Optional[Sequence[int]] = None) -> None:
+        """Zero the VAD state (recurrent h, c and score ring) of the listed streams (None = all).  reset() leaves it alone, like
+        Model.reset() leaves Model.vad alone (model.py:226-230); call this when a stream slot is handed to a new caller."""
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        _lib.check(self._lib.oww_reset_vad(self._h, _ptr(ids), 0 if ids is None else ids.size))
+
     def sync(self):
         _lib.check(self._lib.oww_sync(self._h))
 
@@ -377,10 +414,11 @@ class StreamEngine:
         _lib.check(self._lib.oww_enable_timing(self._h, int(on)))
 
     def kernel_times(self) -> Dict[str, Dict[str, float]]:
-        ms = (C.c_double * 8)()
-        n = (C.c_int64 * 8)()
+        k = len(KERNEL_CLASSES)
+        ms = (C.c_double * k)()
+        n = (C.c_int64 * k)()
         _lib.check(self._lib.oww_kernel_times(self._h, ms, n))
-        return {KERNEL_CLASSES[i]: {"ms": ms[i], "launches": int(n[i])} for i in range(8)}
+        return {KERNEL_CLASSES[i]: {"ms": ms[i], "launches": int(n[i])} for i in range(k)}
 
     def use_graph(self, on: bool = True):
         _lib.check(self._lib.oww_use_graph(self._h, int(on)))

@@ -419,7 +419,8 @@ class BatchedModel:
     on the device per stream; `labels` names the score columns in `Model.predict`'s key order."""
 
     def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict, None] = None,
-                 device: int = 0, max_chunks: int = 1, hip_stream: int = 0):
+                 device: int = 0, max_chunks: int = 1, hip_stream: int = 0, vad_weights: Optional[dict] = None,
+                 vad_threshold: float = 0.0):
         # same weight resolution as Model: real .onnx files (heads AND the shared embedding network) unless synthetic
         # weights are asked for explicitly -- never a random-init embedding under real heads
         seed, emb, given = resolve_weights(weights)
@@ -431,7 +432,10 @@ class BatchedModel:
                 name, head = _load_head(m, seed)
                 heads[name] = head
         emb = resolve_embedding(emb, seed)
-        self.engine = StreamEngine(n_streams, heads, emb, device=device, max_chunks=max_chunks, hip_stream=hip_stream)
+        # vad_weights: the on-device voice-activity stand-in network (weights.synthetic_vad layout; Silero's graph is not
+        # available, see openwakeword_amd/vad.py) -- BASELINE configs[4]: network + gate fused into every step
+        self.engine = StreamEngine(n_streams, heads, emb, device=device, max_chunks=max_chunks, hip_stream=hip_stream,
+                                   vad=vad_weights, vad_threshold=vad_threshold)
         self.labels: List[str] = []
         self._keep: List[int] = []
         col = 0
@@ -466,8 +470,14 @@ class BatchedModel:
         frames = int(np.ceil(debounce_time / (chunk_samples / 16000))) if debounce_time > 0 else 0
         self.engine.set_postproc(pat, thr, frames)
 
-    def reset(self, stream_ids: Optional[Sequence[int]] = None, init_features: Optional[np.ndarray] = None):
+    def reset(self, stream_ids: Optional[Sequence[int]] = None, init_features: Optional[np.ndarray] = None,
+              reset_vad: bool = False):
+        """Model.reset for the listed streams (None = all).  Like the reference (model.py:226-230) this leaves the VAD state
+        alone; pass reset_vad=True when a stream slot is handed to a NEW caller, so that it does not inherit the previous
+        caller's voice-activity history."""
         self.engine.reset(stream_ids, init_features)
+        if reset_vad:
+            self.engine.reset_vad(stream_ids)
 
     def predict_batch(self, pcm: np.ndarray) -> np.ndarray:
         if not isinstance(pcm, np.ndarray):

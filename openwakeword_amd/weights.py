@@ -219,3 +219,38 @@ def synthetic_pcm(n_streams: int, n_samples: int, seed: int = 0xA11CE, rms: floa
     r = np.random.default_rng(seed)
     x = np.rint(r.normal(0.0, rms, size=(n_streams, n_samples)))
     return np.clip(x, -32768, 32767).astype(np.int16)
+
+
+# ------------------------------------------------------------------------ voice-activity stand-in network
+# Silero's silero_vad.onnx (vad.py:54-81) is a release asset whose graph is not in the reference checkout, so the device
+# runs a STRUCTURAL stand-in with the interface the reference fixes (640-sample sub-frames / 32767, (h, c) [2, 1, 64]
+# carried, one score per sub-frame): 256/64 STFT magnitudes of bins 1..128, log(1 + 50 |X|), four Conv1d(k=3)+ReLU
+# (128->16 s1, 16->32 s2, 32->32 s2, 32->64 s1), 2-layer LSTM(64), ReLU -> Linear(64->1) -> sigmoid, mean over time.
+# The numpy restatement the tests check it against is oracle/vad_standin.py.
+VAD_N_FFT, VAD_HOP, VAD_SUB, VAD_BINS, VAD_HID = 256, 64, 640, 128, 64
+VAD_MAG_GAIN = 50.0
+VAD_ENC = ((128, 16, 1), (16, 32, 2), (32, 32, 2), (32, 64, 1))
+
+
+def synthetic_vad(seed: int = 1234) -> dict:
+    """Random-init weights of the stand-in: 'enc' [(w [3, cin, cout], b [cout])] x 4, 'lstm' [(w [128, 256] rows (x ; h),
+    columns (i | f | g | o), b [256] = b_ih + b_hh)] x 2, 'dec' (w [64], b)."""
+    r = _rng(seed, "vad")
+    enc = []
+    for cin, cout, _stride in VAD_ENC:
+        enc.append((r.normal(0.0, np.sqrt(2.0 / (3 * cin)), size=(3, cin, cout)).astype(np.float32),
+                    r.normal(0.0, 0.1, size=cout).astype(np.float32)))
+    enc[0] = ((enc[0][0] * 0.25).astype(np.float32), enc[0][1])         # the log-magnitudes are O(4), not O(1)
+    lstm = []
+    for _layer in range(2):
+        w = r.normal(0.0, 1.0 / np.sqrt(VAD_HID), size=(2 * VAD_HID, 4 * VAD_HID)).astype(np.float32)
+        b = r.normal(0.0, 0.1, size=4 * VAD_HID).astype(np.float32)
+        b[VAD_HID:2 * VAD_HID] += 1.0                                    # forget-gate bias, the usual initialisation
+        lstm.append((w, b))
+    dec = (r.normal(0.0, 1.5, size=VAD_HID).astype(np.float32), np.float32(-0.3))
+    return {"enc": enc, "lstm": lstm, "dec": dec}
+
+
+def vad_hann() -> np.ndarray:
+    n = np.arange(VAD_N_FFT, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / VAD_N_FFT)).astype(np.float32)
