@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "owwhip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("owwhip_kernels.h", "owwhip_rr.h", "owwhip_hx.h", "owwhip_vad.h")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("owwhip_kernels.h", "owwhip_rr.h", "owwhip_hx.h", "owwhip_vad.h", "owwhip_fused.h")] + \
        [os.path.join(ROOT, "include", "owwhip.h")]
 LIB = os.path.join(HERE, "libowwhip.so")
 
@@ -31,6 +31,7 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, de
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC,
            "-I" + os.path.join(ROOT, "include"), "-o", target + ".tmp", "-Wall", "-Wno-unused-function"]
     cmd += ["-D" + d for d in defines]
+    cmd += os.environ.get("OWW_HIPCC_FLAGS", "").split()          # (diagnostic builds only, e.g. -mllvm -amdgpu-waitcnt-forcezero)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

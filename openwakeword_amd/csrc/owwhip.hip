@@ -17,6 +17,7 @@
 #include "owwhip_rr.h"
 #include "owwhip_hx.h"
 #include "owwhip_vad.h"
+#include "owwhip_fused.h"
 
 using namespace owk;
 
@@ -267,6 +268,10 @@ struct oww_ctx {
     int* h_range = nullptr;          // sticky f16-range flag: one page-locked, device-mapped word the f16-split kernels raise
     int* d_range = nullptr;          // the same word as the kernels address it
     int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
+    bool fuse = false;               // f16-split family: mel front end fused into stage A for one-chunk streaming steps (owwhip_fused.h)
+    const int16_t* fuse_pcm = nullptr;   // set by launch_step for the duration of a fused step
+    bool post_in_heads = false;          // one group of sigmoid heads covers every label: post-processing + counter advance ride in the heads launch
+    bool post_in_heads_now = false;      // ... for the step being launched (one-chunk steps only)
     float* d_save = nullptr; size_t save_floats = 0;      // streaming state parked by oww_embed / oww_embed_clips
     int* d_ids = nullptr;
     int ids_cap = 0;
@@ -398,7 +403,17 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.range_flag = HX ? h->d_range : nullptr;
         const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
         Timed t(h, 1);
-        if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 256 * OWH_WPS_A)), dim3(256), 0, st, p);
+        if (HX && h->fuse_pcm) {
+            // mel front end + stage A in one launch: PCM in, pooled stage-A activations out (BASELINE configs[2] "mel+embedding fused")
+            owf::MelAParams q{};
+            q.a = p; q.a.mel = nullptr; q.a.n_streams = h->S;          // the PCM buffer holds the S real streams only
+            q.pcm = h->fuse_pcm; q.tail = h->d_tail; q.nfeat = h->d_nfeat; q.hann = h->d_hann; q.mel_start = h->d_mstart; q.mel_taps = h->d_taps;
+            q.mel_out = h->cfg.debug_layers ? h->d_mel : nullptr;
+            const int per_cu = std::max(1, std::min(12 / owf::FA_WG, 163840 / owf::FA_LDS_BYTES));     // persistent: 12 waves per CU
+            const int g2 = std::min((h->S + owf::FA_WG - 1) / owf::FA_WG, 256 * per_cu);
+            hipLaunchKernelGGL(owf::hmelA_kernel<DBG>, dim3(g2), dim3(64 * owf::FA_WG), owf::FA_LDS_BYTES, st, q);
+        }
+        else if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 256 * OWH_WPS_A)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(rstageA_kernel<DBG>, dim3(grid), dim3(256), 0, st, p);
     }
     auto fill = [&](RStageParams& p, const float* xin, float* xout, int first_layer, int sb, int sd, int spt) {
@@ -481,6 +496,12 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 q.feat = base.feat; q.ext = base.ext; q.TR = base.TR; q.T = g.T; q.nfeat = base.nfeat; q.w1hx = g.d_w1hx;
                 q.raw = raw_out; q.NL = h->NL; q.S = n_active; q.accumulate_max = base.accumulate_max;
                 q.range_flag = h->d_range;
+                if (h->post_in_heads_now) {
+                    owh::HeadHxPost& pp = q.post;
+                    pp.enabled = 1; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred; pp.nfeat = h->d_nfeat;
+                    pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
+                    pp.vad_ring = h->d_vadring; pp.n_vad = h->d_nvad; pp.vad_threshold = h->vad_threshold;
+                }
                 for (int i = 0; i < g.n_nets; ++i) {
                     const NetHost& n = h->nets[g.nets[i]];
                     const NetDesc d = h->host_descs[g.nets[i]];
@@ -590,8 +611,13 @@ void free_all(oww_ctx* h) {
 // one chunk of the streaming step on device-resident mel rows
 int step_chunk(oww_ctx* h, int k, int c) {
     if (int rc = run_cnn(h, h->Spad, 8 * k * 32, c * 8 * 32)) return rc;
-    if (int rc = run_heads(h, h->Spad, c > 0, nullptr, -1, h->d_raw, 0)) return rc;
-    hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+    h->post_in_heads_now = h->post_in_heads && k == 1;
+    const int rc = run_heads(h, h->Spad, c > 0, nullptr, -1, h->d_raw, 0);
+    const bool done_in_heads = h->post_in_heads_now;
+    h->post_in_heads_now = false;
+    if (rc) return rc;
+    if (!done_in_heads)
+        hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
     return 0;
 }
 
@@ -622,9 +648,17 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
         if (k != 1) return fail(OWW_EINVAL, "with the on-device VAD network a step carries exactly one 1280-sample chunk per stream (got %d)", k);
         if (int rc = launch_vad(h, d_pcm, OWW_CHUNK * k)) return rc;
     }
-    if (int rc = launch_mel(h, d_pcm, h->S, OWW_CHUNK * k, 8 * k, 1, h->d_mel, nullptr)) return rc;
-    for (int c = 0; c < k; ++c)
-        if (int rc = step_chunk(h, k, c)) return rc;
+    if (h->fuse && k == 1 && (reinterpret_cast<uintptr_t>(d_pcm) & 15) == 0) {      // (the fused front end uses 16-byte sample loads)
+        h->fuse_pcm = d_pcm;
+        const int rc = step_chunk(h, 1, 0);
+        h->fuse_pcm = nullptr;
+        if (rc) return rc;
+    } else {
+        if (int rc = launch_mel(h, d_pcm, h->S, OWW_CHUNK * k, 8 * k, 1, h->d_mel, nullptr)) return rc;
+        for (int c = 0; c < k; ++c)
+            if (int rc = step_chunk(h, k, c)) return rc;
+    }
+    if (h->post_in_heads && k == 1) { HIPCHK(hipGetLastError()); return 0; }      // post-processing already ran inside the heads launch
     PostParams pp{};
     pp.raw = h->d_raw; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred;
     pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
@@ -1044,6 +1078,10 @@ int oww_commit(oww_ctx* h) {
     if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
     if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
+    h->fuse = h->hx && !getenv("OWW_NO_FUSE");
+    h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
+    if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;
+    if (int rc = set_lds(owf::hmelA_kernel<true>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(owh::heads_hx_kernel<1>, owh::HX_NBUF * 1 * 8 * 1024)) return rc;
     if (int rc = set_lds(owh::heads_hx_kernel<2>, owh::HX_NBUF * 2 * 8 * 1024)) return rc;
     if (int rc = set_lds(owh::heads_hx_kernel<3>, owh::HX_NBUF * 3 * 8 * 1024)) return rc;
@@ -1482,6 +1520,9 @@ int oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out) {
 
 int oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_mel: handle not committed");
+    if (h->fuse && h->k_last == 1 && !h->cfg.debug_layers)
+        return fail(OWW_ESTATE, "oww_get_mel: with the mel front end fused into stage A the rows of a one-chunk step never reach HBM; "
+                    "create the handle with debug_layers = 1 to keep them");
     const int rows_last = 8 * h->k_last;           // the last step wrote [S][8 * n_chunks][32]
     if (sid < 0 || sid >= h->S || !out || n_rows < 1 || n_rows > rows_last)
         return fail(OWW_EINVAL, "oww_get_mel: bad argument (sid=%d n_rows=%d; the last step produced %d rows per stream)", sid, n_rows, rows_last);

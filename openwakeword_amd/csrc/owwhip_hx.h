@@ -518,6 +518,182 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 // ------------------------------------------------------------------------------------------------
 // stage A (parameters and layouts: owr::RAParams; w0 / w1 / w2 = hx-packed, hist2 tiles in plain D order)
 // ------------------------------------------------------------------------------------------------
+// one stream-step of stage A for the wave: mel rows (LDS tile sM: rows 0, 1 = history, 2..9 = the step's eight new rows, one zero
+// column either side) -> conv0, conv1, conv2, pool -> stage B input; updates the stream's conv2 / mel histories.  MEL_IN_LDS:
+// the caller has already put the new rows into sM (fused mel front end, owh::hmelA_kernel), else they are read from p.mel.
+template <bool DBG, bool MEL_IN_LDS>
+__device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, float* sM, const float* sW0, const float* sW1,
+                                               const float* sW2, const float* sbn0, const int (&goff)[8], lanemask_t& bad, int lane) {
+    using namespace owr;
+    const int pos = lane & 15, j = lane >> 4;
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    const float* w0s = sW0 + z;
+    const float* w1s = sW1 + z;
+    const float* w2s = sW2 + z;
+    const float* bn = sbn0 + z;
+    const float* mel = MEL_IN_LDS ? nullptr : p.mel + (size_t)s * p.mel_stride + p.mel_off;
+    float* hm = p.hist_mel + (size_t)s * 64;
+    float* h2 = p.hist2 + (size_t)s * (2 * 2 * 8 * 64);
+    if (MEL_IN_LDS) {
+        sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hm[lane];        // rows 2..9 were written by the caller (fused mel front end)
+    } else {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mel + lane * 4);
+        const float hv = hm[lane];
+        const int row = lane >> 3, col = (lane & 7) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sM[(2 + row) * 34 + 1 + col + e] = m4[e];
+        sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hv;
+    }
+    Op Yh[2][2][1];                               // conv1 output rows r-2, r-1 in operand form: [row][half][ks]
+    f32x4 Yf[2][2][2];                            // the same rows in fp32 (become the stored history)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { load_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane); to_ops<2>(Yf[r][h], Yh[r][h]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // rows 2q, 2q+1
+        OWR_SB();
+        // ---- conv0 (K = 9 -> one k-step)
+        Op Y0o[4][1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = 2 * q + (t >> 1), h = t & 1;
+            f32x4 b0, b1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { b0[e] = sM[r * 34 + h * 16 + goff[e]]; b1[e] = sM[r * 34 + h * 16 + goff[4 + e]]; }
+            const Op b = split_pair(b0, b1);
+            f32x4 Y0[2];
+#pragma unroll
+            for (int oct = 0; oct < 2; ++oct) {
+                const f16x8 ah = lds_h(w0s, oct * 2 + 0, lane), al = lds_h(w0s, oct * 2 + 1, lane);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = OWH_MFMA(ah, b.h, acc);
+                acc = OWH_MFMA(ah, b.l, acc);
+                acc = OWH_MFMA(al, b.h, acc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmax_nc(acc[e], 0.f);
+                Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
+                pin(Y0[oct]);
+            }
+            if (DBG && p.dbg) dump_tile<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
+            to_ops<2>(Y0, Y0o[t]);
+        }
+        // ---- conv1: 1x3 over two half-row tiles with carries across the seam
+        f32x4 Y1[4][2];
+#pragma unroll
+        for (int oct = 0; oct < 2; ++oct) {
+            f32x4 acc[3][4];
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti) {
+                const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (ti < 2) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[1][t][e] = (t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]);
+                    }
+                }
+                const f16x8 ah = lds_h(w1s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + tap) * 2 + 1, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].h, acc[tap][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].l, acc[tap][t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(al, Y0o[t][0].h, acc[tap][t]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int t0 = 2 * rr, t1 = 2 * rr + 1;
+                f32x4 r0, r1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
+                    r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
+                }
+                if (oct == 0) { nan_guard(bad, r0[0]); nan_guard(bad, r1[0]); }
+                Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
+                Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
+                pin(Y1[t0][oct]); pin(Y1[t1][oct]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DBG && p.dbg) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dump_tile<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+        }
+        Op Y1o[4][1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) to_ops<2>(Y1[t], Y1o[t]);
+        // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1]
+        f32x4 Y2[4][2];
+#pragma unroll
+        for (int oct = 0; oct < 2; ++oct) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const f16x8 ah = lds_h(w2s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w2s, (oct * 3 + tap) * 2 + 1, lane);
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int src = (t >> 1) + tap, h = t & 1;
+                        const Op& b = src < 2 ? Yh[src][h][0] : Y1o[(src - 2) * 2 + h][0];
+                        acc[t] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[t]);
+                    }
+            }
+            if (oct == 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j); pin(Y2[t][oct]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DBG && p.dbg) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dump_tile<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Yh[0][h][0] = Y1o[h][0]; Yh[1][h][0] = Y1o[2 + h][0];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) { Yf[0][h][ct] = Y1[h][ct]; Yf[1][h][ct] = Y1[2 + h][ct]; }
+        }
+        // ---- pool 2x2 -> stage B input row q
+        float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64) + j * 16 + (pos >> 1);
+        float pm[2][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
+                    pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m));
+                }
+        if ((pos & 1) == 0) {                                      // one predicated region for all sixteen stores
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xo[(ct * 4 + e) * 64 + h * 8] = pm[h][ct][e];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) store_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
+    hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
+}
+
 template <bool DBG>
 __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p) {
     using namespace owr;
@@ -549,175 +725,10 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
     for (int q = 0; q < 8; ++q) { const int k = min(8 * j + q, 8); goff[q] = (k / 3) * 34 + (k % 3) + pos; }
     lanemask_t bad = 0;
 
-    for (int s = gw; s < p.n_streams; s += nw) {
-        int z = 0;
-        asm volatile("" : "+s"(z));
-        const float* w0s = sW0 + z;
-        const float* w1s = sW[0] + z;
-        const float* w2s = sW[1] + z;
-        const float* bn = &sbn[0][0][0] + z;
-        const float* mel = p.mel + (size_t)s * p.mel_stride + p.mel_off;
-        float* hm = p.hist_mel + (size_t)s * 64;
-        float* h2 = p.hist2 + (size_t)s * (2 * 2 * 8 * 64);
-        {
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mel + lane * 4);
-            const float hv = hm[lane];
-            const int row = lane >> 3, col = (lane & 7) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sM[(2 + row) * 34 + 1 + col + e] = m4[e];
-            sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hv;
-        }
-        Op Yh[2][2][1];                               // conv1 output rows r-2, r-1 in operand form: [row][half][ks]
-        f32x4 Yf[2][2][2];                            // the same rows in fp32 (become the stored history)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { load_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane); to_ops<2>(Yf[r][h], Yh[r][h]); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                 // rows 2q, 2q+1
-            OWR_SB();
-            // ---- conv0 (K = 9 -> one k-step)
-            Op Y0o[4][1];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = 2 * q + (t >> 1), h = t & 1;
-                f32x4 b0, b1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { b0[e] = sM[r * 34 + h * 16 + goff[e]]; b1[e] = sM[r * 34 + h * 16 + goff[4 + e]]; }
-                const Op b = split_pair(b0, b1);
-                f32x4 Y0[2];
-#pragma unroll
-                for (int oct = 0; oct < 2; ++oct) {
-                    const f16x8 ah = lds_h(w0s, oct * 2 + 0, lane), al = lds_h(w0s, oct * 2 + 1, lane);
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = OWH_MFMA(ah, b.h, acc);
-                    acc = OWH_MFMA(ah, b.l, acc);
-                    acc = OWH_MFMA(al, b.h, acc);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = fmax_nc(acc[e], 0.f);
-                    Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
-                    pin(Y0[oct]);
-                }
-                if (DBG && p.dbg) dump_tile<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
-                to_ops<2>(Y0, Y0o[t]);
-            }
-            // ---- conv1: 1x3 over two half-row tiles with carries across the seam
-            f32x4 Y1[4][2];
-#pragma unroll
-            for (int oct = 0; oct < 2; ++oct) {
-                f32x4 acc[3][4];
-#pragma unroll
-                for (int ti = 0; ti < 3; ++ti) {
-                    const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (ti < 2) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc[1][t][e] = (t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]);
-                        }
-                    }
-                    const f16x8 ah = lds_h(w1s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + tap) * 2 + 1, lane);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].h, acc[tap][t]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].l, acc[tap][t]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(al, Y0o[t][0].h, acc[tap][t]);
-                }
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int t0 = 2 * rr, t1 = 2 * rr + 1;
-                    f32x4 r0, r1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
-                        r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
-                    }
-                    if (oct == 0) { nan_guard(bad, r0[0]); nan_guard(bad, r1[0]); }
-                    Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
-                    Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
-                    pin(Y1[t0][oct]); pin(Y1[t1][oct]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (DBG && p.dbg) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    dump_tile<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
-            }
-            Op Y1o[4][1];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) to_ops<2>(Y1[t], Y1o[t]);
-            // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1]
-            f32x4 Y2[4][2];
-#pragma unroll
-            for (int oct = 0; oct < 2; ++oct) {
-                f32x4 acc[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int tap = 0; tap < 3; ++tap) {
-                    const f16x8 ah = lds_h(w2s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w2s, (oct * 3 + tap) * 2 + 1, lane);
-#pragma unroll
-                    for (int part = 0; part < 3; ++part)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int src = (t >> 1) + tap, h = t & 1;
-                            const Op& b = src < 2 ? Yh[src][h][0] : Y1o[(src - 2) * 2 + h][0];
-                            acc[t] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[t]);
-                        }
-                }
-                if (oct == 0) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j); pin(Y2[t][oct]); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (DBG && p.dbg) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    dump_tile<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                Yh[0][h][0] = Y1o[h][0]; Yh[1][h][0] = Y1o[2 + h][0];
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) { Yf[0][h][ct] = Y1[h][ct]; Yf[1][h][ct] = Y1[2 + h][ct]; }
-            }
-            // ---- pool 2x2 -> stage B input row q
-            float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64) + j * 16 + (pos >> 1);
-            float pm[2][2][4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
-                        pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m));
-                    }
-            if ((pos & 1) == 0) {                                      // one predicated region for all sixteen stores
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xo[(ct * 4 + e) * 64 + h * 8] = pm[h][ct][e];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) store_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
-        hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
-    }
+    for (int s = gw; s < p.n_streams; s += nw)
+        hstageA_stream<DBG, false>(p, s, sM, sW0, sW[0], sW[1], &sbn[0][0][0], goff, bad, lane);
     raise_range_flag(bad, p.range_flag);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // wake-word heads, fp16-split GEMM form (model.py:299-302; architecture train.py:56-83)
@@ -733,6 +744,23 @@ struct HeadHxNet {
     const float *b1, *ln1g, *ln1b, *b2, *ln2g, *ln2b, *w3, *b3;
     int has_ln, role, head, out_col;
 };
+// Optional tail of the heads kernel: Model.predict's post-processing (model.py:330-381 -- first-5 zeroing, patience / debounce
+// over the 30-deep score ring, ring append, VAD gate) and the step's frame-counter advance for the same streams, instead of two
+// more launches (owk::postproc_kernel, owk::advance_kernel).  Valid when every label of the handle is produced by THIS launch
+// (one group of sigmoid heads) and the step carries one chunk; otherwise the separate kernels run.
+struct HeadHxPost {
+    int enabled;
+    float* scores;           // [S][NL]
+    float* ring;             // [S][NL][30]
+    uint32_t* npred;         // [S]
+    uint32_t* nfeat;         // [S] (advanced here)
+    const int* patience;     // [NL]
+    const float* threshold;  // [NL] (NaN = none)
+    int debounce_frames;
+    const float* vad_ring;   // [S][8]
+    const uint32_t* n_vad;   // [S]
+    float vad_threshold;     // <= 0: gate off
+};
 struct HeadHxParams {
     const float* feat;      // ring [S][TR][96] or external [B][T][96] when ext != 0
     int ext, TR, T;
@@ -742,6 +770,7 @@ struct HeadHxParams {
     float* raw;             // [S][NL]
     int NL, S, accumulate_max;
     int* range_flag;        // sticky f16-range flag of the handle (see nan_guard)
+    HeadHxPost post;
 };
 
 __device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
@@ -923,13 +952,57 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
         for (int t = 0; t < 2; ++t) {
             const int st = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
             if (st >= p.S) continue;
+            const uint32_t cnt = p.post.enabled ? p.post.npred[st] : 0u;
+            const int have = cnt < 30u ? (int)cnt : 30;
+            float fin[NN];
 #pragma unroll
             for (int n = 0; n < NN; ++n) {
+                fin[n] = 0.f;
                 if (p.net[n].role != 0) continue;
                 float sc = score[n][t];
                 if (n + 1 < NN && p.net[n + 1].role == 1 && p.net[n + 1].head == p.net[n].head && sc > 0.5f) sc = score[n + 1][t];
-                float* o = p.raw + (size_t)st * p.NL + p.net[n].out_col;
-                *o = p.accumulate_max ? fmaxf(*o, sc) : sc;
+                const int l = p.net[n].out_col;
+                float* o = p.raw + (size_t)st * p.NL + l;
+                sc = p.accumulate_max ? fmaxf(*o, sc) : sc;
+                *o = sc;
+                if (p.post.enabled) {                                       // the rules of owk::postproc_kernel, same order
+                    float* ring = p.post.ring + ((size_t)st * p.NL + l) * 30;
+                    if (cnt < 5u) sc = 0.0f;                                // model.py:331-333
+                    if (sc != 0.0f) {
+                        const int pat = p.post.patience[l];
+                        const float thr = p.post.threshold[l];
+                        if (pat > 0) {                                      // model.py:349-352
+                            const int look = pat < have ? pat : have;
+                            int n_ok = 0;
+                            for (int i = 1; i <= look; ++i) n_ok += ring[(cnt - i) % 30u] >= thr ? 1 : 0;
+                            if (n_ok < pat) sc = 0.0f;
+                        } else if (p.post.debounce_frames > 0 && thr == thr) {   // model.py:353-359
+                            const int look = p.post.debounce_frames < have ? p.post.debounce_frames : have;
+                            int n_hit = 0;
+                            for (int i = 1; i <= look; ++i) n_hit += ring[(cnt - i) % 30u] >= thr ? 1 : 0;
+                            if (sc >= thr && n_hit > 0) sc = 0.0f;
+                        }
+                    }
+                    ring[cnt % 30u] = sc;                                   // model.py:362-363
+                    fin[n] = sc;
+                }
+            }
+            if (p.post.enabled) {
+                p.post.npred[st] = cnt + 1u;
+                p.post.nfeat[st] += 1u;                                     // (this stream's ring slot was read at kernel start)
+                bool gate = false;
+                if (p.post.vad_threshold > 0.0f) {                          // model.py:375-381
+                    const uint32_t L = p.post.n_vad[st];
+                    float vmax = 0.0f;
+                    if (L >= 5u) {
+                        vmax = -INFINITY;
+                        for (uint32_t i = (L >= 7u ? L - 7u : 0u); i + 5u <= L; ++i) vmax = fmaxf(vmax, p.post.vad_ring[(size_t)st * 8 + (i & 7u)]);
+                    }
+                    gate = vmax < p.post.vad_threshold;
+                }
+#pragma unroll
+                for (int n = 0; n < NN; ++n)
+                    if (p.net[n].role == 0) p.post.scores[(size_t)st * p.NL + p.net[n].out_col] = gate ? 0.0f : fin[n];
             }
         }
     }

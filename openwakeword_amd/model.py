@@ -209,6 +209,25 @@ class AudioFeatures:
 class Model:
     """openwakeword.Model on the HIP library (one stream per object)."""
 
+    def __new__(cls, *args, **kwargs):
+        """`inference_framework="onnx"` / `"tflite"` (model.py:112-141) keep working where their runtimes exist: the call is
+        handed to the reference package unchanged and ITS Model object is returned.  Where `openwakeword` (or the runtime it
+        imports at module level, vad.py:48) is not importable this raises the reference's own kind of error (ValueError, cf.
+        model.py:141) -- there is no silent fall-back to the HIP path or to anything else."""
+        framework = kwargs.get("inference_framework", "hip")
+        if framework == "hip":
+            return super().__new__(cls)
+        if framework not in ("onnx", "tflite"):
+            raise ValueError(f"unknown inference_framework '{framework}': 'hip' (this package), or 'onnx' / 'tflite' "
+                             "(handed to the reference package)")
+        try:
+            import openwakeword as reference_package
+        except Exception as e:                       # ImportError of the package itself or of onnxruntime / tflite inside it
+            raise ValueError(f"inference_framework='{framework}' is served by the reference package, which cannot be imported "
+                             f"here ({type(e).__name__}: {e}); use inference_framework='hip'") from e
+        passthrough = {k: v for k, v in kwargs.items() if k not in ("weights", "device", "max_chunks", "vad_session")}
+        return reference_package.Model(*args, **passthrough)
+
     def __init__(self, wakeword_models: List[str] = [], class_mapping_dicts: List[dict] = [],
                  enable_speex_noise_suppression: bool = False, vad_threshold: float = 0,
                  custom_verifier_models: dict = {}, custom_verifier_threshold: float = 0.1,
@@ -216,9 +235,6 @@ class Model:
                  max_chunks: int = 32, wakeword_model_paths: Optional[List[str]] = None, vad_session=None, **kwargs):
         if wakeword_model_paths is not None:            # deprecated alias (model.py:37)
             wakeword_models = wakeword_model_paths
-        if inference_framework != "hip":
-            raise ValueError(f"openwakeword_amd only provides inference_framework='hip' (got '{inference_framework}'); "
-                             "use the reference package for 'onnx' / 'tflite'")
         seed, embedding, given_heads = resolve_weights(weights)
         wakeword_models = list(wakeword_models)
         if wakeword_models == [] and given_heads:

@@ -213,7 +213,6 @@ def load_head(path: str) -> dict:
     lin = _linear_layers(g)
     if len(lin) not in (3, 6):
         raise ValueError(f"{path}: expected 3 (or 6 for a gated model) linear layers, found {len(lin)}")
-    ops = [n["op"] for n in g["nodes"]]
     n_nets = len(lin) // 3
     w1 = lin[0][0]
     if w1.shape[0] % W.EMB_DIM:
@@ -229,7 +228,27 @@ def load_head(path: str) -> dict:
             raise ValueError(f"{path}: network {k} has layer shapes {a.shape}, {b.shape}, {c.shape}")
         nets.append({"w1": a, "b1": ab, "ln1": lns[2 * k] if lns else None, "w2": b, "b2": bb,
                      "ln2": lns[2 * k + 1] if lns else None, "w3": c, "b3": cb})
-    kind = "gated" if n_nets == 2 else ("multiclass" if "Softmax" in ops else "binary")
+    # the activations the kernels will apply are fixed (Linear -> [LN] -> ReLU twice, then Sigmoid, or ReLU + Softmax for a
+    # multiclass model): check that the file really has them instead of inferring the kind from one op name
+    acts = {"Relu", "Sigmoid", "Softmax", "Tanh", "LeakyRelu", "Elu", "Selu", "Gelu", "HardSigmoid", "PRelu", "Clip"}
+    tails = []
+    for k in range(n_nets):
+        idx = [lin[3 * k + i][2] for i in range(3)]
+        stop = lin[3 * k + 3][2] if k + 1 < n_nets else len(g["nodes"])
+        for a, b in ((idx[0], idx[1]), (idx[1], idx[2])):
+            between = [n["op"] for n in g["nodes"][a + 1:b] if n["op"] in acts]
+            if between != ["Relu"]:
+                raise ValueError(f"{path}: expected exactly one Relu between the linear layers of network {k}, found {between}")
+        tails.append([n["op"] for n in g["nodes"][idx[2] + 1:stop] if n["op"] in acts])
+    if any(t != tails[0] for t in tails):
+        raise ValueError(f"{path}: the networks of a gated model end differently: {tails}")
+    if tails[0] == ["Sigmoid"]:
+        kind = "gated" if n_nets == 2 else "binary"
+    elif tails[0] == ["Relu", "Softmax"] and n_nets == 1:
+        kind = "multiclass"
+    else:
+        # e.g. train.py's multiclass branch ends in a bare ReLU (train.py:81-83): no kernel applies that, so refuse
+        raise ValueError(f"{path}: unsupported output activation {tails[0]} (supported: Sigmoid, or Relu -> Softmax)")
     head = {"kind": kind, "T": int(T), "hidden": int(hidden), "n_out": int(n_out), "net": nets[0]}
     if n_nets == 2:
         head["net2"] = nets[1]

@@ -20,10 +20,33 @@ def test_constructor_errors_match_reference():
     from openwakeword_amd import Model
     with pytest.raises(ValueError, match="Could not find pretrained model"):       # model.py:96-97
         Model(wakeword_models=["no_such_word"], weights="synthetic")
-    with pytest.raises(ValueError):                                                 # backend selector
+    # backend selector (model.py:112-141): "onnx" / "tflite" are handed to the reference package; it is not importable in this
+    # environment (no onnxruntime), which surfaces as the reference's kind of error, never as a silent switch of backend
+    with pytest.raises(ValueError, match="reference package"):
         Model(wakeword_models=["alexa"], inference_framework="onnx")
+    with pytest.raises(ValueError, match="unknown inference_framework"):
+        Model(wakeword_models=["alexa"], inference_framework="tensorrt")
     with pytest.raises(ValueError, match="does not exist"):                        # no silent synthetic weights
         Model(wakeword_models=["alexa"])
+
+
+def test_inference_framework_passthrough_returns_the_reference_object(monkeypatch):
+    """Where the reference package imports, inference_framework='onnx' / 'tflite' yield ITS Model (here: a stand-in module)."""
+    import sys
+    import types
+    from openwakeword_amd import Model
+    seen = {}
+
+    class RefModel:
+        def __init__(self, *a, **kw):
+            seen.update(kw)
+
+    fake = types.ModuleType("openwakeword")
+    fake.Model = RefModel
+    monkeypatch.setitem(sys.modules, "openwakeword", fake)
+    m = Model(wakeword_models=["alexa"], inference_framework="tflite", vad_threshold=0.3, weights="synthetic", device=1)
+    assert isinstance(m, RefModel) and not isinstance(m, Model)
+    assert seen == {"wakeword_models": ["alexa"], "inference_framework": "tflite", "vad_threshold": 0.3}
 
 
 def test_registry_mirrors_reference():

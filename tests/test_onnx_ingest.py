@@ -52,7 +52,7 @@ def _model(nodes, inits):
     return _vi((1 << 3) | 0) + _vi(8) + _ld(7, graph)
 
 
-def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True):
+def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True, tail=None, hidden_act="Relu"):
     nodes, inits, cur = [_node("Flatten", ["x"], ["f0"], [_attr_i("axis", 1)])], [], "f0"
     nets = [head["net"]] + ([head["net2"]] if head["kind"] == "gated" else [])
     for k, net in enumerate(nets):
@@ -75,9 +75,13 @@ def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True):
                     else:
                         nodes += [_node("Mul", [cur, f"n{k}g{li}"], [f"n{k}q{li}"]), _node("Add", [f"n{k}q{li}", f"n{k}be{li}"], [f"n{k}n{li}"])]
                     cur = f"n{k}n{li}"
-                nodes.append(_node("Relu", [cur], [f"n{k}r{li}"]))
+                nodes.append(_node(hidden_act, [cur], [f"n{k}r{li}"]))
                 cur = f"n{k}r{li}"
-        if head["kind"] == "multiclass":
+        if tail is not None:
+            for t_i, op in enumerate(tail):
+                nodes.append(_node(op, [cur], [f"n{k}t{t_i}"]))
+                cur = f"n{k}t{t_i}"
+        elif head["kind"] == "multiclass":
             nodes += [_node("Relu", [cur], [f"n{k}rr"]), _node("Softmax", [f"n{k}rr"], [f"n{k}out"])]
         else:
             nodes.append(_node("Sigmoid", [cur], [f"n{k}out"]))
@@ -119,6 +123,24 @@ def test_head_round_trip(tmp_path, name, kw):
     assert (got["kind"], got["T"], got["hidden"], got["n_out"]) == (head["kind"], head["T"], head["hidden"], head["n_out"])
     feats = np.random.default_rng(1).normal(0, 2, (5, head["T"], 96)).astype(np.float32)
     np.testing.assert_array_equal(O.head_stage(feats, got, np.float32), O.head_stage(feats, head, np.float32))
+
+
+def test_head_activations_are_verified_not_assumed(tmp_path):
+    """A graph whose activations differ from what the kernels apply must be refused, not scored differently from onnxruntime:
+    train.py's multiclass branch ends in a bare ReLU (train.py:81-83); a Tanh hidden layer; a Softmax without its ReLU."""
+    path = os.path.join(tmp_path, "odd.onnx")
+    timer = W.synthetic_head("timer", 77)
+    write_head(path, timer, tail=["Relu"])
+    with pytest.raises(ValueError, match="unsupported output activation"):
+        onnx_ingest.load_head(path)
+    write_head(path, timer, tail=["Softmax"])
+    with pytest.raises(ValueError, match="unsupported output activation"):
+        onnx_ingest.load_head(path)
+    write_head(path, W.synthetic_head("alexa", 77), hidden_act="Tanh")
+    with pytest.raises(ValueError, match="exactly one Relu"):
+        onnx_ingest.load_head(path)
+    write_head(path, W.synthetic_head("alexa", 77), tail=["Relu", "Softmax"])          # n_out == 1 with a softmax tail loads as multiclass
+    assert onnx_ingest.load_head(path)["kind"] == "multiclass"
 
 
 def test_embedding_round_trip(tmp_path):
