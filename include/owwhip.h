@@ -91,6 +91,15 @@ int  oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* in
  * patience[i] <= 0 and debounce_frames <= 0 disable the respective rule for label i. */
 int  oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold, int32_t debounce_frames);
 
+/* ---- custom verifier models (model.py:320-328; trained by custom_verifier_model.py:95-113) on the device ----------------------
+ * The reference re-scores a label whose base score reaches `threshold` (custom_verifier_threshold, default 0.1) with a pickled
+ * scikit-learn pipeline: flatten -> StandardScaler -> LogisticRegression over the last T feature rows of the label's model
+ * (T x 96 values, oldest row first).  Scaler and regression fold into one affine map, which is what this entry takes:
+ * w[T*96] = coef / scale, bias = intercept - sum(coef * mean / scale); the label then reads sigmoid(w . features + bias)
+ * (= predict_proba(...)[0][-1]) whenever its head output is >= threshold, before the post-processing rules.  w == NULL removes
+ * the label's verifier.  Host pointers; call after oww_commit. */
+int  oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, float bias, float threshold);
+
 /* ---- VAD gate of Model.predict (model.py:366-381) for the batched path -------------------------------------------------
  * The voice-activity NETWORK is not part of this library (silero_vad.onnx is a release asset whose graph is not in the reference
  * checkout): the caller supplies one VAD score per stream and step -- the mean over the step's 640-sample sub-frames that

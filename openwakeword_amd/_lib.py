@@ -43,6 +43,7 @@ SYMBOLS = {
     "oww_collect": (C.c_int, [_P, _P]),
     "oww_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "oww_host_free": (C.c_int, [_P]),
+    "oww_set_verifier": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_float, C.c_float]),
     "oww_set_vad_threshold": (C.c_int, [_P, C.c_float]),
     "oww_push_vad": (C.c_int, [_P, _P, C.c_int]),
     "oww_load_vad": (C.c_int, [_P, _P, C.c_size_t]),

@@ -270,6 +270,10 @@ struct oww_ctx {
     int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
     bool fuse = false;               // f16-split family: mel front end fused into stage A for one-chunk streaming steps (owwhip_fused.h)
     const int16_t* fuse_pcm = nullptr;   // set by launch_step for the duration of a fused step
+    // custom verifiers on the device (oww_set_verifier)
+    float *d_verw = nullptr, *d_verb = nullptr, *d_verthr = nullptr; int* d_verT = nullptr;
+    int ver_stride = 0, n_verifiers = 0;
+    std::vector<int> ver_T;
     bool post_in_heads = false;          // one group of sigmoid heads covers every label: post-processing + counter advance ride in the heads launch
     bool post_in_heads_now = false;      // ... for the step being launched (one-chunk steps only)
     float* d_save = nullptr; size_t save_floats = 0;      // streaming state parked by oww_embed / oww_embed_clips
@@ -590,7 +594,7 @@ void free_all(oww_ctx* h) {
     for (auto& g : h->groups) fr(g.d_nets);
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
-    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin); fr(h->d_vadx); fr(h->d_vadhc); fr(h->d_vadlast);
+    fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin); fr(h->d_vadx); fr(h->d_vadhc); fr(h->d_vadlast); fr(h->d_verw); fr(h->d_verb); fr(h->d_verthr); fr(h->d_verT);
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
     if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
@@ -611,11 +615,17 @@ void free_all(oww_ctx* h) {
 // one chunk of the streaming step on device-resident mel rows
 int step_chunk(oww_ctx* h, int k, int c) {
     if (int rc = run_cnn(h, h->Spad, 8 * k * 32, c * 8 * 32)) return rc;
-    h->post_in_heads_now = h->post_in_heads && k == 1;
+    h->post_in_heads_now = h->post_in_heads && k == 1 && h->n_verifiers == 0;
     const int rc = run_heads(h, h->Spad, c > 0, nullptr, -1, h->d_raw, 0);
     const bool done_in_heads = h->post_in_heads_now;
     h->post_in_heads_now = false;
     if (rc) return rc;
+    if (h->n_verifiers > 0 && c == k - 1) {          // after the maximum over the call's chunks, on the newest feature rows
+        VerifierParams v{};
+        v.raw = h->d_raw; v.feat = h->d_feat; v.nfeat = h->d_nfeat; v.w = h->d_verw; v.bias = h->d_verb; v.thr = h->d_verthr; v.T = h->d_verT;
+        v.wstride = h->ver_stride; v.NL = h->NL; v.TR = h->TR; v.S = h->S;
+        hipLaunchKernelGGL(verifier_kernel, dim3((h->S + 3) / 4), dim3(256), 0, h->stream, v);
+    }
     if (!done_in_heads)
         hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
     return 0;
@@ -658,7 +668,7 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
         for (int c = 0; c < k; ++c)
             if (int rc = step_chunk(h, k, c)) return rc;
     }
-    if (h->post_in_heads && k == 1) { HIPCHK(hipGetLastError()); return 0; }      // post-processing already ran inside the heads launch
+    if (h->post_in_heads && k == 1 && h->n_verifiers == 0) { HIPCHK(hipGetLastError()); return 0; }      // post-processing already ran inside the heads launch
     PostParams pp{};
     pp.raw = h->d_raw; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred;
     pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
@@ -1266,6 +1276,37 @@ int oww_host_alloc(void** out, size_t nbytes) {
 
 int oww_host_free(void* p) {
     if (p) HIPCHK(hipHostFree(p));
+    return OWW_OK;
+}
+
+int oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, float bias, float threshold) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_set_verifier: handle not committed");
+    if (label < 0 || label >= h->NL) return fail(OWW_EINVAL, "oww_set_verifier: label %d outside [0,%d)", label, h->NL);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int T = 0;                                         // feature rows of the model that owns this label
+    for (const auto& hh : h->heads) if (label >= hh.out_col && label < hh.out_col + hh.n_out) T = hh.T;
+    if (w && n_w != T * OWW_EMB_DIM) return fail(OWW_EINVAL, "oww_set_verifier: %d weights given, the label's model has %d x 96 = %d features", n_w, T, T * OWW_EMB_DIM);
+    if (!h->d_verw) {
+        int maxT = 1;
+        for (const auto& hh : h->heads) maxT = std::max(maxT, hh.T);
+        h->ver_stride = maxT * OWW_EMB_DIM;
+        if (int rc = dalloc(&h->d_verw, (size_t)h->NL * h->ver_stride)) return rc;
+        if (int rc = dalloc(&h->d_verb, (size_t)h->NL)) return rc;
+        if (int rc = dalloc(&h->d_verthr, (size_t)h->NL)) return rc;
+        if (int rc = dalloc(&h->d_verT, (size_t)h->NL)) return rc;
+        h->ver_T.assign(h->NL, 0);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (w) {
+        HIPCHK(hipMemcpy(h->d_verw + (size_t)label * h->ver_stride, w, (size_t)n_w * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_verb + label, &bias, sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_verthr + label, &threshold, sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->ver_T[label] = w ? T : 0;
+    HIPCHK(hipMemcpy(h->d_verT, h->ver_T.data(), (size_t)h->NL * sizeof(int), hipMemcpyHostToDevice));
+    h->n_verifiers = 0;
+    for (int t : h->ver_T) h->n_verifiers += t > 0;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }       // the launch list changed
     return OWW_OK;
 }
 

@@ -23,6 +23,9 @@ namespace owf {
 using owh::lanemask_t;
 using owr::f32x4;
 
+#ifndef OWF_I16_STAGE
+#define OWF_I16_STAGE 0    // 1: sample window staged in LDS as raw int16 -- measured SLOWER (stage 2.26 vs 2.17 ms: 16 ds_read_i16 + more spills); kept as an A/B switch
+#endif
 #ifndef OWF_WG
 #define OWF_WG 12          // waves per workgroup (one workgroup per CU: 3 waves per SIMD)
 #endif
@@ -129,7 +132,11 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         const int lane = lane_all + z;            // (the mel phase's lane-derived offsets are iteration-local for the same reason)
         float* xr = planes + z;                   // FFT planes; the sample window and the two power rows alias them (owk::mel_kernel)
         float* xi = xr + 576;
+#if OWF_I16_STAGE
+        int16_t* sx = reinterpret_cast<int16_t*>(xr);   // 680 int16 = the first 340 floats of the re plane
+#else
         float* sx = xr;
+#endif
         float* pw0 = xr + 128;
         float* pw1 = xr + 256;
         const float* s_hann = fl + FA_OFF_HANN + z;
@@ -148,14 +155,20 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
             wave_sync();                         // the previous pass's readers of the planes / power rows are done (same wave)
+            // the window is staged as the raw int16 samples (one conflict-free 16-byte write per lane; the float form cost four
+            // 8-way-conflicting ds_write2_b32 per lane) and converted when the lanes pick up their strided samples
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = lane * 8 + u * 512;
+#if OWF_I16_STAGE
+                if (i < owk::MEL_WX) *reinterpret_cast<int4*>(sx + i) = raw[u];
+#else
                 if (i < owk::MEL_WX) {
                     const int16_t* h = reinterpret_cast<const int16_t*>(&raw[u]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sx[i + e] = (float)h[e];
                 }
+#endif
             }
             if (f2 < 3) fetch_pass(tail_row, pcm_row, f2 + 1, lane, raw);     // next pass's samples fly during this FFT
             wave_sync();
@@ -165,8 +178,8 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 const int n = 64 * n2 + lane;
                 const bool in = (n >= 56) && (n < 456);
                 const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
-                re[n2] = w * sx[n];
-                im[n2] = w * sx[160 + n];
+                re[n2] = w * (float)sx[n];
+                im[n2] = w * (float)sx[160 + n];
             }
             dft8(re, im);
 #pragma unroll

@@ -1218,6 +1218,44 @@ __global__ void push_vad_kernel(float* ring, uint32_t* n_vad, const float* score
     n_vad[s] = L + 1u;
 }
 
+// ------------------------------------------------------------------------------------------------
+// custom verifier on the device (model.py:320-328; custom_verifier_model.py:95-113): the reference re-scores a label whose
+// base score reaches custom_verifier_threshold with a pickled scikit-learn pipeline -- flatten -> StandardScaler ->
+// LogisticRegression on the last T feature rows.  Scaler and regression fold into ONE affine map, so the device form is a
+// dot product of the stream's T x 96 ring rows with w' = coef / scale plus b' = intercept - sum(coef * mean / scale), then a
+// sigmoid (= predict_proba(...)[0][-1]).  One wave per stream; runs between the heads and the post-processing.
+// ------------------------------------------------------------------------------------------------
+struct VerifierParams {
+    float* raw;              // [S][NL] head outputs of this step (re-scored in place)
+    const float* feat;       // feature ring [S][TR][96]
+    const uint32_t* nfeat;   // [S] (not yet advanced for this step)
+    const float* w;          // [NL][wstride]
+    const float* bias;       // [NL]
+    const float* thr;        // [NL] custom_verifier_threshold
+    const int* T;            // [NL] feature rows of the label's model; 0 = no verifier for this label
+    int wstride, NL, TR, S;
+};
+
+__global__ __launch_bounds__(256) void verifier_kernel(VerifierParams p) {
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= p.S) return;
+    for (int l = 0; l < p.NL; ++l) {
+        const int T = p.T[l];
+        if (T <= 0) continue;
+        const float base = p.raw[(size_t)s * p.NL + l];
+        if (!(base >= p.thr[l])) continue;                                   // model.py:322
+        const uint32_t slot0 = p.nfeat[s] + (uint32_t)(2 * p.TR - T + 1);    // oldest of the last T rows (cf. heads_generic_kernel)
+        float acc = 0.f;
+        for (int i = lane; i < T * 96; i += 64) {
+            const uint32_t slot = (slot0 + (uint32_t)(i / 96)) % (uint32_t)p.TR;
+            acc = fmaf(p.feat[((size_t)s * p.TR + slot) * 96 + i % 96], p.w[(size_t)l * p.wstride + i], acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) p.raw[(size_t)s * p.NL + l] = 1.0f / (1.0f + expf(-(acc + p.bias[l])));
+    }
+}
+
 // forget the VAD score history of the listed streams (ids == nullptr: streams [0, n)); oww_reset itself leaves it alone (model.py:226-230)
 __global__ void vad_ring_reset_kernel(float* ring, uint32_t* n_vad, const int* ids, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -280,6 +280,15 @@ class StreamEngine:
                                 f"({res}): create the engine with use_mfma=1")
         return res
 
+    def set_verifier(self, label: int, w: Optional[np.ndarray], bias: float = 0.0, threshold: float = 0.1) -> None:
+        """Custom verifier of score column `label` on the device: sigmoid(w . last-T-feature-rows + bias) replaces the head
+        output wherever that is >= threshold (model.py:320-328).  w = None removes it."""
+        if w is None:
+            _lib.check(self._lib.oww_set_verifier(self._h, int(label), None, 0, 0.0, 0.0))
+            return
+        w = np.ascontiguousarray(w, dtype=np.float32).ravel()
+        _lib.check(self._lib.oww_set_verifier(self._h, int(label), _ptr(w), int(w.size), float(bias), float(threshold)))
+
     def set_vad_threshold(self, threshold: float) -> None:
         """VAD gate of model.py:366-381 on the device (0 = off); the scores come from push_vad()."""
         _lib.check(self._lib.oww_set_vad_threshold(self._h, float(threshold)))

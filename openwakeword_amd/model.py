@@ -99,6 +99,28 @@ def resolve_embedding(embedding: Optional[dict], seed: Optional[int]) -> dict:
     raise ValueError(f"{path} does not exist; pass weights='synthetic' for random-init weights of the same architecture")
 
 
+def fold_verifier(verifier):
+    """(w, bias) of a custom verifier: the reference's scikit-learn pipeline FunctionTransformer(flatten) -> StandardScaler ->
+    LogisticRegression (custom_verifier_model.py:95-113) folded into one affine map, or a ready (w, bias) pair."""
+    if isinstance(verifier, (tuple, list)) and len(verifier) == 2:
+        return np.asarray(verifier[0], np.float32).ravel(), float(verifier[1])
+    steps = getattr(verifier, "steps", None)
+    if not steps:
+        raise ValueError("the device verifier needs the reference's pipeline (flatten -> StandardScaler -> LogisticRegression) or a (w, bias) pair")
+    scaler = next((st for _, st in steps if hasattr(st, "scale_") and hasattr(st, "mean_")), None)
+    clf = steps[-1][1]
+    if not hasattr(clf, "coef_") or not hasattr(clf, "intercept_") or np.asarray(clf.coef_).shape[0] != 1:
+        raise ValueError("the last step of the verifier pipeline must be a fitted binary LogisticRegression")
+    coef = np.asarray(clf.coef_, np.float64)[0]
+    b = float(np.asarray(clf.intercept_, np.float64)[0])
+    if scaler is not None:
+        scale = np.asarray(scaler.scale_, np.float64)
+        mean = np.asarray(scaler.mean_, np.float64)
+        b -= float(np.sum(coef * mean / scale))
+        coef = coef / scale
+    return coef.astype(np.float32), b
+
+
 class AudioFeatures:
     """Streaming half of openwakeword.utils.AudioFeatures on one device stream.
 
@@ -499,6 +521,23 @@ class BatchedModel:
         if not isinstance(pcm, np.ndarray):
             raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
         return self.engine.step(pcm)[:, self._keep]
+
+    def set_custom_verifier(self, model_name: str, verifier, threshold: float = 0.1) -> None:
+        """`Model(custom_verifier_models=..., custom_verifier_threshold=...)` for every stream, on the device (model.py:320-328).
+        `verifier` is the scikit-learn pipeline custom_verifier_model.train_verifier_model returns (flatten -> StandardScaler ->
+        LogisticRegression; custom_verifier_model.py:95-113), or an already folded (w [T*96], bias) pair, or None to remove it.
+        Anything else -- an arbitrary object with predict_proba -- cannot run on the device: use the single-stream Model, which
+        keeps the reference's host-side hook."""
+        if model_name not in self._parent.values():
+            raise ValueError("Custom verifier models were provided, but some were not matched with a base model!")
+        cols = [c for c, n in self._parent.items() if n == model_name]
+        if verifier is None:
+            for c in cols:
+                self.engine.set_verifier(c, None)
+            return
+        w, b = fold_verifier(verifier)
+        for c in cols:
+            self.engine.set_verifier(c, w, b, threshold)
 
     def set_vad_threshold(self, threshold: float) -> None:
         """The VAD gate of `Model(vad_threshold=...)` (model.py:366-381) for every stream; 0 switches it off."""

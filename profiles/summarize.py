@@ -18,6 +18,12 @@ def short(name):
             return s + "_rr"
         if tag in name and name.startswith(("owh::hstage", "hstage")):
             return s + "_hx"
+    if "hmelA_kernel" in name:
+        return "stageA_hx"                       # mel front end + stage A in one launch (owwhip_fused.h); same key as the separate stage A
+    if "vad_front_kernel" in name:
+        return "vad_front"
+    if "vad_lstm_kernel" in name:
+        return "vad_lstm"
     if "heads_hx_kernel" in name:
         return "heads_hx"
     return name.split("(")[0][:60]
@@ -37,7 +43,7 @@ def main():
         r = [x for _, g, x in v if g == gmax][0]
         out.append((sum(full), k, len(full), sum(full) / len(full) / 1e3, min(full) / 1e3, max(full) / 1e3, gmax, r))
     for s, k, n, avg, mn, mx, g, r in sorted(out, reverse=True):
-        if not (k.startswith("stage") or k.startswith("mel") or k.startswith("heads") or k.startswith("postproc") or k.startswith("advance")):
+        if not k.startswith(("stage", "mel", "heads", "postproc", "advance", "vad_", "verifier")):
             continue
         tot += s
         print(f"{k:32s} {n:8d} {avg:10.1f} {mn:10.1f} {mx:10.1f} {g:10d} {r['Workgroup_Size_X']:>5s} {r['VGPR_Count']:>5s} {r['LDS_Block_Size']:>7s}")
@@ -55,7 +61,7 @@ def main():
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"\ncounters from {path} (mean per full-grid launch)")
         for k in sorted(agg):
-            if k.startswith(("stage", "mel", "heads", "r")):
+            if k.startswith(("stage", "mel", "heads", "r", "vad_")):
                 print(f"  {k:20s} " + "  ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(agg[k].items())))
 
 

@@ -6,6 +6,7 @@ import pytest
 
 import cases
 from openwakeword_amd import weights as W
+from oracle import oww_oracle as O
 
 TOL_SCORE = 1e-4          # fp32 path; north_star budget is 1e-3
 
@@ -204,6 +205,88 @@ class _Verifier:
         assert feats.shape == (1, 16, 96)
         v = float(np.tanh(np.abs(feats).mean()))
         return np.array([[1.0 - v, v]])
+
+
+def _flatten_features(x):                       # custom_verifier_model.py:91-92
+    return [i.flatten() for i in x]
+
+
+def _trained_verifier(seed=0):
+    """The pipeline custom_verifier_model.train_verifier_model builds (custom_verifier_model.py:95-113), fitted on random data."""
+    from sklearn.linear_model import LogisticRegression
+    from sklearn.pipeline import make_pipeline
+    from sklearn.preprocessing import FunctionTransformer, StandardScaler
+    r = np.random.default_rng(seed)
+    X = r.normal(0, 4.0, (60, 16, 96)).astype(np.float32)
+    y = (X[:, :, :8].mean(axis=(1, 2)) > 0).astype(int)
+    clf = LogisticRegression(random_state=0, max_iter=2000, C=0.001)
+    pipe = make_pipeline(FunctionTransformer(_flatten_features), StandardScaler(), clf)
+    pipe.fit(X, y)
+    return pipe
+
+
+def test_fold_verifier_equals_predict_proba():
+    from openwakeword_amd.model import fold_verifier
+    pipe = _trained_verifier()
+    w, b = fold_verifier(pipe)
+    X = np.random.default_rng(5).normal(0, 4.0, (7, 16, 96)).astype(np.float32)
+    want = pipe.predict_proba(X)[:, -1]
+    got = 1.0 / (1.0 + np.exp(-(X.reshape(7, -1).astype(np.float64) @ w.astype(np.float64) + b)))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        fold_verifier(object())
+
+
+@gpu
+def test_batched_custom_verifier_on_device(golden):
+    """(f)4: the verifier of model.py:320-328 for every stream of a BatchedModel, as one dot product per stream on the device,
+    against OracleModel with the scikit-learn pipeline wrapped around its head function."""
+    from openwakeword_amd import BatchedModel
+    pipe = _trained_verifier()
+    names = ["alexa", "hey_mycroft"]
+    w = _weights(names)
+    thr = 0.1
+    S, n_frames = 5, 12
+    pcm = np.stack([np.resize(golden["pcm/" + k], n_frames * 1280) for k in ("alexa_test", "hey_mycroft_test", "hey_jane", "alexa_test", "hey_jane")])
+    pcm[3] = np.roll(pcm[3], 4000); pcm[4] //= 3
+    noise = W.synthetic_pcm(1, 64000, seed=3, rms=600.0)[0]
+
+    def verified(head):
+        def fn(x):
+            sc = O.head_stage(x, head, np.float32)
+            if sc[0, 0] >= thr:
+                sc = np.array([[pipe.predict_proba(x)[0][-1]]], np.float32)
+            return [sc]
+        return fn
+
+    bm = BatchedModel(S, names, weights=w)
+    try:
+        bm.set_custom_verifier("alexa", pipe, threshold=thr)
+        with pytest.raises(ValueError, match="not matched"):
+            bm.set_custom_verifier("no_such_model", pipe)
+        models = [O.OracleModel(w["heads"], w["embedding"], init_noise=noise,
+                                head_fns={"alexa": verified(w["heads"]["alexa"]),
+                                          "hey_mycroft": (lambda x, _h=w["heads"]["hey_mycroft"]: [O.head_stage(x, _h, np.float32)])})
+                  for _ in range(S)]
+        bm.reset(None, models[0].preprocessor.features[-bm.engine.feature_ring:])
+        n_rescored = 0
+        for t in range(n_frames):
+            x = pcm[:, t * 1280:(t + 1) * 1280]
+            got = bm.predict_batch(x)
+            for s, m in enumerate(models):
+                pred = m.predict(x[s])
+                np.testing.assert_allclose(got[s], [pred[k] for k in names], rtol=0, atol=1e-4, err_msg=f"stream {s} frame {t}")
+            plain = np.array([O.head_stage(m.preprocessor.get_features(16), w["heads"]["alexa"], np.float32)[0, 0] for m in models])
+            n_rescored += int((plain >= thr).sum())
+        assert n_rescored > 0
+        bm.set_custom_verifier("alexa", None)                    # removed: plain head scores again
+        got = bm.predict_batch(pcm[:, :1280])
+        for s, m in enumerate(models):
+            m.head_fns["alexa"] = (lambda x, _h=w["heads"]["alexa"]: [O.head_stage(x, _h, np.float32)])
+            pred = m.predict(pcm[s, :1280])
+            np.testing.assert_allclose(got[s], [pred[k] for k in names], rtol=0, atol=1e-4)
+    finally:
+        bm.close()
 
 
 @gpu
