@@ -26,6 +26,9 @@ using owr::f32x4;
 #ifndef OWF_I16_STAGE
 #define OWF_I16_STAGE 0    // 1: sample window staged in LDS as raw int16 -- measured SLOWER (stage 2.26 vs 2.17 ms: 16 ds_read_i16 + more spills); kept as an A/B switch
 #endif
+#ifndef OWF_B128_STAGE
+#define OWF_B128_STAGE 1   // float staging with two ds_write_b128 per lane (0: scalar stores, paired by the compiler into ds_write2_b32)
+#endif
 #ifndef OWF_WG
 #define OWF_WG 12          // waves per workgroup (one workgroup per CU: 3 waves per SIMD)
 #endif
@@ -164,9 +167,16 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 if (i < owk::MEL_WX) *reinterpret_cast<int4*>(sx + i) = raw[u];
 #else
                 if (i < owk::MEL_WX) {
+                    // two 16-byte stores per lane (2-way bank conflicts) instead of the eight scalar ones the compiler pairs into
+                    // ds_write2_b32 at a stride of 8 floats (8-way conflicts: a quarter of this kernel's LDS-active cycles)
                     const int16_t* h = reinterpret_cast<const int16_t*>(&raw[u]);
+#if OWF_B128_STAGE
+                    *reinterpret_cast<f32x4*>(sx + i) = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                    *reinterpret_cast<f32x4*>(sx + i + 4) = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+#else
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sx[i + e] = (float)h[e];
+#endif
                 }
 #endif
             }

@@ -26,12 +26,16 @@ using owh::lanemask_t;
 using owh::Op;
 using owr::f32x4;
 
-constexpr int V_WG = 8;                   // waves per workgroup of the front kernel
+#ifndef OWV_WG
+#define OWV_WG 12
+#endif
+constexpr int V_WG = OWV_WG;              // waves per workgroup of the front kernel (12: one workgroup per CU, 3 waves per SIMD)
 constexpr int V_FEAT_STRIDE = 144;        // floats per staged feature row (128 bins + 16: the gather of 16 lanes x 16 B is conflict-free)
 // encoder weight blocks of 1 KB in LDS: layer l = [oct][tap][ks][part]
 constexpr int V_BLK1 = 1 * 3 * 4 * 2, V_BLK2 = 2 * 3 * 1 * 2, V_BLK3 = 2 * 3 * 1 * 2, V_BLK4 = 4 * 3 * 1 * 2;
 constexpr int V_WFLOATS = (V_BLK1 + V_BLK2 + V_BLK3 + V_BLK4) * 256;
-constexpr int V_WAVE_FLOATS = 640 + 2 * 576 + 4 * V_FEAT_STRIDE;       // samples (1280 int16) + FFT planes + feature staging
+constexpr int V_WAVE_FLOATS = 640 + 2 * 576;       // samples (1280 int16) + FFT planes (the feature staging rows alias the re plane)
+static_assert(4 * V_FEAT_STRIDE <= 576, "feature rows fit the re plane");
 constexpr int V_LDS_BYTES = (V_WFLOATS + 4 * 64 + 256 + V_WG * V_WAVE_FLOATS) * 4;
 
 struct VadFrontParams {
@@ -102,7 +106,7 @@ __device__ __forceinline__ void vad_fetch(const VadFrontParams& p, int s, int la
     }
 }
 
-__global__ __launch_bounds__(64 * V_WG, 2) void vad_front_kernel(VadFrontParams p) {
+__global__ __launch_bounds__(64 * V_WG, (V_WG + 3) / 4) void vad_front_kernel(VadFrontParams p) {
     using owk::dft8;
     using owk::wave_sync;
     extern __shared__ __attribute__((aligned(16))) float vlds[];
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(64 * V_WG, 2) void vad_front_kernel(VadFrontParams 
     int16_t* sx = reinterpret_cast<int16_t*>(mine);                   // 1280 samples
     float* xr = mine + 640;                                         // FFT planes (re, im), 576 floats each
     float* xi = xr + 576;
-    float* sF = xi + 576;                                           // features of the pass's four frames [4][V_FEAT_STRIDE]
+    float* sF = xr;                                                 // features of the pass's four frames [4][V_FEAT_STRIDE]: written over the
+                                                                    // re plane once every lane has read its spectrum values
     for (int i = tid; i < V_WFLOATS / 4; i += 64 * V_WG) reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
     for (int i = tid; i < 4 * 64; i += 64 * V_WG) sB[i] = p.bias[i];
     for (int i = tid; i < 256; i += 64 * V_WG) sHann[i] = p.hann[i];
@@ -218,13 +223,21 @@ __global__ __launch_bounds__(64 * V_WG, 2) void vad_front_kernel(VadFrontParams 
             }
             wave_sync();
             // two real spectra per complex FFT: |A[k]|, |B[k]| for k = 1..128, compressed; 4 frames x 128 bins over 64 lanes
+            float fa[4], fb[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = it * 64 + lane, f = idx >> 7, kb = idx & 127, k = kb + 1;
                 const float zr_ = xr[f * 256 + k], zi_ = xi[f * 256 + k], yr_ = xr[f * 256 + 256 - k], yi_ = xi[f * 256 + 256 - k];
                 const float ar = zr_ + yr_, ai = zi_ - yi_, br = zi_ + yi_, bi = zr_ - yr_;
-                sF[(2 * f) * V_FEAT_STRIDE + kb] = __logf(1.0f + p.mag_gain * 0.5f * sqrtf(ar * ar + ai * ai));
-                sF[(2 * f + 1) * V_FEAT_STRIDE + kb] = __logf(1.0f + p.mag_gain * 0.5f * sqrtf(br * br + bi * bi));
+                fa[it] = __logf(1.0f + p.mag_gain * 0.5f * sqrtf(ar * ar + ai * ai));
+                fb[it] = __logf(1.0f + p.mag_gain * 0.5f * sqrtf(br * br + bi * bi));
+            }
+            wave_sync();                             // every spectrum value has been read: the re plane becomes the staging rows
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane, f = idx >> 7, kb = idx & 127;
+                sF[(2 * f) * V_FEAT_STRIDE + kb] = fa[it];
+                sF[(2 * f + 1) * V_FEAT_STRIDE + kb] = fb[it];
             }
             wave_sync();
             if ((pos >> 2) == q) {                   // the 16 lanes whose tile position is one of this pass's frames take their operands
