@@ -106,8 +106,23 @@ bool hx_in_range(const float* w, size_t n) {
     return true;
 }
 
+// Half channel tiles of the fp16-split family (24 = 16 + 8, 72 = 64 + 8 channels).  The MFMA D layout puts row 4j + e of a tile into
+// register e of lane group j; with the natural order the 8 real channels of the last tile would sit in registers 0..3 of lane groups
+// 0, 1 and no register would be all padding.  The f16-split kernels instead place them in registers 0, 1 of ALL four lane groups:
+//     row 4j + e of the half tile  <->  channel 16 ct + 2j + e   (e < 2),   rows with e >= 2: padding
+// so that registers 2, 3 of that tile are identically zero and their epilogue, operand split, loads and stores can be skipped.
+// The same order is the K order of the layer that consumes the tile (operand halves q % 4 = e of lane group g = j), of the folded
+// BatchNorm arrays and of the debug dump (owh::dump_tile_ht).
+inline int hx_row_channel(int tile, int row, int C) {            // channel in row `row` (0..15) of channel tile `tile`, or -1
+    const bool half = C % 16 == 8 && tile == (C + 15) / 16 - 1;
+    if (!half) { const int c = tile * 16 + row; return c < C ? c : -1; }
+    const int j = row >> 2, e = row & 3;
+    return e < 2 ? tile * 16 + 2 * j + e : -1;
+}
+
 // fp16-split operand order (owwhip_hx.h): blocks [oct][tap][ks][part hi/lo] of 64 lanes x 8 halves; lane (i, g), half q
-// <-> weight of input channel 16*(2ks + q/4) + 4g + q%4 and output channel 16oct + i, pre-scaled by 2^8
+// <-> weight of the input channel in row 4g + q%4 of channel tile 2ks + q/4 and the output channel in row i of tile oct
+// (hx_row_channel), pre-scaled by 2^8
 void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
     const int ks_n = ((cin + 15) / 16 + 1) / 2, ncto = (cout + 15) / 16;
     std::vector<_Float16> hbuf((size_t)ncto * ntaps * ks_n * 2 * 64 * 8, (_Float16)0.f);
@@ -117,8 +132,9 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                 for (int lane = 0; lane < 64; ++lane)
                     for (int q = 0; q < 8; ++q) {
                         const int i = lane & 15, g = lane >> 4;
-                        const int ci = 16 * (2 * ks + q / 4) + 4 * g + q % 4, co = oct * 16 + i;
-                        if (ci >= cin || co >= cout) continue;
+                        const int ci = 2 * ks + q / 4 < (cin + 15) / 16 ? hx_row_channel(2 * ks + q / 4, 4 * g + q % 4, cin) : -1;
+                        const int co = hx_row_channel(oct, i, cout);
+                        if (ci < 0 || co < 0) continue;
                         const float v = w[((size_t)tap * cin + ci) * cout + co] * owh::WSCALE;
                         const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
                         const size_t blk = (((size_t)oct * ntaps + tap) * ks_n + ks) * 2;
@@ -127,6 +143,13 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                     }
     out.assign(hbuf.size() / 2, 0.f);
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
+}
+// per-channel array (folded BatchNorm scale / shift) in the row order of the f16-split tiles, zero in padding rows
+void pad_hx_rows(const float* v, int C, float mul, std::vector<float>& out) {
+    const int nct = (C + 15) / 16;
+    out.assign((size_t)nct * 16, 0.f);
+    for (int t = 0; t < nct; ++t)
+        for (int r = 0; r < 16; ++r) { const int c = hx_row_channel(t, r, C); if (c >= 0) out[t * 16 + r] = v[c] * mul; }
 }
 // heads layer 1 (owh::heads_hx_kernel): k-step major [K/32][NH/16][part][64][8]; lane (i, g), half q <-> input 32ks + 8g + q
 void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, std::vector<float>& out) {
@@ -152,8 +175,8 @@ void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out) {
     for (int oct = 0; oct < 2; ++oct)
         for (int lane = 0; lane < 64; ++lane)
             for (int q = 0; q < 8; ++q) {
-                const int i = lane & 15, g = lane >> 4, k = 8 * g + q, co = oct * 16 + i;
-                if (k >= 9 || co >= 24) continue;
+                const int i = lane & 15, g = lane >> 4, k = 8 * g + q, co = hx_row_channel(oct, i, 24);
+                if (k >= 9 || co < 0) continue;
                 const float v = w[k * 24 + co] * owh::WSCALE;
                 const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
                 hbuf[((size_t)(oct * 2 + 0) * 64 + lane) * 8 + q] = hi;
@@ -898,11 +921,13 @@ int oww_commit(oww_ctx* h) {
             if (l < 19) {
                 // zero padded to whole 16-channel tiles: the register-resident kernels evaluate the pad channels (as zeros)
                 std::vector<float> pad((size_t)(L.cout + 15) / 16 * 16, 0.f);
-                memcpy(pad.data(), q, L.cout * sizeof(float));
-                if (h->hx) for (float& v : pad) v *= owh::WUNSCALE;          // the f16-split weights carry a factor 2^8
+                if (h->hx) pad_hx_rows(q, L.cout, owh::WUNSCALE, pad);       // tile row order; the f16-split weights carry a factor 2^8
+                else memcpy(pad.data(), q, L.cout * sizeof(float));
                 o_scale[l] = hb.add(pad); q += L.cout;
                 std::fill(pad.begin(), pad.end(), 0.f);
-                memcpy(pad.data(), q, L.cout * sizeof(float)); o_shift[l] = hb.add(pad); q += L.cout;
+                if (h->hx) pad_hx_rows(q, L.cout, 1.0f, pad);
+                else memcpy(pad.data(), q, L.cout * sizeof(float));
+                o_shift[l] = hb.add(pad); q += L.cout;
             }
         }
     }

@@ -26,6 +26,9 @@ using owr::f32x4;
 #ifndef OWF_I16_STAGE
 #define OWF_I16_STAGE 0    // 1: sample window staged in LDS as raw int16 -- measured SLOWER (stage 2.26 vs 2.17 ms: 16 ds_read_i16 + more spills); kept as an A/B switch
 #endif
+#ifndef OWF_T_STAGE
+#define OWF_T_STAGE 0      // 1: transposed float staging [8][89] (A/B switch)
+#endif
 #ifndef OWF_B128_STAGE
 #define OWF_B128_STAGE 1   // float staging with two ds_write_b128 per lane (0: scalar stores, paired by the compiler into ds_write2_b32)
 #endif
@@ -53,7 +56,7 @@ constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16
 constexpr int FA_OFF_Z = FA_OFF_MEL + FA_WG * FA_MT + ((4 - (FA_WG * FA_MT) % 4) % 4);
 constexpr int FA_LDS_BYTES = (FA_OFF_Z + FA_WG * FA_Z) * 4;
 static_assert(FA_OFF_Z % 4 == 0 && FA_OFF_W1 % 4 == 0 && FA_OFF_W2 % 4 == 0, "16-byte aligned operand blocks");
-static_assert(owk::MEL_WX <= FA_Z, "sample window fits the transpose planes");
+static_assert(owk::MEL_WX <= FA_Z && 8 * 89 <= FA_Z, "sample window fits the transpose planes");
 
 // the 672 (+8) samples of pass f2 (frames 2 f2, 2 f2 + 1) of [tail(480) ; pcm(1280)] as raw int16 (lane l: samples 8l.., 512 + 8l..):
 // every piece of 8 samples lies wholly in the tail or wholly in the chunk, and both rows are 16-byte aligned (the host checks)
@@ -170,7 +173,12 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                     // two 16-byte stores per lane (2-way bank conflicts) instead of the eight scalar ones the compiler pairs into
                     // ds_write2_b32 at a stride of 8 floats (8-way conflicts: a quarter of this kernel's LDS-active cycles)
                     const int16_t* h = reinterpret_cast<const int16_t*>(&raw[u]);
-#if OWF_B128_STAGE
+#if OWF_T_STAGE
+                    // transposed window [8][89]: sample 8 m + e at row e, column m -- the writes of a lane go to eight rows (each
+                    // store instruction covers consecutive columns: conflict-free), the strided reads below stay nearly conflict-free
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sx[e * 89 + (i >> 3)] = (float)h[e];
+#elif OWF_B128_STAGE
                     *reinterpret_cast<f32x4*>(sx + i) = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                     *reinterpret_cast<f32x4*>(sx + i + 4) = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
 #else
@@ -188,8 +196,13 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 const int n = 64 * n2 + lane;
                 const bool in = (n >= 56) && (n < 456);
                 const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
+#if OWF_T_STAGE
+                re[n2] = w * sx[(n & 7) * 89 + (n >> 3)];
+                im[n2] = w * sx[(n & 7) * 89 + 20 + (n >> 3)];
+#else
                 re[n2] = w * (float)sx[n];
                 im[n2] = w * (float)sx[160 + n];
+#endif
             }
             dft8(re, im);
 #pragma unroll

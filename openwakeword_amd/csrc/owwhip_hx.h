@@ -124,14 +124,100 @@ __device__ __forceinline__ void pin_op(Op& o) {
     o.h = __builtin_bit_cast(f16x8, a); o.l = __builtin_bit_cast(f16x8, b);
 }
 
-// operand form of a whole fp32 tile (NCT channel tiles -> KS = ceil(NCT/2) k-steps; an odd last tile pairs with zeros)
-template <int NCT>
-__device__ __forceinline__ void to_ops(const f32x4 (&t)[NCT], Op (&o)[(NCT + 1) / 2]) {
+// the same for a k-step of which only the first NP (1..3) of the four packed pairs carry channels: (a0 a1)(a2 a3)(b0 b1)(b2 b3);
+// the others are zero operands and cost nothing (an odd last channel tile pairs with nothing: NP = 2; a HALF last tile -- see
+// pack_hx in owwhip.hip: its registers 2, 3 are padding -- ends the list one pair earlier)
+template <int NP>
+__device__ __forceinline__ Op split_some(const f32x4 a, const f32x4 b) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < (NCT + 1) / 2; ++k) {
-        o[k] = split_pair(t[2 * k], 2 * k + 1 < NCT ? t[2 * k + 1] : f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int v = 0; v < NP; ++v) {
+        const float x0 = v < 2 ? a[2 * v] : b[2 * v - 4], x1 = v < 2 ? a[2 * v + 1] : b[2 * v - 3];
+        const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)x0, (_Float16)x1});
+        unsigned lp;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(lp) : "v"(hp), "v"(x0), "v"(x1));
+        h[v] = hp; l[v] = lp;
+    }
+    Op o;
+    o.h = __builtin_bit_cast(f16x8, h);
+    o.l = __builtin_bit_cast(f16x8, l);
+    return o;
+}
+
+// operand form of a whole fp32 tile (NCT channel tiles -> KS = ceil(NCT/2) k-steps; an odd last tile pairs with zeros).
+// HALF: the last channel tile is a half tile (8 channels in its registers 0, 1).
+template <int NCT, bool HALF = false>
+__device__ __forceinline__ void to_ops(const f32x4 (&t)[NCT], Op (&o)[(NCT + 1) / 2]) {
+    constexpr int KS = (NCT + 1) / 2;
+    constexpr int NP_LAST = (NCT % 2 ? 2 : 4) - (HALF ? 1 : 0);       // valid pairs of the last k-step
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const f32x4 b = 2 * k + 1 < NCT ? t[2 * k + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k == KS - 1 && NP_LAST < 4) o[k] = split_some<NP_LAST>(t[2 * k], b);
+        else o[k] = split_pair(t[2 * k], b);
         pin_op(o[k]);
     }
+}
+
+// register-dump I/O of the f16-split family: like owr::load_tile / store_tile, minus the two padding registers of a half last tile
+template <int NCT, bool HALF>
+__device__ __forceinline__ void load_tile_h(f32x4 (&t)[NCT], const float* __restrict__ base, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#ifdef OWR_EXP_NOLOAD
+            t[ct][e] = (float)(lane + ct * 4 + e) * 1e-3f;
+#else
+            if (HALF && ct == NCT - 1 && e >= 2) t[ct][e] = 0.f;
+            else t[ct][e] = base[(ct * 4 + e) * 64 + lane];
+#endif
+        }
+}
+template <int NCT, bool HALF>
+__device__ __forceinline__ void store_tile_h(const f32x4 (&t)[NCT], float* __restrict__ base, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (HALF && ct == NCT - 1 && e >= 2) continue;
+#ifdef OWR_EXP_NOSTORE
+            if (t[ct][e] == 12345.678f) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
+#else
+            base[(ct * 4 + e) * 64 + lane] = t[ct][e];
+#endif
+        }
+}
+
+// folded BatchNorm + activation of one output tile; HALF: registers 2, 3 are padding and stay zero
+template <bool BN, bool HALF>
+__device__ __forceinline__ f32x4 bn_act_t(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift, int oct, int j) {
+    if (!HALF) return bn_act<BN>(v, scale, shift, oct, j);
+    if (!BN) return f32x4{v[0], v[1], 0.f, 0.f};
+    const float s0 = scale[oct * 16 + 4 * j], s1 = scale[oct * 16 + 4 * j + 1];
+    const float h0 = shift[oct * 16 + 4 * j], h1 = shift[oct * 16 + 4 * j + 1];
+    return f32x4{owr::leaky_clamp(v[0] * s0 + h0), owr::leaky_clamp(v[1] * s1 + h1), 0.f, 0.f};
+}
+
+// debug dump of the f16-split family (cf. owr::dump_tile): a half last tile keeps channel 16 ct + 2j + e in register e < 2
+template <int NCT, int F, int C>
+__device__ __forceinline__ void dump_tile_ht(const f32x4 (&t)[NCT], float* __restrict__ dbg, size_t stride, int off, int s_first,
+                                             int row, int S, int lane) {
+    const int pos = lane & 15, j = lane >> 4;
+    const int sp = pos / F, f = pos % F, s = s_first + sp;
+    if (s >= S) return;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int c = ct * 16 + 4 * j + e;
+            if (C % 16 == 8 && ct == NCT - 1) c = e < 2 ? ct * 16 + 2 * j + e : C;
+            if (c < C) dbg[(size_t)s * stride + off + (row * F + f) * C + c] = t[ct][e];
+        }
 }
 
 __device__ __forceinline__ f16x8 lds_h(const float* buf, int blk, int lane) {
@@ -191,7 +277,7 @@ using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
 // chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
 // 1x3 (mel) layer: NT tiles in operand form -> NT fp32 D tiles (BatchNorm + activation applied)
-template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG>
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
@@ -218,7 +304,10 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 else {
 #pragma unroll
 #if OWH_MASKSEL
-                    for (int e = 0; e < 4; ++e) { const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && mfirst == 0.f) ? 0.f : l; }
+                    for (int e = 0; e < 4; ++e) {
+                        if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
+                        const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && mfirst == 0.f) ? 0.f : l;
+                    }
 #else
                     for (int e = 0; e < 4; ++e) acc[t][e] = F < 16 ? dpp_shr1_zero(accs[0][t][e]) * mfirst : dpp_shr1_zero(accs[0][t][e]);
 #endif
@@ -242,6 +331,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
 #if OWH_MASKSEL
+                        if (HOUT && oct == NCTO - 1 && e >= 2) { res[t][e] = 0.f; continue; }
                         const float hh = dpp_shl1_zero(accs[1][t][e]);
                         res[t][e] = acc[t][e] + ((F < 16 && mlast == 0.f) ? 0.f : hh);
 #else
@@ -258,7 +348,11 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
         }
 #endif
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j); pin(out[t][oct]); }
+        for (int t = 0; t < NT; ++t) {
+            if (HOUT && oct == NCTO - 1) out[t][oct] = bn_act_t<BN, true>(res[t], scale, shift, oct, j);
+            else out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j);
+            pin(out[t][oct]);
+        }
         OWH_OCT_SB();
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
     }
@@ -274,7 +368,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #ifndef OWH_PIPE_VALU
 #define OWH_PIPE_VALU 2
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane,
@@ -321,7 +415,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (BN) out[r][oct - 1] = bn_act<true>(prev[r], scale, shift, oct - 1, j);
+                if (BN && HOUT && oct == NCTO) out[r][oct - 1] = bn_act_t<true, true>(prev[r], scale, shift, oct - 1, j);
+                else if (BN) out[r][oct - 1] = bn_act<true>(prev[r], scale, shift, oct - 1, j);
                 else out[r][oct - 1] = prev[r] * post;
                 pin(out[r][oct - 1]);
             }
@@ -363,6 +458,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
     lanemask_t bad = 0;
+#ifdef OWH_SETPRIO
+    if (wave & 1) __builtin_amdgcn_s_setprio(OWH_SETPRIO);        // (A/B: static priority for half the waves of a SIMD)
+#endif
     issue_chunk<NBA, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
@@ -380,66 +478,66 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         f32x4 X[NCTI];
-        load_tile<NCTI>(X, p.xin + ((size_t)g * C::R + pass * R + r) * (NCTI * 4 * 64), lane);
-        to_ops<NCTI>(X, Xo[r]);
+        load_tile_h<NCTI, C::HIN>(X, p.xin + ((size_t)g * C::R + pass * R + r) * (NCTI * 4 * 64), lane);
+        to_ops<NCTI, C::HIN>(X, Xo[r]);
     }
     if (pass == 0) chunk_sync();
 
     // conv a: 1x3, CIN -> C
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NB, WG>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NB, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
     }
     Op Ao[R][KS], H0[KS], H1[KS];
     {
         f32x4 T0[NCT], T1[NCT];
-        load_tile<NCT>(T0, hb, lane);
-        load_tile<NCT>(T1, hb + NCT * 4 * 64, lane);
-        to_ops<NCT>(T0, H0);
-        to_ops<NCT>(T1, H1);
+        load_tile_h<NCT, C::HOUT>(T0, hb, lane);
+        load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane);
+        to_ops<NCT, C::HOUT>(T0, H0);
+        to_ops<NCT, C::HOUT>(T1, H1);
     }
     if (active) {
-        store_tile<NCT>(Y[R - 2], hb, lane);
-        store_tile<NCT>(Y[R - 1], hb + NCT * 4 * 64, lane);
+        store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
+        store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
+    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NB, WG>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NB, WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
+    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB, WG>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
     }
     {
         f32x4 T0[NCT], T1[NCT];
-        load_tile<NCT>(T0, hd, lane);
-        load_tile<NCT>(T1, hd + NCT * 4 * 64, lane);
-        to_ops<NCT>(T0, H0);
-        to_ops<NCT>(T1, H1);
+        load_tile_h<NCT, C::HOUT>(T0, hd, lane);
+        load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane);
+        to_ops<NCT, C::HOUT>(T0, H0);
+        to_ops<NCT, C::HOUT>(T1, H1);
     }
     if (active) {
-        store_tile<NCT>(Y[R - 2], hd, lane);
-        store_tile<NCT>(Y[R - 1], hd + NCT * 4 * 64, lane);
+        store_tile_h<NCT, C::HOUT>(Y[R - 2], hd, lane);
+        store_tile_h<NCT, C::HOUT>(Y[R - 1], hd + NCT * 4 * 64, lane);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) to_ops<NCT>(Y[r], Ao[r]);
+    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
     }
 
     if (!LAST && active) {
@@ -457,6 +555,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    if (C::HOUT && ct == NCT - 1 && e >= 2) { pm[ct][e] = 0.f; continue; }      // padding registers of the half tile
                     float m = Y[ro * C::PT][ct][e];
                     if (C::PT == 2) m = fmax_nc(m, Y[ro * C::PT + 1][ct][e]);
                     pm[ct][e] = fmax_nc(m, dpp_shl1_zero(m));
@@ -466,7 +565,8 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xo[(ct * 4 + e) * 64] = pm[ct][e];
+                    for (int e = 0; e < 4; ++e)
+                        if (!(C::HOUT && ct == NCT - 1 && e >= 2)) xo[(ct * 4 + e) * 64] = pm[ct][e];
             }
         }
     }
@@ -550,7 +650,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { load_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane); to_ops<2>(Yf[r][h], Yh[r][h]); }
+        for (int h = 0; h < 2; ++h) { load_tile_h<2, true>(Yf[r][h], h2 + (r * 2 + h) * 512, lane); to_ops<2, true>(Yf[r][h], Yh[r][h]); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                 // rows 2q, 2q+1
         OWR_SB();
@@ -572,12 +672,13 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
                 acc = OWH_MFMA(ah, b.l, acc);
                 acc = OWH_MFMA(al, b.h, acc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmax_nc(acc[e], 0.f);
-                Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
+                for (int e = 0; e < (oct == 1 ? 2 : 4); ++e) acc[e] = fmax_nc(acc[e], 0.f);       // (tile 1 = the half tile: 8 channels)
+                if (oct == 1) Y0[oct] = bn_act_t<true, true>(acc, bn, bn + 32, oct, j);
+                else Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
                 pin(Y0[oct]);
             }
-            if (DBG && p.dbg) dump_tile<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
-            to_ops<2>(Y0, Y0o[t]);
+            if (DBG && p.dbg) dump_tile_ht<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
+            to_ops<2, true>(Y0, Y0o[t]);
         }
         // ---- conv1: 1x3 over two half-row tiles with carries across the seam
         f32x4 Y1[4][2];
@@ -592,8 +693,10 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
                     if (ti < 2) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                     else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < 4; ++e) {
+                            if (oct == 1 && e >= 2) { acc[1][t][e] = 0.f; continue; }
                             acc[1][t][e] = (t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]);
+                        }
                     }
                 }
                 const f16x8 ah = lds_h(w1s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + tap) * 2 + 1, lane);
@@ -610,12 +713,18 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
                 f32x4 r0, r1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    if (oct == 1 && e >= 2) { r0[e] = 0.f; r1[e] = 0.f; continue; }
                     r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
                     r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
                 }
                 if (oct == 0) { nan_guard(bad, r0[0]); nan_guard(bad, r1[0]); }
-                Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
-                Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
+                if (oct == 1) {
+                    Y1[t0][oct] = bn_act_t<true, true>(r0, bn + 64, bn + 96, oct, j);
+                    Y1[t1][oct] = bn_act_t<true, true>(r1, bn + 64, bn + 96, oct, j);
+                } else {
+                    Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
+                    Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
+                }
                 pin(Y1[t0][oct]); pin(Y1[t1][oct]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -623,11 +732,11 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
         if (DBG && p.dbg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                dump_tile<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+                dump_tile_ht<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
         }
         Op Y1o[4][1];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) to_ops<2>(Y1[t], Y1o[t]);
+        for (int t = 0; t < 4; ++t) to_ops<2, true>(Y1[t], Y1o[t]);
         // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1]
         f32x4 Y2[4][2];
 #pragma unroll
@@ -652,13 +761,17 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
                 for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j); pin(Y2[t][oct]); }
+            for (int t = 0; t < 4; ++t) {
+                if (oct == 1) Y2[t][oct] = bn_act_t<true, true>(acc[t], bn + 128, bn + 160, oct, j);
+                else Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j);
+                pin(Y2[t][oct]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (DBG && p.dbg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                dump_tile<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+                dump_tile_ht<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -675,6 +788,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    if (ct == 1 && e >= 2) { pm[h][ct][e] = 0.f; continue; }
                     const float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
                     pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m));
                 }
@@ -684,13 +798,14 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xo[(ct * 4 + e) * 64 + h * 8] = pm[h][ct][e];
+                    for (int e = 0; e < 4; ++e)
+                        if (!(ct == 1 && e >= 2)) xo[(ct * 4 + e) * 64 + h * 8] = pm[h][ct][e];
         }
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) store_tile<2>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
+        for (int h = 0; h < 2; ++h) store_tile_h<2, true>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
     hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
 }
 
