@@ -144,6 +144,38 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
     out.assign(hbuf.size() / 2, 0.f);
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
 }
+// K-merged 3x1 (time) layer of a stage with an odd number of channel tiles (owh::conv_time_hxm): per output tile the blocks
+// [tap][full k-step][part], then [merged k-step][part]; merged k-step mk, lane (i, g), half q: pair index pi = 4 mk + q/2 carries
+// tap pi / NPR, pair v = pi % NPR of the remainder tile, i.e. its row 4g + 2v + q%2
+void pack_hx_tm(const float* w, int cin, int cout, std::vector<float>& out) {
+    const int ncti = (cin + 15) / 16, ncto = (cout + 15) / 16;
+    const bool half = cin % 16 == 8;
+    const int ksf = ncti / 2, npr = half ? 1 : 2, nmk = (3 * npr + 3) / 4, nb = (3 * ksf + nmk) * 2;
+    std::vector<_Float16> hbuf((size_t)ncto * nb * 64 * 8, (_Float16)0.f);
+    auto put = [&](size_t blk, int lane, int q, int tap, int ci, int co) {
+        if (ci < 0 || co < 0) return;
+        const float v = w[((size_t)tap * cin + ci) * cout + co] * owh::WSCALE;
+        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        hbuf[(blk * 64 + lane) * 8 + q] = hi;
+        hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
+    };
+    for (int oct = 0; oct < ncto; ++oct)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int q = 0; q < 8; ++q) {
+                const int i = lane & 15, g = lane >> 4, co = hx_row_channel(oct, i, cout);
+                for (int tap = 0; tap < 3; ++tap)
+                    for (int ks = 0; ks < ksf; ++ks)
+                        put(((size_t)oct * nb) + (tap * ksf + ks) * 2, lane, q, tap, hx_row_channel(2 * ks + q / 4, 4 * g + q % 4, cin), co);
+                for (int mk = 0; mk < nmk; ++mk) {
+                    const int pi = 4 * mk + q / 2;
+                    if (pi >= 3 * npr) continue;
+                    const int tap = pi / npr, v = pi % npr;
+                    put(((size_t)oct * nb) + (3 * ksf + mk) * 2, lane, q, tap, hx_row_channel(ncti - 1, 4 * g + 2 * v + q % 2, cin), co);
+                }
+            }
+    out.assign(hbuf.size() / 2, 0.f);
+    memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
+}
 // per-channel array (folded BatchNorm scale / shift) in the row order of the f16-split tiles, zero in padding rows
 void pad_hx_rows(const float* v, int C, float mul, std::vector<float>& out) {
     const int nct = (C + 15) / 16;
@@ -902,7 +934,11 @@ int oww_commit(oww_ctx* h) {
             if (!h->mfma) o_conv[l] = hb.add(q, nw);
             else if (h->hx) {
                 if (!hx_in_range(q, nw)) return fail(OWW_EINVAL, "conv layer %d: weight magnitude too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1", l);
-                if (l == 0) pack_hx_conv0(q, pk); else pack_hx(q, 3, L.cin, L.cout, pk);
+                const bool time_merged = OWH_KMERGE && L.kh == 3 && L.kw == 1 && ((L.cin + 15) / 16) % 2 == 1 &&
+                                         (L.cin % 16 == 8 || OWH_KMERGE_B);                     // stage C (and B): layers b, d
+                if (l == 0) pack_hx_conv0(q, pk);
+                else if (time_merged) pack_hx_tm(q, L.cin, L.cout, pk);
+                else pack_hx(q, 3, L.cin, L.cout, pk);
                 o_conv[l] = hb.add(pk);
             }
             else if (h->rr && l > 0) { pack_rr(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }

@@ -440,6 +440,137 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-merged form of the 3x1 (time) layers of stages whose channel count is not a multiple of 32 (B: 48 = 32 + 16, C: 72 = 64 + 8).
+// A k-step carries 32 input channels; with one k-step sequence per tap the remainder tile of every tap costs a whole, mostly
+// empty k-step (B: 16 of 32 slots, C: 8 of 32).  The K order of a convolution is free, and for a TIME conv all three taps feed the
+// same accumulator, so the remainder tiles of the three taps are packed together: B 3 x 16 channels -> 2 k-steps instead of 3,
+// C 3 x 8 -> 1 instead of 3 (C: 7 k-steps per output tile instead of 9, B: 5 instead of 6: -22 % / -17 % MFMAs and weight bytes in
+// these layers).  Operand dwords (f16 pairs) of the remainder tiles are copied into the merged operands in the order
+// pair index = tap * NPR + v  (NPR = pairs per remainder tile: 2, or 1 for a half tile); pack_hx_tm (owwhip.hip) packs the weights
+// in the same order.  The 1x3 (mel) layers keep one accumulator chain per tap and cannot merge.
+// ------------------------------------------------------------------------------------------------
+#ifndef OWH_KMERGE
+#define OWH_KMERGE 1
+#endif
+#ifndef OWH_KMERGE_B
+#define OWH_KMERGE_B 0     // stage B too (48 = 32 + 16 channels: 2 merged k-steps per OUTPUT row cost 16 more registers than the 6 source
+                           // rows' separate remainder k-steps -> spills at 3 waves per SIMD); stage C (72 = 64 + 8) always
+#endif
+template <int NCT, bool HALF> struct TimeK {
+    static constexpr int KSF = NCT / 2;                         // full k-steps per tap
+    static constexpr int NPR = NCT % 2 ? (HALF ? 1 : 2) : 0;    // f16 pairs of the remainder tile
+    static constexpr int NMK = (3 * NPR + 3) / 4;               // merged k-steps for the three taps' remainders
+    static constexpr int NBLK = (3 * KSF + NMK) * 2;            // 1 KB blocks per output-channel tile
+};
+
+// operand form of a row for a time conv: the full k-steps, and the remainder tile's NPR pairs as bare dwords (hi, lo)
+struct RemPairs { unsigned h[2], l[2]; };
+template <int NCT, bool HALF>
+__device__ __forceinline__ void to_ops_time(const f32x4 (&t)[NCT], Op (&full)[TimeK<NCT, HALF>::KSF], RemPairs& rem) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int k = 0; k < NCT / 2; ++k) { full[k] = split_pair(t[2 * k], t[2 * k + 1]); pin_op(full[k]); }
+    const Op o = split_some<TimeK<NCT, HALF>::NPR>(t[NCT - 1], f32x4{0.f, 0.f, 0.f, 0.f});
+    const u32x4 oh = __builtin_bit_cast(u32x4, o.h), ol = __builtin_bit_cast(u32x4, o.l);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) { rem.h[v] = v < TimeK<NCT, HALF>::NPR ? oh[v] : 0u; rem.l[v] = v < TimeK<NCT, HALF>::NPR ? ol[v] : 0u; }
+}
+// merged operands of output row r from the remainders of rows r, r+1, r+2 (rows 0, 1 = history)
+template <int NR, int NPR, int NMK>
+__device__ __forceinline__ void merge_rems(const RemPairs (&rem)[NR + 2], Op (&M)[NR][NMK]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        u32x4 h[NMK], l[NMK];
+#pragma unroll
+        for (int mk = 0; mk < NMK; ++mk) { h[mk] = u32x4{0u, 0u, 0u, 0u}; l[mk] = u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+        for (int pi = 0; pi < 3 * NPR; ++pi) {
+            const int tap = pi / NPR, v = pi % NPR;
+            h[pi / 4][pi % 4] = rem[r + tap].h[v];
+            l[pi / 4][pi % 4] = rem[r + tap].l[v];
+        }
+#pragma unroll
+        for (int mk = 0; mk < NMK; ++mk) { M[r][mk].h = __builtin_bit_cast(f16x8, h[mk]); M[r][mk].l = __builtin_bit_cast(f16x8, l[mk]); pin_op(M[r][mk]); }
+    }
+}
+
+template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
+__device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1)[KSF], const Op (&in)[NR][KSF], const Op (&M)[NR][NMK],
+                                              f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
+                                              const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
+                                              lanemask_t& bad) {
+    using namespace owr;
+    const int j = lane >> 4;
+    constexpr int NBLK = (3 * KSF + NMK) * 2;
+    f32x4 prev[NR];
+#pragma unroll
+    for (int oct = 0; oct <= NCTO; ++oct) {
+        f32x4 acc[NR];
+        if (oct < NCTO) {
+            const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+            if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < KSF; ++ks) {
+                    const f16x8 ah = lds_h(cur, (tap * KSF + ks) * 2 + 0, lane);
+                    const f16x8 al = lds_h(cur, (tap * KSF + ks) * 2 + 1, lane);
+#pragma unroll
+                    for (int part = 0; part < 3; ++part)
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const int src = r + tap;
+                            const int ri = src >= 2 ? src - 2 : 0;
+                            const Op& b = src == 0 ? h0[ks] : (src == 1 ? h1[ks] : in[ri][ks]);
+                            acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[r]);
+                        }
+                }
+#pragma unroll
+            for (int mk = 0; mk < NMK; ++mk) {
+                const f16x8 ah = lds_h(cur, (3 * KSF + mk) * 2 + 0, lane);
+                const f16x8 al = lds_h(cur, (3 * KSF + mk) * 2 + 1, lane);
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? M[r][mk].l : M[r][mk].h, acc[r]);
+            }
+        }
+        if (oct > 0) {                                       // epilogue of the previous tile
+            if (oct == 1) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) nan_guard(bad, prev[r][0]);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (HOUT && oct == NCTO) out[r][oct - 1] = bn_act_t<BN, true>(prev[r], scale, shift, oct - 1, j);
+                else out[r][oct - 1] = bn_act<BN>(prev[r], scale, shift, oct - 1, j);
+                pin(out[r][oct - 1]);
+            }
+        }
+#if OWH_PIPE
+        if (oct > 0 && oct < NCTO) {
+#pragma unroll
+            for (int i = 0; i < 3 * (3 * KSF + NMK) * NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, OWH_PIPE_VALU, 0);
+            }
+        }
+#endif
+        if (oct < NCTO) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) prev[r] = acc[r];
+            OWH_OCT_SB();
+            if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stages B..E (parameters, geometry and memory layouts: owr::RStageParams / owr::RCfg, channel tiles NOT re-packed)
 // ------------------------------------------------------------------------------------------------
 template <class C, bool LAST, bool DBG, int WG = OWH_WG>
@@ -450,6 +581,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     constexpr int KSA = (NCTI + 1) / 2, KS = (NCT + 1) / 2;          // k-steps per tap: first layer / other layers
     constexpr int NBA = 3 * KSA * 2, NB = 3 * KS * 2;                // 1 KB blocks per chunk
     static_assert(NB * 256 <= WBUF_FLOATS, "chunk fits the LDS buffer");
+    using TK = TimeK<NCT, C::HOUT>;
+    constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
+    constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
@@ -484,12 +618,33 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if (pass == 0) chunk_sync();
 
     // conv a: 1x3, CIN -> C
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NB, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
     }
     Op Ao[R][KS], H0[KS], H1[KS];
+    if constexpr (MERGE) {
+        // conv b: 3x1 over [hist_b(2) ; Ya], K-merged form
+        Op AoF[R][TK::KSF], H0F[TK::KSF], H1F[TK::KSF], M[R][TK::NMK];
+        RemPairs rem[R + 2];
+        {
+            f32x4 T0[NCT], T1[NCT];
+            load_tile_h<NCT, C::HOUT>(T0, hb, lane);
+            load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane);
+            to_ops_time<NCT, C::HOUT>(T0, H0F, rem[0]);
+            to_ops_time<NCT, C::HOUT>(T1, H1F, rem[1]);
+        }
+        if (active) {
+            store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
+            store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
+        merge_rems<R, TK::NPR, TK::NMK>(rem, M);
+        __builtin_amdgcn_sched_barrier(0);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NB, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane, bad);
+    } else {
     {
         f32x4 T0[NCT], T1[NCT];
         load_tile_h<NCT, C::HOUT>(T0, hb, lane);
@@ -506,6 +661,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
     conv_time_hx<KS, NCT, R, true, NCT, NB, WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
+    }
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
@@ -514,11 +670,32 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NB, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
     }
+    if constexpr (MERGE) {
+        // conv d: 3x1 over [hist_d(2) ; Yc], K-merged form
+        Op AoF[R][TK::KSF], H0F[TK::KSF], H1F[TK::KSF], M[R][TK::NMK];
+        RemPairs rem[R + 2];
+        {
+            f32x4 T0[NCT], T1[NCT];
+            load_tile_h<NCT, C::HOUT>(T0, hd, lane);
+            load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane);
+            to_ops_time<NCT, C::HOUT>(T0, H0F, rem[0]);
+            to_ops_time<NCT, C::HOUT>(T1, H1F, rem[1]);
+        }
+        if (active) {
+            store_tile_h<NCT, C::HOUT>(Y[R - 2], hd, lane);
+            store_tile_h<NCT, C::HOUT>(Y[R - 1], hd + NCT * 4 * 64, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
+        merge_rems<R, TK::NPR, TK::NMK>(rem, M);
+        __builtin_amdgcn_sched_barrier(0);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBA : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3][0], sbn[3][1], wave, lane, bad);
+    } else {
     {
         f32x4 T0[NCT], T1[NCT];
         load_tile_h<NCT, C::HOUT>(T0, hd, lane);
@@ -535,6 +712,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
     conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
+    }
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
