@@ -68,6 +68,53 @@ def test_device_embed_clips_matches_oracle_and_window_path(B, n):
 
 
 @gpu
+def test_embed_calls_leave_live_streams_untouched():
+    """Since ABI 2 oww_embed / oww_embed_clips park the state of the streams they borrow (conv histories, feature ring, frame
+    counters of ALL streams) and put it back: a stream that is in the middle of an utterance continues bit-for-bit as if the
+    bulk call had not happened (they used to clobber streams [0, B))."""
+    from openwakeword_amd.engine import StreamEngine
+    emb = W.synthetic_embedding(1234)
+    heads = {"alexa": W.synthetic_head("alexa", 1234), "hey_jarvis": W.synthetic_head("hey_jarvis", 1234)}
+    S, n_frames = 11, 9
+    pcm = W.synthetic_pcm(S, 1280 * n_frames, seed=21)
+    clips = W.synthetic_pcm(7, 16000, seed=22)
+    feats0 = np.random.default_rng(3).normal(0, 1, (16, 96)).astype(np.float32)
+    runs = []
+    for interrupt in (False, True):
+        eng = StreamEngine(S, heads, emb)
+        try:
+            eng.reset(None, feats0)
+            out = []
+            for t in range(n_frames):
+                out.append(eng.step(pcm[:, 1280 * t:1280 * (t + 1)]).copy())
+                if interrupt and t in (2, 5):
+                    e = eng.embed_clips(clips)
+                    assert e.shape == (7, 3, 96) and np.isfinite(e).all()
+                if interrupt and t == 6:
+                    spec = eng.mel_clips(clips[:2]) / 10.0 + 2.0
+                    eng.embed(np.ascontiguousarray(spec[:, :76], dtype=np.float32))
+            runs.append((np.stack(out), np.stack([eng.get_features(s, 8) for s in range(S)])))
+        finally:
+            eng.close()
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+
+
+def test_batched_model_never_pairs_real_heads_with_a_synthetic_embedding():
+    """BatchedModel / bulk_predict resolve weights exactly like Model -- without the .onnx files and
+    without an explicit request for synthetic weights they refuse instead of scoring with a random-init embedding."""
+    from openwakeword_amd import BatchedModel
+    from openwakeword_amd.model import resolve_embedding, resolve_weights
+    with pytest.raises(ValueError, match="does not exist"):
+        BatchedModel(4, ["alexa"])
+    assert resolve_weights("synthetic")[0] == 1234 and resolve_weights(None) == (None, None, {})
+    with pytest.raises(ValueError, match="does not exist"):
+        resolve_embedding(None, None)
+    with pytest.raises(ValueError):
+        resolve_weights("random")
+
+
+@gpu
 def test_device_embed_clips_errors():
     from openwakeword_amd.engine import StreamEngine
     eng = StreamEngine(4, {"alexa": W.synthetic_head("alexa", 1234)}, W.synthetic_embedding(1234))

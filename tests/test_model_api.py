@@ -207,6 +207,26 @@ class _Verifier:
         return np.array([[1.0 - v, v]])
 
 
+@gpu
+def test_call_longer_than_max_chunks_is_fed_in_slices(golden):
+    """a predict() call longer than max_chunks x 1280 samples used to raise AFTER mutating the buffers and left
+    the stream stuck; it is now fed in slices (raw scores max-combined like the reference's multi-chunk rule) and the stream
+    carries on.  The reference takes any length (model.py:287-298)."""
+    from openwakeword_amd import Model
+    m = Model(wakeword_models=["alexa"], weights=_weights(["alexa"]), max_chunks=4)
+    try:
+        clip = np.resize(golden["pcm/alexa_test"], 1280 * 11)
+        for t in range(6):
+            m.predict(clip[:1280])
+        out = m.predict(clip)                           # 11 chunks > max_chunks = 4: three slices
+        assert set(out) == {"alexa"} and 0.0 <= out["alexa"] <= 1.0
+        assert m.preprocessor.accumulated_samples == 0
+        again = m.predict(clip[:1280])                  # the stream is not stuck
+        assert 0.0 <= again["alexa"] <= 1.0 and len(m.prediction_buffer["alexa"]) == 8
+    finally:
+        m.close()
+
+
 def _flatten_features(x):                       # custom_verifier_model.py:91-92
     return [i.flatten() for i in x]
 
