@@ -134,6 +134,15 @@ int  oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n);
 int  oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks,
               float* scores, int scores_on_device);
 int  oww_sync(oww_ctx* h);
+/* The same one-chunk step for the streams a serving edge actually has a full 80 ms chunk for (clients of
+ * examples/web/streaming_server.py:49-66 arrive, stall and leave independently; in the reference each of them simply does not
+ * call predict() while it has no audio).  stream_on: uint8 [S], 1 = the stream takes part: exactly oww_step for it; 0 = the
+ * stream sits the step out: none of its state moves (sample tail, conv histories, feature and score rings, frame counters,
+ * VAD state) and its row of `scores` repeats its previous step's values; its 1280 PCM samples are not read.  A stream
+ * stepped k times through any interleaving of masked steps is in the state k plain steps leave it in, bit for bit.
+ * Default kernel family only (use_mfma = 3 with the fused front end); OWW_EINVAL otherwise. */
+int  oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uint8_t* stream_on, int stream_on_on_device,
+                     float* scores, int scores_on_device);
 /* Range guard of the default kernel family (use_mfma = 3 evaluates every fp32 product as three f16 MFMAs on hi/lo-split
  * operands, so an activation with |x| >= 65520 cannot be represented).  The reference's fp32 graphs have no such limit
  * (onnxruntime CPU kernels, utils.py:84-93), so instead of scoring silently differently the kernels test one accumulator

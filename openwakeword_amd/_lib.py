@@ -37,6 +37,7 @@ SYMBOLS = {
     "oww_reset": (C.c_int, [_P, _P, C.c_int32, _P]),
     "oww_set_postproc": (C.c_int, [_P, _P, _P, C.c_int32]),
     "oww_step": (C.c_int, [_P, _P, C.c_int, C.c_int32, _P, C.c_int]),
+    "oww_step_masked": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "oww_sync": (C.c_int, [_P]),
     "oww_range_status": (C.c_int, [_P, C.c_int]),
     "oww_submit": (C.c_int, [_P, _P, C.c_int32]),

@@ -322,6 +322,8 @@ struct oww_ctx {
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
     int* h_range = nullptr;          // sticky f16-range flag: one page-locked, device-mapped word the f16-split kernels raise
     int* d_range = nullptr;          // the same word as the kernels address it
+    uint8_t* d_on = nullptr;         // oww_step_masked: [Spad] participation mask of the step being launched (pad streams 0)
+    const uint8_t* on_now = nullptr; // = d_on (or the caller's device mask) while a masked step is being launched, else nullptr
     int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
     bool fuse = false;               // f16-split family: mel front end fused into stage A for one-chunk streaming steps (owwhip_fused.h)
     const int16_t* fuse_pcm = nullptr;   // set by launch_step for the duration of a fused step
@@ -460,6 +462,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.xout = h->d_xA; p.n_streams = n_active; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         p.range_flag = HX ? h->d_range : nullptr;
+        p.stream_on = h->on_now;
         const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
         Timed t(h, 1);
         if (HX && h->fuse_pcm) {
@@ -484,6 +487,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.n_groups = (n_active + spt - 1) / spt; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         p.range_flag = HX ? h->d_range : nullptr;
+        p.stream_on = h->on_now;
     };
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
@@ -554,7 +558,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 owh::HeadHxParams q{};
                 q.feat = base.feat; q.ext = base.ext; q.TR = base.TR; q.T = g.T; q.nfeat = base.nfeat; q.w1hx = g.d_w1hx;
                 q.raw = raw_out; q.NL = h->NL; q.S = n_active; q.accumulate_max = base.accumulate_max;
-                q.range_flag = h->d_range;
+                q.range_flag = h->d_range; q.stream_on = h->on_now;
                 if (h->post_in_heads_now) {
                     owh::HeadHxPost& pp = q.post;
                     pp.enabled = 1; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred; pp.nfeat = h->d_nfeat;
@@ -652,6 +656,7 @@ void free_all(oww_ctx* h) {
     fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin); fr(h->d_vadx); fr(h->d_vadhc); fr(h->d_vadlast); fr(h->d_verw); fr(h->d_verb); fr(h->d_verthr); fr(h->d_verT);
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
+    if (h->d_on) { (void)hipFree(h->d_on); h->d_on = nullptr; }
     if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
     for (auto& sl : h->slot) {
         fr(sl.d_pcm); fr(sl.d_scores);
@@ -678,11 +683,11 @@ int step_chunk(oww_ctx* h, int k, int c) {
     if (h->n_verifiers > 0 && c == k - 1) {          // after the maximum over the call's chunks, on the newest feature rows
         VerifierParams v{};
         v.raw = h->d_raw; v.feat = h->d_feat; v.nfeat = h->d_nfeat; v.w = h->d_verw; v.bias = h->d_verb; v.thr = h->d_verthr; v.T = h->d_verT;
-        v.wstride = h->ver_stride; v.NL = h->NL; v.TR = h->TR; v.S = h->S;
+        v.wstride = h->ver_stride; v.NL = h->NL; v.TR = h->TR; v.S = h->S; v.stream_on = h->on_now;
         hipLaunchKernelGGL(verifier_kernel, dim3((h->S + 3) / 4), dim3(256), 0, h->stream, v);
     }
     if (!done_in_heads)
-        hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+        hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad, h->on_now);
     return 0;
 }
 
@@ -692,7 +697,7 @@ int launch_vad(oww_ctx* h, const int16_t* d_pcm, int n_samples) {
     {
         owv::VadFrontParams p{};
         p.pcm = d_pcm; p.n_samples = n_samples; p.S = h->S; p.hann = h->d_vad_hann; p.mag_gain = h->vad_gain;
-        p.w = h->d_vad_encw; p.bias = h->d_vad_encb; p.xout = h->d_vadx; p.range_flag = h->d_range;
+        p.w = h->d_vad_encw; p.bias = h->d_vad_encb; p.xout = h->d_vadx; p.range_flag = h->d_range; p.stream_on = h->on_now;
         const int grid = std::min((h->S + owv::V_WG - 1) / owv::V_WG, 256);          // persistent: one 8-wave workgroup per CU
         Timed t(h, 8);
         hipLaunchKernelGGL(owv::vad_front_kernel, dim3(grid), dim3(64 * owv::V_WG), owv::V_LDS_BYTES, h->stream, p);
@@ -700,7 +705,7 @@ int launch_vad(oww_ctx* h, const int16_t* d_pcm, int n_samples) {
     {
         owv::VadLstmParams p{};
         p.xin = h->d_vadx; p.hc = h->d_vadhc; p.w = h->d_vad_lstmw; p.bias = h->d_vad_lstmb; p.wd = h->d_vad_wd; p.bd = h->vad_bd;
-        p.ring = h->d_vadring; p.n_vad = h->d_nvad; p.last = h->d_vadlast; p.S = h->S; p.n_groups = G;
+        p.ring = h->d_vadring; p.n_vad = h->d_nvad; p.last = h->d_vadlast; p.S = h->S; p.n_groups = G; p.stream_on = h->on_now;
         Timed t(h, 9);
         hipLaunchKernelGGL(owv::vad_lstm_kernel, dim3((G + owv::L_WG - 1) / owv::L_WG), dim3(64 * owv::L_WG), 0, h->stream, p);
     }
@@ -728,7 +733,7 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
     pp.raw = h->d_raw; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred;
     pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
     pp.NL = h->NL; pp.S = h->Spad;
-    pp.vad_ring = h->d_vadring; pp.n_vad = h->d_nvad; pp.vad_threshold = h->vad_threshold;
+    pp.vad_ring = h->d_vadring; pp.n_vad = h->d_nvad; pp.vad_threshold = h->vad_threshold; pp.stream_on = h->on_now;
     {
         Timed t(h, 7);
         hipLaunchKernelGGL(postproc_kernel, dim3((h->Spad + 127) / 128), dim3(128), 0, h->stream, pp);
@@ -1274,6 +1279,43 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
     return OWW_OK;
 }
 
+int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uint8_t* stream_on, int stream_on_on_device,
+                    float* scores, int scores_on_device) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step_masked: handle not committed");
+    if (!pcm || !stream_on) return fail(OWW_EINVAL, "oww_step_masked: null argument");
+    if (!h->hx || !h->fuse || !h->generic_nets.empty())
+        return fail(OWW_EINVAL, "oww_step_masked: needs the fp16-split kernels with the fused front end (use_mfma = 3, OWW_NO_FUSE unset) and "
+                    "heads of the fast [T,96] -> 128/64/32 form");
+    if (int rc = range_check(h, "oww_step_masked")) return rc;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    h->k_last = 1;
+    if (!h->d_on) {
+        HIPCHK(hipMalloc(&h->d_on, h->Spad));
+        HIPCHK(hipMemsetAsync(h->d_on, 0, h->Spad, h->stream));
+    }
+    // (always through the handle's own buffer: the kernels index it up to the padded stream count)
+    HIPCHK(hipMemcpyAsync(h->d_on, stream_on, h->S, stream_on_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    const int16_t* d_pcm = pcm;
+    if (!pcm_on_device || (reinterpret_cast<uintptr_t>(pcm) & 15)) {
+        HIPCHK(hipMemcpyAsync(h->d_pcm, pcm, (size_t)h->S * OWW_CHUNK * sizeof(int16_t),
+                              pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        d_pcm = h->d_pcm;
+    }
+    h->on_now = h->d_on;
+    const int rc = launch_step(h, d_pcm, 1);
+    h->on_now = nullptr;
+    if (rc) return rc;
+    if (scores) {
+        const size_t nb = (size_t)h->S * h->NL * sizeof(float);
+        if (nb) HIPCHK(hipMemcpyAsync(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        if (!scores_on_device) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (int rc2 = range_check(h, "oww_step_masked")) return rc2;
+        }
+    }
+    return OWW_OK;
+}
+
 static int ensure_ingest(oww_ctx* h) {
     if (h->up_stream) return 0;
     HIPCHK(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
@@ -1513,7 +1555,7 @@ int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float*
             }
         if (hipMemcpyAsync(h->d_mel, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: H2D failed"); break; }
         if ((rc_all = run_cnn(h, B, 256, 0))) break;
-        hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+        hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad, (const uint8_t*)nullptr);
         if (it >= 9 && hipMemcpyAsync(emb.data(), h->d_emb, emb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: D2H failed"); break; }
         if (hipStreamSynchronize(h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: device error"); break; }   // slab is reused next iteration
         if (it >= 9)
@@ -1558,7 +1600,7 @@ int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32
         for (int it = 0; it < n_steps && !rc; ++it) {
             rc = run_cnn(h, B, F * 32, (it * 8 - 4) * 32);
             if (rc) break;
-            hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad);
+            hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad, (const uint8_t*)nullptr);
             if (it >= 9 && hipMemcpy2DAsync(o + (size_t)(it - 9) * 96, (size_t)n_out * 96 * sizeof(float), h->d_emb, 96 * sizeof(float),
                                             96 * sizeof(float), B, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
                 rc = fail(OWW_EHIP, "oww_embed_clips: gather failed");

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         // strength-reduced 64-bit per-lane pointers that would stay alive (and spill) across the whole loop body
         int s = __builtin_amdgcn_readfirstlane(s0);
         asm volatile("" : "+s"(s));
+        if (q.a.stream_on && !q.a.stream_on[s]) continue;        // masked step (oww_step_masked): no sample is consumed, no state touched
 
         // an opaque zero added to every LDS base of the mel phase: its per-lane addresses are then recomputed in each iteration
         // (a few VALU adds) instead of being hoisted out of the stream loop and kept alive -- i.e. spilled -- across stage A

@@ -602,6 +602,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         sbn[l][1][c] = p.shift[l][c];
     }
     const int s_first = g * C::SPT;
+    // masked steps (oww_step_masked): a stream that sits this step out is computed like any other (the workgroup shares its weight
+    // stream) but none of its state, hand-over or output is stored; per lane, because a tile holds 16 / F streams
+    const bool lane_on = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (lane & 15) / F, p.S - 1)] != 0);
     float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
     float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
 
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
             to_ops_time<NCT, C::HOUT>(T0, H0F, rem[0]);
             to_ops_time<NCT, C::HOUT>(T1, H1F, rem[1]);
         }
-        if (active) {
+        if (lane_on) {
             store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
             store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
         }
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         to_ops<NCT, C::HOUT>(T0, H0);
         to_ops<NCT, C::HOUT>(T1, H1);
     }
-    if (active) {
+    if (lane_on) {
         store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
         store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
     }
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
             to_ops_time<NCT, C::HOUT>(T0, H0F, rem[0]);
             to_ops_time<NCT, C::HOUT>(T1, H1F, rem[1]);
         }
-        if (active) {
+        if (lane_on) {
             store_tile_h<NCT, C::HOUT>(Y[R - 2], hd, lane);
             store_tile_h<NCT, C::HOUT>(Y[R - 1], hd + NCT * 4 * 64, lane);
         }
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         to_ops<NCT, C::HOUT>(T0, H0);
         to_ops<NCT, C::HOUT>(T1, H1);
     }
-    if (active) {
+    if (lane_on) {
         store_tile_h<NCT, C::HOUT>(Y[R - 2], hd, lane);
         store_tile_h<NCT, C::HOUT>(Y[R - 1], hd + NCT * 4 * 64, lane);
     }
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
     }
 
-    if (!LAST && active) {
+    if (!LAST && lane_on) {
         constexpr int FO = C::FO, RO = C::RO;
         constexpr int SPTN = 16 / FO;
         const int pos = lane & 15, j = lane >> 4;
@@ -773,12 +776,13 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         f32x4 E[1][NCT];
         // (no guard here: an out-of-range input of conv19 yields a NaN embedding, which the heads kernel's guard reports)
         conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane, bad);
-        if (active) {
+        const bool on19 = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (pos & 7), p.S - 1)] != 0);   // lanes 8..15 mirror 0..7
+        if (on19) {
             store_tile<NCT>(T1, h19, lane);
             store_tile<NCT>(Pl, h19 + NCT * 4 * 64, lane);
         }
         const int s = s_first + pos;
-        if (active && pos < C::SPT && s < p.S) {
+        if (on19 && pos < C::SPT && s < p.S) {
             const uint32_t slot = p.nfeat[s] % (uint32_t)p.TR;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -1018,8 +1022,10 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
     for (int q = 0; q < 8; ++q) { const int k = min(8 * j + q, 8); goff[q] = (k / 3) * 34 + (k % 3) + pos; }
     lanemask_t bad = 0;
 
-    for (int s = gw; s < p.n_streams; s += nw)
+    for (int s = gw; s < p.n_streams; s += nw) {
+        if (p.stream_on && !p.stream_on[s]) continue;            // masked step: this stream sits it out
         hstageA_stream<DBG, false>(p, s, sM, sW0, sW[0], sW[1], &sbn[0][0][0], goff, bad, lane);
+    }
     raise_range_flag(bad, p.range_flag);
 }
 
@@ -1064,6 +1070,7 @@ struct HeadHxParams {
     int NL, S, accumulate_max;
     int* range_flag;        // sticky f16-range flag of the handle (see nan_guard)
     HeadHxPost post;
+    const uint8_t* stream_on;   // oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
 };
 
 __device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
@@ -1245,6 +1252,7 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
         for (int t = 0; t < 2; ++t) {
             const int st = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
             if (st >= p.S) continue;
+            if (p.stream_on && !p.stream_on[st]) continue;          // sits this step out: scores, rings and counters stay as they are
             const uint32_t cnt = p.post.enabled ? p.post.npred[st] : 0u;
             const int have = cnt < 30u ? (int)cnt : 30;
             float fin[NN];

@@ -1166,11 +1166,13 @@ struct PostParams {
     const float* vad_ring;   // [S][8]
     const uint32_t* n_vad;   // [S] scores pushed so far
     float vad_threshold;     // <= 0: gate off
+    const uint8_t* stream_on;    // oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
 };
 
 __global__ void postproc_kernel(PostParams p) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= p.S) return;
+    if (p.stream_on && !p.stream_on[s]) return;
     const uint32_t cnt = p.npred[s];
     const int have = cnt < 30u ? (int)cnt : 30;
     for (int l = 0; l < p.NL; ++l) {
@@ -1234,11 +1236,13 @@ struct VerifierParams {
     const float* thr;        // [NL] custom_verifier_threshold
     const int* T;            // [NL] feature rows of the label's model; 0 = no verifier for this label
     int wstride, NL, TR, S;
+    const uint8_t* stream_on;    // oww_step_masked
 };
 
 __global__ __launch_bounds__(256) void verifier_kernel(VerifierParams p) {
     const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= p.S) return;
+    if (p.stream_on && !p.stream_on[s]) return;
     for (int l = 0; l < p.NL; ++l) {
         const int T = p.T[l];
         if (T <= 0) continue;
@@ -1265,9 +1269,9 @@ __global__ void vad_ring_reset_kernel(float* ring, uint32_t* n_vad, const int* i
     n_vad[s] = 0u;
 }
 
-__global__ void advance_kernel(uint32_t* nfeat, int S) {
+__global__ void advance_kernel(uint32_t* nfeat, int S, const uint8_t* stream_on) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < S) nfeat[s] += 1u;
+    if (s < S && (stream_on == nullptr || stream_on[s])) nfeat[s] += 1u;
 }
 
 __global__ void fill_kernel(float* x, size_t n, float v) {

@@ -493,6 +493,7 @@ struct RStageParams {
     size_t dbg_stride;
     int dbg_off[5];
     int* range_flag;       // f16-split family: sticky out-of-range flag of the handle (owwhip_hx.h nan_guard); nullptr otherwise
+    const uint8_t* stream_on;  // f16-split family, oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
 };
 
 // max-pool PT x PF of the stage output and scatter into the next stage's register-dump layout
@@ -660,6 +661,7 @@ struct RAParams {
     size_t dbg_stride;
     int dbg_off[3];
     int* range_flag;       // see RStageParams::range_flag
+    const uint8_t* stream_on;  // see RStageParams::stream_on
 };
 
 #ifndef OWR_WPS_A

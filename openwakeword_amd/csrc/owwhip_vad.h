@@ -47,6 +47,7 @@ struct VadFrontParams {
     const float* bias;      // [4][64], zero padded
     float* xout;            // [ceil(S/16)][4 (sub-frame, time)][16 registers][64 lanes]: LSTM input tiles
     int* range_flag;
+    const uint8_t* stream_on;   // oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
 };
 
 template <int D> __device__ __forceinline__ float dpp_shr_zero(float x) {       // lane p <- x[p - D] inside the 16-lane row, else 0
@@ -144,6 +145,10 @@ __global__ __launch_bounds__(64 * V_WG, (V_WG + 3) / 4) void vad_front_kernel(Va
     int4 raw[3] = {};
     if (gw < p.S) vad_fetch(p, gw, lane, raw);
     for (int s = gw; s < p.S; s += nw) {
+        if (p.stream_on && !p.stream_on[s]) {        // sits this step out (its LSTM lanes store nothing either); keep the prefetch chain going
+            if (s + nw < p.S) vad_fetch(p, s + nw, lane, raw);
+            continue;
+        }
         wave_sync();                                 // the previous stream's readers of sx are done (same wave)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -283,6 +288,7 @@ struct VadLstmParams {
     uint32_t* n_vad;        // [S]
     float* last;            // [S] the score just pushed
     int S, n_groups;
+    const uint8_t* stream_on;   // see VadFrontParams::stream_on
 };
 
 constexpr int L_WG = 4;                       // waves per workgroup: they share one weight chunk stream
@@ -379,14 +385,14 @@ __global__ __launch_bounds__(64 * L_WG, 2) void vad_lstm_kernel(VadLstmParams p)
         yacc += sigm(z);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the chunk prefetched after the last one
-    if (active) {
+    const int s = g * 16 + pos;
+    if (active && s < p.S && (p.stream_on == nullptr || p.stream_on[s] != 0)) {      // per lane: position = stream
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
             store_tile<4>(hf[l], hc + (2 * l) * 1024, lane);
             store_tile<4>(cf[l], hc + (2 * l + 1) * 1024, lane);
         }
-        const int s = g * 16 + pos;
-        if (j == 0 && s < p.S) {
+        if (j == 0) {
             const float score = yacc * 0.25f;                  // mean over the 2 sub-frames x 2 time steps (vad.py:127)
             const uint32_t L = p.n_vad[s];
             p.ring[(size_t)s * 8 + (L & 7u)] = score;

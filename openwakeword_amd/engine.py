@@ -187,6 +187,23 @@ class StreamEngine:
         _lib.check(self._lib.oww_step(self._h, _ptr(pcm), 0, k, _ptr(out), 0))
         return out
 
+    def step_masked(self, pcm: np.ndarray, stream_on: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """One 1280-sample step for the streams with stream_on != 0 only (oww_step_masked): the others keep every bit of their
+        state and repeat their previous scores -- the batched form of a client that simply does not call predict() while it has
+        no audio (examples/web/streaming_server.py:49-66)."""
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype != np.int16:
+            raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {pcm.dtype} data.")
+        if pcm.shape != (self.n_streams, CHUNK):
+            raise ValueError(f"pcm must be [n_streams={self.n_streams}, 1280], got {pcm.shape}")
+        on = np.ascontiguousarray(np.asarray(stream_on) != 0, dtype=np.uint8)
+        if on.shape != (self.n_streams,):
+            raise ValueError(f"stream_on must be [n_streams={self.n_streams}], got {on.shape}")
+        if out is None:
+            out = np.empty((self.n_streams, self.n_labels), dtype=np.float32)
+        _lib.check(self._lib.oww_step_masked(self._h, _ptr(pcm), 0, _ptr(on), 0, _ptr(out), 0))
+        return out
+
     def step_raw(self, pcm: np.ndarray) -> np.ndarray:
         """Like step(), but returns the head outputs before post-processing (model.py:313-317)."""
         pcm = np.ascontiguousarray(pcm)

@@ -522,6 +522,13 @@ class BatchedModel:
             raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
         return self.engine.step(pcm)[:, self._keep]
 
+    def predict_active(self, pcm: np.ndarray, active) -> np.ndarray:
+        """predict_batch for the streams flagged in `active` ([n_streams] bool) only; the others do not advance at all and
+        repeat their previous scores (the reference's per-client behaviour: no audio, no predict() call)."""
+        if not isinstance(pcm, np.ndarray):
+            raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
+        return self.engine.step_masked(pcm, active)[:, self._keep]
+
     def set_custom_verifier(self, model_name: str, verifier, threshold: float = 0.1) -> None:
         """`Model(custom_verifier_models=..., custom_verifier_threshold=...)` for every stream, on the device (model.py:320-328).
         `verifier` is the scikit-learn pipeline custom_verifier_model.train_verifier_model returns (flatten -> StandardScaler ->

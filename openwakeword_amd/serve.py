@@ -1,0 +1,213 @@
+"""Fan-in streaming server: many websocket clients, ONE batched step on the GPU.
+
+The reference's web example (examples/web/streaming_server.py:32-70) holds one `Model` and calls `predict()` inside the
+websocket handler of whichever client sent audio: one graph evaluation per client message on the CPU, and all clients share that
+single model's streaming state.  This module keeps the example's wire protocol --
+
+    client -> server   TEXT    the client's sample rate ("16000", "44100", ...)           (streaming_server.py:50-52)
+    client -> server   BINARY  little-endian int16 PCM, any length                         (streaming_server.py:53-59)
+    server -> client   TEXT    {"loaded_models": [...]} once, on connect                   (streaming_server.py:44-46)
+    server -> client   TEXT    {"activations": [...]} for labels scoring >= threshold      (streaming_server.py:62-68)
+
+-- and changes what happens behind it: every connection owns one stream slot of a `BatchedModel` (its own sample tail, conv
+histories, rings and counters on the device), the handler only appends (resampled) samples to the connection's queue, and a single
+pump coroutine gathers one 1280-sample chunk from every connection that has one and runs ONE `oww_step_masked` for all of them.
+A connection without a full chunk sits the step out bit-exactly (no zero padding, no skipped audio), so each client gets exactly the
+scores a private `openwakeword.Model` would have produced on its own audio in 1280-sample calls.
+
+Sample-rate conversion follows the example (per message, stateless: `resampy.resample(data, sample_rate, 16000)`,
+streaming_server.py:57-58) with scipy's polyphase resampler; resampy is not a dependency here.
+
+    python -m openwakeword_amd.serve --streams 4096 --models alexa hey_jarvis --weights synthetic --port 9000
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import json
+from fractions import Fraction
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .engine import CHUNK
+
+try:  # aiohttp is the example's server library too (streaming_server.py:19)
+    from aiohttp import WSMsgType, web
+except ImportError as e:  # pragma: no cover
+    raise ImportError("openwakeword_amd.serve needs aiohttp (the library the reference's web example uses)") from e
+
+
+def to_16k(pcm: np.ndarray, sample_rate: int) -> np.ndarray:
+    """int16 at `sample_rate` -> int16 at 16 kHz (one message at a time, like streaming_server.py:57-58)."""
+    if sample_rate == 16000 or pcm.size == 0:
+        return pcm
+    from scipy.signal import resample_poly
+    r = Fraction(16000, int(sample_rate))
+    y = resample_poly(pcm.astype(np.float32), r.numerator, r.denominator)
+    return np.clip(np.rint(y), -32768, 32767).astype(np.int16)
+
+
+class _Client:
+    __slots__ = ("slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed")
+
+    def __init__(self, slot: int, ws):
+        self.slot, self.ws, self.rate = slot, ws, 16000
+        self.pending: List[np.ndarray] = []
+        self.n_pending = 0
+        self.n_steps = 0
+        self.closed = False
+
+    def push(self, x: np.ndarray) -> None:
+        if x.size:
+            self.pending.append(x)
+            self.n_pending += x.size
+
+    def pop_chunk(self, out: np.ndarray) -> None:
+        """Move the oldest 1280 samples into `out`."""
+        need, o = CHUNK, 0
+        while need:
+            head = self.pending[0]
+            take = min(need, head.size)
+            out[o:o + take] = head[:take]
+            if take == head.size:
+                self.pending.pop(0)
+            else:
+                self.pending[0] = head[take:]
+            o += take
+            need -= take
+        self.n_pending -= CHUNK
+
+
+class FanInServer:
+    """`model`: a BatchedModel; its n_streams is the number of clients that can be connected at once (further connections are
+    refused with close code 1013).  `window_s`: how long the pump waits after the first chunk of a round becomes available for other
+    connections' chunks to arrive before it steps (0 = step at once; real-time clients deliver one chunk per 80 ms, so a few ms
+    gathers nearly everyone into the same step).  `on_scores(slot, step_index, scores_row)`: optional tap, called for every
+    stream-step (used by the tests)."""
+
+    def __init__(self, model, threshold: float = 0.5, window_s: float = 0.01, on_scores=None):
+        self.model = model
+        self.threshold = float(threshold)
+        self.window_s = float(window_s)
+        self.on_scores = on_scores
+        self.free: List[int] = list(range(model.n_streams - 1, -1, -1))
+        self.clients: Dict[int, _Client] = {}
+        self._have_chunk: Optional[asyncio.Event] = None
+        self._pump_task: Optional[asyncio.Task] = None
+        self._gpu: Optional[asyncio.Lock] = None     # one caller at a time on the handle (pump step vs. a new connection's reset)
+        self._pcm = np.zeros((model.n_streams, CHUNK), dtype=np.int16)
+        self._on = np.zeros(model.n_streams, dtype=np.uint8)
+        self.n_steps = 0              # batched steps taken
+        self.n_stream_steps = 0       # sum over steps of the streams that took part
+
+    # ---- aiohttp plumbing
+    def app(self) -> "web.Application":
+        app = web.Application()
+        app.add_routes([web.get("/ws", self.handle)])
+        app.on_startup.append(self._start)
+        app.on_cleanup.append(self._stop)
+        return app
+
+    async def _start(self, app) -> None:
+        self._have_chunk = asyncio.Event()
+        self._gpu = asyncio.Lock()
+        self._pump_task = asyncio.get_running_loop().create_task(self._pump())
+
+    async def _stop(self, app) -> None:
+        if self._pump_task:
+            self._pump_task.cancel()
+            try:
+                await self._pump_task
+            except asyncio.CancelledError:
+                pass
+
+    async def handle(self, request):
+        ws = web.WebSocketResponse()
+        await ws.prepare(request)
+        if not self.free:
+            await ws.close(code=1013, message=b"all stream slots are taken")
+            return ws
+        slot = self.free.pop()
+        # a slot handed to a new caller starts from Model()'s initial state, VAD history included; after any step still in
+        # flight that carried the slot's previous owner
+        async with self._gpu:
+            self.model.reset([slot], reset_vad=bool(self.model.engine.has_vad))
+        c = _Client(slot, ws)
+        self.clients[slot] = c
+        try:
+            await ws.send_str(json.dumps({"loaded_models": list(self.model.labels)}))
+            async for msg in ws:
+                if msg.type == WSMsgType.TEXT:
+                    c.rate = int(msg.data)
+                elif msg.type == WSMsgType.BINARY:
+                    n = len(msg.data) // 2
+                    c.push(to_16k(np.frombuffer(msg.data, dtype="<i2", count=n), c.rate))
+                    if c.n_pending >= CHUNK:
+                        self._have_chunk.set()
+                elif msg.type == WSMsgType.ERROR:
+                    break
+        finally:
+            c.closed = True          # the pump scores what the client still delivered, then returns the slot to the pool
+            self._have_chunk.set()
+        return ws
+
+    def _reap(self) -> None:
+        for slot in [s for s, c in self.clients.items() if c.closed and c.n_pending < CHUNK]:
+            del self.clients[slot]
+            self.free.append(slot)
+
+    # ---- the one place the GPU is driven from
+    async def _pump(self) -> None:
+        loop = asyncio.get_running_loop()
+        while True:
+            await self._have_chunk.wait()
+            if self.window_s > 0:
+                await asyncio.sleep(self.window_s)
+            self._have_chunk.clear()
+            async with self._gpu:
+                self._reap()
+                ready = [c for c in self.clients.values() if c.n_pending >= CHUNK]
+                if not ready:
+                    continue
+                self._on[:] = 0
+                for c in ready:
+                    c.pop_chunk(self._pcm[c.slot])
+                    self._on[c.slot] = 1
+                # (blocking ctypes call: off the event loop, so that sockets keep draining while the kernels run)
+                scores = await loop.run_in_executor(None, self.model.predict_active, self._pcm, self._on)
+            self.n_steps += 1
+            self.n_stream_steps += len(ready)
+            for c in ready:
+                row = scores[c.slot]
+                if self.on_scores is not None:
+                    self.on_scores(c.slot, c.n_steps, row)
+                c.n_steps += 1
+                hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
+                if hits and not c.closed:
+                    try:
+                        await c.ws.send_str(json.dumps({"activations": hits}))
+                    except (ConnectionError, RuntimeError):
+                        c.closed = True
+            self._reap()
+            if any(c.n_pending >= CHUNK for c in self.clients.values()):
+                self._have_chunk.set()          # somebody sent more than one chunk: go again without waiting for a message
+
+
+def main(argv=None) -> None:
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--streams", type=int, default=1024, help="client slots (= streams of the batched model)")
+    ap.add_argument("--models", nargs="+", default=["alexa"])
+    ap.add_argument("--weights", default=None, help='"synthetic" for random-init weights; default: the .onnx files next to the package')
+    ap.add_argument("--threshold", type=float, default=0.5)
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=9000)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    from .model import BatchedModel
+    model = BatchedModel(a.streams, a.models, weights=a.weights, device=a.device)
+    web.run_app(FanInServer(model, threshold=a.threshold).app(), host=a.host, port=a.port)
+
+
+if __name__ == "__main__":
+    main()

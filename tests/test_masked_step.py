@@ -1,0 +1,178 @@
+"""oww_step_masked: a stream that sits a step out keeps every bit of its state (the batched form of a client that does not call
+predict() while it has no audio, examples/web/streaming_server.py:49-66), and the fan-in server built on it gives every websocket
+client the scores of a private model."""
+import asyncio
+import json
+
+import numpy as np
+import pytest
+
+from openwakeword_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+HEADS = ["alexa", "hey_mycroft", "hey_jarvis"]
+
+
+def _engine(S, heads=HEADS, vad=None, vad_threshold=0.0):
+    from openwakeword_amd.engine import StreamEngine
+    hs = {n: W.synthetic_head(n, seed=11 + i) for i, n in enumerate(heads)}
+    return StreamEngine(S, hs, W.synthetic_embedding(seed=3), vad=vad, vad_threshold=vad_threshold)
+
+
+def _pcm(rng, S, T):
+    return (rng.standard_normal((T, S, 1280)) * 4000).astype(np.int16)
+
+
+@pytest.mark.parametrize("S,with_vad", [(40, False), (200, False), (72, True)])
+def test_masked_step_equals_private_sequences(S, with_vad):
+    """Random participation masks over 40 steps; every stream's k-th active step must equal, BIT FOR BIT, the k-th step of an
+    unmasked engine that is fed the stream's active chunks back to back (S chosen to leave partly filled position tiles)."""
+    rng = np.random.default_rng(5)
+    T = 40
+    pcm = _pcm(rng, S, T)
+    on = rng.random((T, S)) < 0.6
+    on[:, 0] = True                      # one stream in every step
+    on[:, 1] = False                     # one stream in none
+    on[::2, 2] = True
+    on[1::2, 2] = False
+    vad = W.synthetic_vad(seed=9) if with_vad else None
+    thr = 0.5 if with_vad else 0.0
+    a, b = _engine(S, vad=vad, vad_threshold=thr), _engine(S, vad=vad, vad_threshold=thr)
+    first = a.step(np.zeros((S, 1280), np.int16)).copy()       # a plain step first, so that "previous scores" exist
+    b.step(np.zeros((S, 1280), np.int16))
+    masked = np.empty((T, S, len(HEADS)), np.float32)
+    for t in range(T):
+        junk = pcm[t].copy()
+        junk[~on[t]] = 12345                                    # samples of a stream sitting out must not be read
+        masked[t] = a.step_masked(junk, on[t])
+    # reference: stream s gets its active chunks at plain steps 0, 1, 2, ...
+    counts = on.sum(0)
+    K = int(counts.max())
+    packed = np.zeros((K, S, 1280), np.int16)
+    for s in range(S):
+        packed[:counts[s], s] = pcm[on[:, s], s]
+    plain = np.stack([b.step(packed[k]) for k in range(K)])
+    for s in range(S):
+        ts = np.nonzero(on[:, s])[0]
+        np.testing.assert_array_equal(masked[ts, s], plain[:len(ts), s], err_msg=f"stream {s}")
+        prev = first[s]
+        for t in range(T):                                       # sitting out repeats the previous step's scores
+            if not on[t, s]:
+                np.testing.assert_array_equal(masked[t, s], prev)
+            prev = masked[t, s]
+    assert np.abs(masked).max() > 0
+    if with_vad:
+        assert np.isfinite(a.get_vad()).all()
+    a.close(); b.close()
+
+
+def test_masked_step_with_verifier_and_two_groups():
+    """Heads of two window lengths (post-processing in its own launch) and a custom verifier: the masks reach those kernels too."""
+    from openwakeword_amd.engine import StreamEngine
+    rng = np.random.default_rng(6)
+    S, T = 48, 24
+    hs = {"a16": W.synthetic_head("a16", seed=1), "b28": W.synthetic_head("b28", seed=2, T=28)}
+
+    def make():
+        e = StreamEngine(S, hs, W.synthetic_embedding(seed=3))
+        e.set_verifier(0, (rng0.standard_normal(16 * 96) * 0.01).astype(np.float32), 0.1, 0.0)
+        return e
+    rng0 = np.random.default_rng(1); a = make()
+    rng0 = np.random.default_rng(1); b = make()
+    pcm = _pcm(rng, S, T)
+    on = rng.random((T, S)) < 0.5
+    masked = np.stack([a.step_masked(pcm[t], on[t]) for t in range(T)])
+    counts = on.sum(0)
+    packed = np.zeros((int(counts.max()), S, 1280), np.int16)
+    for s in range(S):
+        packed[:counts[s], s] = pcm[on[:, s], s]
+    plain = np.stack([b.step(p) for p in packed])
+    for s in range(S):
+        ts = np.nonzero(on[:, s])[0]
+        np.testing.assert_array_equal(masked[ts, s], plain[:len(ts), s], err_msg=f"stream {s}")
+    a.close(); b.close()
+
+
+def test_masked_step_argument_errors():
+    from openwakeword_amd.engine import StreamEngine
+    e = _engine(8)
+    with pytest.raises(ValueError):
+        e.step_masked(np.zeros((8, 2560), np.int16), np.ones(8))
+    with pytest.raises(ValueError):
+        e.step_masked(np.zeros((8, 1280), np.int16), np.ones(7))
+    e.close()
+    hs = {"alexa": W.synthetic_head("alexa", seed=1)}
+    f = StreamEngine(8, hs, W.synthetic_embedding(seed=3), use_mfma=1)          # exact-fp32 family: not supported, loudly
+    from openwakeword_amd._lib import OwwError
+    with pytest.raises(OwwError):
+        f.step_masked(np.zeros((8, 1280), np.int16), np.ones(8))
+    f.close()
+
+
+def test_fan_in_server_gives_each_client_private_scores():
+    """Five websocket clients with different sample rates, message sizes and pacing against one 8-slot server; the per-stream-step
+    tap must equal a private single-stream engine run on each client's (resampled) audio, and the activation messages must be the
+    labels at or above the threshold."""
+    from aiohttp.test_utils import TestClient, TestServer
+    from openwakeword_amd.model import BatchedModel
+    from openwakeword_amd.serve import FanInServer, to_16k
+
+    rng = np.random.default_rng(8)
+    heads = {n: W.synthetic_head(n, seed=11 + i) for i, n in enumerate(HEADS)}
+    wts = {"heads": heads, "embedding": W.synthetic_embedding(seed=3)}
+    model = BatchedModel(8, HEADS, weights=wts)
+    tap = {}
+    srv = FanInServer(model, threshold=0.02, window_s=0.002,
+                      on_scores=lambda slot, k, row: tap.setdefault(slot, []).append(row.copy()))
+    plans = [(16000, 1280, 30), (16000, 700, 41), (8000, 640, 36), (48000, 4096, 25), (16000, 5000, 9)]   # rate, samples/message, messages
+    audio = [(rng.standard_normal(n * m) * 5000).astype(np.int16) for _r, n, m in plans]
+    got = [dict(loaded=None, hits=[]) for _ in plans]
+
+    async def client(ws, i):
+        rate, n, m = plans[i]
+        await ws.send_str(str(rate))
+        for k in range(m):
+            await ws.send_bytes(audio[i][k * n:(k + 1) * n].tobytes())
+            if k % 3 == i % 3:
+                await asyncio.sleep(0.003 * (i + 1))
+        expect_steps = sum(to_16k(audio[i][k * n:(k + 1) * n], rate).size for k in range(m)) // 1280
+        # read activation messages until the server has scored everything this client sent
+        quiet = 0
+        while quiet < 2:                       # (the tap fills before the step's messages go out: drain past completion)
+            try:
+                msg = await ws.receive(timeout=0.1)
+                if msg.data:
+                    got[i]["hits"].append(json.loads(msg.data)["activations"])
+                    continue
+            except asyncio.TimeoutError:
+                pass
+            if len(tap.get(i, [])) >= expect_steps:
+                quiet += 1
+        await ws.close()
+        return expect_steps
+
+    async def run():
+        async with TestClient(TestServer(srv.app())) as tc:
+            wss = []
+            for i in range(len(plans)):          # one after the other: client i owns slot i
+                ws = await tc.ws_connect("/ws")
+                got[i]["loaded"] = json.loads((await ws.receive()).data)["loaded_models"]
+                assert srv.clients[i].slot == i
+                wss.append(ws)
+            return await asyncio.gather(*[client(ws, i) for i, ws in enumerate(wss)])
+
+    steps = asyncio.run(asyncio.wait_for(run(), 120))
+    model.close()
+    assert all(g["loaded"] == HEADS for g in got)
+    assert srv.n_stream_steps == sum(steps) and srv.n_steps < sum(steps)          # steps were shared between clients
+    for i, (rate, n, m) in enumerate(plans):
+        x = np.concatenate([to_16k(audio[i][k * n:(k + 1) * n], rate) for k in range(m)])
+        e = _engine(1)
+        private = np.stack([e.step(x[None, k * 1280:(k + 1) * 1280])[0] for k in range(x.size // 1280)])
+        e.close()
+        assert len(private) == steps[i]
+        np.testing.assert_array_equal(np.stack(tap[i]), private, err_msg=f"client {i}")
+        want = [[HEADS[j] for j in np.nonzero(r >= 0.02)[0]] for r in private]
+        assert got[i]["hits"] == [w for w in want if w], f"client {i}"
+    assert any(g["hits"] for g in got)
