@@ -176,3 +176,37 @@ def test_fan_in_server_gives_each_client_private_scores():
         want = [[HEADS[j] for j in np.nonzero(r >= 0.02)[0]] for r in private]
         assert got[i]["hits"] == [w for w in want if w], f"client {i}"
     assert any(g["hits"] for g in got)
+
+
+def test_masked_step_properties_at_scale():
+    """65,536 x 3 (BASELINE configs[2]): an all-ones mask is oww_step bit for bit, an all-zeros step changes nothing, and a
+    half-on mask equals a plain step on exactly the rows it names -- checked on every stream (the oracle is not needed for
+    these identities)."""
+    import torch
+    S, T = 65536, 12
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(17)
+    pcm = [(torch.randn(S, 1280, device=dev, generator=g) * 3000).round().clamp(-32768, 32767).to(torch.int16) for _ in range(T)]
+    a, b = _engine(S), _engine(S)
+    on_all = np.ones(S, np.uint8)
+    half = (np.arange(S) * 2654435761 >> 7) & 1
+    half = half.astype(np.uint8)
+    zeros = np.zeros(S, np.uint8)
+    last = None
+    for t in range(T):
+        x = pcm[t].cpu().numpy()
+        sa = a.step_masked(x, on_all)
+        sb = b.step(x)
+        np.testing.assert_array_equal(sa, sb)
+        if t == 5:                                              # three steps nobody takes part in
+            for _ in range(3):
+                np.testing.assert_array_equal(a.step_masked(pcm[0].cpu().numpy(), zeros), sa)
+        last = sb
+    # half the streams advance in a, all of them in b: the advanced rows agree, the others repeat a's previous scores
+    x = pcm[3].cpu().numpy()
+    sa = a.step_masked(x, half)
+    sb = b.step(x)
+    np.testing.assert_array_equal(sa[half == 1], sb[half == 1])
+    np.testing.assert_array_equal(sa[half == 0], last[half == 0])
+    assert (sb != last).any()
+    a.close(); b.close()
