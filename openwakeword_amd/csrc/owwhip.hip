@@ -632,6 +632,7 @@ int do_reset(oww_ctx* h, const int* d_ids, int n, const float* d_featinit) {
         p.dst[a] = h->d_state[a]; p.tmpl[a] = h->d_tmpl[a]; p.len[a] = h->state_len[a];
         p.spg[a] = h->rr ? kStateSpgRr[a] : 1; p.fpos[a] = h->rr ? kStateFposRr[a] : 16;
     }
+    p.interleaved = h->hx && owh::kInterleave;
     p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.npred = h->d_npred;
     p.ring = h->d_ring; p.ring_len = h->NL * OWW_SCORE_RING;
     p.feat = h->d_feat; p.feat_len = h->TR * OWW_EMB_DIM; p.feat_init = d_featinit;

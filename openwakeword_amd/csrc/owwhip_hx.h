@@ -203,12 +203,35 @@ __device__ __forceinline__ f32x4 bn_act_t(const f32x4 v, const float* __restrict
     return f32x4{owr::leaky_clamp(v[0] * s0 + h0), owr::leaky_clamp(v[1] * s1 + h1), 0.f, 0.f};
 }
 
+// Position order inside a 16-position tile of stages C, D, E (F = 8, 4, 2 mel positions per stream, SPT = 16 / F streams per tile).
+// The fp32 family keeps a stream's positions together (position p = F * stream + mel), so a +-1 mel shift of the per-tap
+// accumulators of a 1x3 layer is a DPP row shift by one lane plus a select that zeroes what crossed a stream boundary: 2 extra
+// VALU per value and tap.  The f16-split family INTERLEAVES the streams instead: p = SPT * mel + stream.  A mel shift is then a row
+// shift by SPT lanes, and exactly the lanes that would read across a stream's edge are the ones the shift leaves without a source:
+// DPP bound_ctrl zero-fills them and no select is needed (5.3 -> 2.5 VALU per value in the tap combine of stages C, D, E).
+// Everything that maps a lane to a (stream, mel position) goes through tile_stream / tile_mel: the pooled hand-over stores, the
+// per-lane participation mask, the debug dump, and owk::reset_kernel on the host side (owh::kInterleave).
+#ifndef OWH_INTERLEAVE
+#define OWH_INTERLEAVE 1
+#endif
+constexpr bool kInterleave = OWH_INTERLEAVE != 0;
+template <int F> __device__ __forceinline__ int tile_stream(int pos) { return kInterleave ? pos % (16 / F) : pos / F; }
+template <int F> __device__ __forceinline__ int tile_mel(int pos) { return kInterleave ? pos / (16 / F) : pos % F; }
+template <int F> __device__ __forceinline__ int tile_pos(int stream, int mel) { return kInterleave ? mel * (16 / F) + stream : stream * F + mel; }
+// lane p <- x[p - N] / x[p + N] inside the 16-lane row, lanes without a source <- 0
+template <int N> __device__ __forceinline__ float dpp_shr_zero(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xf, 0xf, true));
+}
+template <int N> __device__ __forceinline__ float dpp_shl_zero(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xf, 0xf, true));
+}
+
 // debug dump of the f16-split family (cf. owr::dump_tile): a half last tile keeps channel 16 ct + 2j + e in register e < 2
 template <int NCT, int F, int C>
 __device__ __forceinline__ void dump_tile_ht(const f32x4 (&t)[NCT], float* __restrict__ dbg, size_t stride, int off, int s_first,
                                              int row, int S, int lane) {
     const int pos = lane & 15, j = lane >> 4;
-    const int sp = pos / F, f = pos % F, s = s_first + sp;
+    const int sp = tile_stream<F>(pos), f = tile_mel<F>(pos), s = s_first + sp;
     if (s >= S) return;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -285,6 +308,9 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
     // stream-boundary masks as 0/1 values (used as select conditions, or as multipliers with OWH_MASKSEL=0)
+    // (interleaved order: the row shift by SH = 16 / F lanes zero-fills exactly the stream-edge lanes and the masks are not used)
+    constexpr int SH = kInterleave ? 16 / F : 1;
+    constexpr bool MASKS = F < 16 && !kInterleave;
     const float mfirst = (pos & (F - 1)) == 0 ? 0.f : 1.f, mlast = (pos & (F - 1)) == F - 1 ? 0.f : 1.f;
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
@@ -306,10 +332,10 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #if OWH_MASKSEL
                     for (int e = 0; e < 4; ++e) {
                         if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
-                        const float l = dpp_shr1_zero(accs[0][t][e]); acc[t][e] = (F < 16 && mfirst == 0.f) ? 0.f : l;
+                        const float l = dpp_shr_zero<SH>(accs[0][t][e]); acc[t][e] = (MASKS && mfirst == 0.f) ? 0.f : l;
                     }
 #else
-                    for (int e = 0; e < 4; ++e) acc[t][e] = F < 16 ? dpp_shr1_zero(accs[0][t][e]) * mfirst : dpp_shr1_zero(accs[0][t][e]);
+                    for (int e = 0; e < 4; ++e) acc[t][e] = MASKS ? dpp_shr_zero<SH>(accs[0][t][e]) * mfirst : dpp_shr_zero<SH>(accs[0][t][e]);
 #endif
                 }
             }
@@ -332,10 +358,10 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                     for (int e = 0; e < 4; ++e) {
 #if OWH_MASKSEL
                         if (HOUT && oct == NCTO - 1 && e >= 2) { res[t][e] = 0.f; continue; }
-                        const float hh = dpp_shl1_zero(accs[1][t][e]);
-                        res[t][e] = acc[t][e] + ((F < 16 && mlast == 0.f) ? 0.f : hh);
+                        const float hh = dpp_shl_zero<SH>(accs[1][t][e]);
+                        res[t][e] = acc[t][e] + ((MASKS && mlast == 0.f) ? 0.f : hh);
 #else
-                        res[t][e] = F < 16 ? fmaf(dpp_shl1_zero(accs[1][t][e]), mlast, acc[t][e]) : acc[t][e] + dpp_shl1_zero(accs[1][t][e]);
+                        res[t][e] = MASKS ? fmaf(dpp_shl_zero<SH>(accs[1][t][e]), mlast, acc[t][e]) : acc[t][e] + dpp_shl_zero<SH>(accs[1][t][e]);
 #endif
                     }
                 }
@@ -604,7 +630,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const int s_first = g * C::SPT;
     // masked steps (oww_step_masked): a stream that sits this step out is computed like any other (the workgroup shares its weight
     // stream) but none of its state, hand-over or output is stored; per lane, because a tile holds 16 / F streams
-    const bool lane_on = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (lane & 15) / F, p.S - 1)] != 0);
+    const bool lane_on = active && (p.stream_on == nullptr || p.stream_on[min(s_first + tile_stream<F>(lane & 15), p.S - 1)] != 0);
     float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
     float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
 
@@ -725,10 +751,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         constexpr int FO = C::FO, RO = C::RO;
         constexpr int SPTN = 16 / FO;
         const int pos = lane & 15, j = lane >> 4;
-        const int sp = pos / F, f = pos % F;
+        const int sp = tile_stream<F>(pos), f = tile_mel<F>(pos);
         const int s = g * C::SPT + sp;
         const int gn = s / SPTN, spn = s % SPTN;
-        const int posn = spn * FO + f / 2;
+        const int posn = tile_pos<FO>(spn, f / 2);                     // (the consumer's own position order)
+        constexpr int SH = kInterleave ? C::SPT : 1;                   // lanes between a stream's neighbouring mel positions
 #pragma unroll
         for (int ro = 0; ro < R / C::PT; ++ro) {
             float pm[NCT][4];
@@ -739,7 +766,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
                     if (C::HOUT && ct == NCT - 1 && e >= 2) { pm[ct][e] = 0.f; continue; }      // padding registers of the half tile
                     float m = Y[ro * C::PT][ct][e];
                     if (C::PT == 2) m = fmax_nc(m, Y[ro * C::PT + 1][ct][e]);
-                    pm[ct][e] = fmax_nc(m, dpp_shl1_zero(m));
+                    pm[ct][e] = fmax_nc(m, dpp_shl_zero<SH>(m));
                 }
             if ((f & 1) == 0) {                                        // one predicated region per pooled row
                 float* xo = p.xout + ((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4)) * 64 + j * 16 + posn;
@@ -755,13 +782,15 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         static_assert(!LAST || (C::RO == 1 && C::FO == 1 && NCT == 6), "last stage pools to one position, 96 channels");
         const int pos = lane & 15, j = lane >> 4;
         f32x4 Pl[NCT];
-        const int src = (j * 16 + 2 * (pos & 7)) * 4;
+        // the pooled value of stream sp sits at the lane of its mel position 0; lanes 8..15 mirror lanes 0..7
+        const int src = (j * 16 + tile_pos<F>(pos & 7, 0)) * 4;
+        constexpr int SH = kInterleave ? C::SPT : 1;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float m = fmax_nc(Y[0][ct][e], Y[1][ct][e]);
-                m = fmax_nc(m, dpp_shl1_zero(m));
+                m = fmax_nc(m, dpp_shl_zero<SH>(m));
                 Pl[ct][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, m)));
             }
         float* h19 = p.hist19 + (size_t)g * (2 * NCT * 4 * 64);

@@ -1289,6 +1289,7 @@ struct ResetParams {
     int len[16];             // floats per stream
     int spg[16];             // streams per group block (register-dump layouts interleave the streams of a wave; 1 = plain)
     int fpos[16];            // positions per stream inside the 16 positions of a tile (when spg > 1)
+    int interleaved;         // position order of such a tile: 0 = fpos * stream + mel (fp32 family), 1 = spg * mel + stream (f16-split family)
     int16_t* tail;
     uint32_t* nfeat;
     uint32_t* npred;
@@ -1304,10 +1305,10 @@ __global__ void reset_kernel(ResetParams p) {
         if (p.spg[a] <= 1) {
             for (int i = threadIdx.x; i < p.len[a]; i += blockDim.x) p.dst[a][(size_t)s * p.len[a] + i] = p.tmpl[a][i];
         } else {
-            // block of spg streams in register-dump order [..][64 lanes]: stream sp owns the lanes whose position / fpos == sp
+            // block of spg streams in register-dump order [..][64 lanes]: stream sp owns the lanes whose position maps to it
             const int bl = p.len[a] * p.spg[a], g = s / p.spg[a], sp = s % p.spg[a];
             for (int i = threadIdx.x; i < bl; i += blockDim.x)
-                if (((i & 15) / p.fpos[a]) == sp) p.dst[a][(size_t)g * bl + i] = p.tmpl[a][i];
+                if ((p.interleaved ? (i & 15) % p.spg[a] : (i & 15) / p.fpos[a]) == sp) p.dst[a][(size_t)g * bl + i] = p.tmpl[a][i];
         }
     }
     for (int i = threadIdx.x; i < 480; i += blockDim.x) p.tail[(size_t)s * 480 + i] = 0;
