@@ -384,6 +384,102 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     }
 }
 
+// K-merged form of a 1x3 (mel) layer whose input has a half remainder tile (72 = 64 + 8 channels: stage C layer c, stage D layer a).
+// The per-tap accumulator chains keep their KSF full k-steps; the three taps' 8-channel remainders -- each a single operand dword
+// per lane -- share ONE k-step that feeds the centre chain directly: its B operand carries, for position p, the remainder channels of
+// positions p-1, p, p+1 in dwords 0, 1, 2 (two DPP row shifts per tile and part, done once per layer: the operand is the same for
+// every output tile; interleaved position order, so the shifts zero-fill the stream edges themselves).  7 instead of 9 k-steps per
+// output tile; the weights come in pack_hx_tm order (same pair index = tap rule as the time layers).
+#ifndef OWH_KMERGE_MEL
+#define OWH_KMERGE_MEL 1
+#endif
+template <int KSI, int NT, int F>
+__device__ __forceinline__ void merge_mel_rems(const Op (&in)[NT][KSI], Op (&M)[NT]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(kInterleave || F == 16, "the operand shift relies on the zero fill at the stream edges");
+    constexpr int SH = 16 / F;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const unsigned h = __builtin_bit_cast(u32x4, in[t][KSI - 1].h)[0], l = __builtin_bit_cast(u32x4, in[t][KSI - 1].l)[0];
+        u32x4 mh, ml;
+        mh[0] = __builtin_amdgcn_update_dpp(0, h, 0x110 + SH, 0xf, 0xf, true);  mh[1] = h;
+        mh[2] = __builtin_amdgcn_update_dpp(0, h, 0x100 + SH, 0xf, 0xf, true);  mh[3] = 0u;
+        ml[0] = __builtin_amdgcn_update_dpp(0, l, 0x110 + SH, 0xf, 0xf, true);  ml[1] = l;
+        ml[2] = __builtin_amdgcn_update_dpp(0, l, 0x100 + SH, 0xf, 0xf, true);  ml[3] = 0u;
+        M[t].h = __builtin_bit_cast(f16x8, mh); M[t].l = __builtin_bit_cast(f16x8, ml);
+        pin_op(M[t]);
+    }
+}
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
+__device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT], f32x4 (&out)[NT][NCTO], float* wbuf,
+                                             const float* __restrict__ w, const float* __restrict__ w_next,
+                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
+                                             lanemask_t& bad) {
+    using namespace owr;
+    const int j = lane >> 4;
+    constexpr int SH = 16 / F, KSF = KSI - 1;
+    constexpr int NBLK = (3 * KSF + 1) * 2;
+#pragma unroll
+    for (int oct = 0; oct < NCTO; ++oct) {
+        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
+        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+        f32x4 res[NT], accs[2][NT];
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
+            const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
+                        acc[t][e] = dpp_shr_zero<SH>(accs[0][t][e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSF + (ti == 2 ? 1 : 0); ++ks) {
+                const int blk = ks < KSF ? (tap * KSF + ks) * 2 : 3 * KSF * 2;
+                const f16x8 ah = lds_h(cur, blk + 0, lane);
+                const f16x8 al = lds_h(cur, blk + 1, lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].h : M[t].h, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].l : M[t].l, acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(al, ks < KSF ? in[t][ks].h : M[t].h, acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (ti < 2) accs[ti][t] = acc[t];
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (HOUT && oct == NCTO - 1 && e >= 2) { res[t][e] = 0.f; continue; }
+                        res[t][e] = acc[t][e] + dpp_shl_zero<SH>(accs[1][t][e]);
+                    }
+                }
+            }
+        }
+        if (oct == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) nan_guard(bad, res[t][0]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (HOUT && oct == NCTO - 1) out[t][oct] = bn_act_t<BN, true>(res[t], scale, shift, oct, j);
+            else out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j);
+            pin(out[t][oct]);
+        }
+        OWH_OCT_SB();
+        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+    }
+}
+
 // 3x1 (time) layer: rows h0, h1 (history) and in[0..NR-1] in operand form; out row r uses rows r, r+1, r+2.
 // Software pipelined over the output-channel tiles: the MFMA chain of tile k is issued interleaved with the BatchNorm /
 // activation epilogue of tile k-1 (a wave issues in order, so VALU work only overlaps a MFMA if it sits between two MFMAs
@@ -610,6 +706,10 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     using TK = TimeK<NCT, C::HOUT>;
     constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
     constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
+    // 1x3 layers whose 72-channel input leaves a half remainder tile, in the K-merged form (conv_mel_hxm): layer a of stage D, c of C
+    constexpr bool MMA = OWH_KMERGE_MEL && kInterleave && C::HIN && NCTI % 2 == 1 && NCTI >= 3;
+    constexpr bool MMC = OWH_KMERGE_MEL && kInterleave && C::HOUT && NCT % 2 == 1 && NCT >= 3;
+    constexpr int NBAM = MMA ? (3 * (KSA - 1) + 1) * 2 : NBA, NBCM = MMC ? (3 * (KS - 1) + 1) * 2 : NB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
@@ -621,7 +721,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 #ifdef OWH_SETPRIO
     if (wave & 1) __builtin_amdgcn_s_setprio(OWH_SETPRIO);        // (A/B: static priority for half the waves of a SIMD)
 #endif
-    issue_chunk<NBA, WG>(p.w[0], wbuf, wave, lane);
+    issue_chunk<NBAM, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
         sbn[l][0][c] = p.scale[l][c];
@@ -647,6 +747,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if (pass == 0) chunk_sync();
 
     // conv a: 1x3, CIN -> C
+    if constexpr (MMA) {
+        Op Mx[R];
+        merge_mel_rems<KSA, R, F>(Xo, Mx);
+        conv_mel_hxm<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
+    } else
     conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -672,7 +777,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NB, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -689,7 +794,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NB, WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -699,6 +804,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
+    if constexpr (MMC) {
+        Op Mc[R];
+        merge_mel_rems<KS, R, F>(Ao, Mc);
+        conv_mel_hxm<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+    } else
     conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -723,7 +833,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBA : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3][0], sbn[3][1], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3][0], sbn[3][1], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -740,7 +850,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
