@@ -603,17 +603,21 @@ __device__ __forceinline__ void merge_rems(const RemPairs (&rem)[NR + 2], Op (&M
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        u32x4 h[NMK], l[NMK];
+        // (scalar arrays with compile-time indices after unrolling: a vector element written through a loop index is not promoted to
+        //  registers reliably and ended up in scratch)
+        unsigned h[NMK * 4], l[NMK * 4];
 #pragma unroll
-        for (int mk = 0; mk < NMK; ++mk) { h[mk] = u32x4{0u, 0u, 0u, 0u}; l[mk] = u32x4{0u, 0u, 0u, 0u}; }
-#pragma unroll
-        for (int pi = 0; pi < 3 * NPR; ++pi) {
-            const int tap = pi / NPR, v = pi % NPR;
-            h[pi / 4][pi % 4] = rem[r + tap].h[v];
-            l[pi / 4][pi % 4] = rem[r + tap].l[v];
+        for (int i = 0; i < NMK * 4; ++i) {
+            const int tap = i / NPR, v = i % NPR;
+            h[i] = i < 3 * NPR ? rem[r + (tap < 3 ? tap : 0)].h[v] : 0u;
+            l[i] = i < 3 * NPR ? rem[r + (tap < 3 ? tap : 0)].l[v] : 0u;
         }
 #pragma unroll
-        for (int mk = 0; mk < NMK; ++mk) { M[r][mk].h = __builtin_bit_cast(f16x8, h[mk]); M[r][mk].l = __builtin_bit_cast(f16x8, l[mk]); pin_op(M[r][mk]); }
+        for (int mk = 0; mk < NMK; ++mk) {
+            M[r][mk].h = __builtin_bit_cast(f16x8, u32x4{h[4 * mk], h[4 * mk + 1], h[4 * mk + 2], h[4 * mk + 3]});
+            M[r][mk].l = __builtin_bit_cast(f16x8, u32x4{l[4 * mk], l[4 * mk + 1], l[4 * mk + 2], l[4 * mk + 3]});
+            pin_op(M[r][mk]);
+        }
     }
 }
 
