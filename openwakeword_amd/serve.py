@@ -139,7 +139,14 @@ class FanInServer:
             await ws.send_str(json.dumps({"loaded_models": list(self.model.labels)}))
             async for msg in ws:
                 if msg.type == WSMsgType.TEXT:
-                    c.rate = int(msg.data)
+                    try:
+                        rate = int(msg.data)
+                    except ValueError:
+                        rate = 0
+                    if not 1000 <= rate <= 384000:          # (the example trusts the client here; a bad value would poison the resampler)
+                        await ws.close(code=1003, message=b"the first text message must be the sample rate in Hz")
+                        break
+                    c.rate = rate
                 elif msg.type == WSMsgType.BINARY:
                     n = len(msg.data) // 2
                     c.push(to_16k(np.frombuffer(msg.data, dtype="<i2", count=n), c.rate))

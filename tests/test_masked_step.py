@@ -210,3 +210,52 @@ def test_masked_step_properties_at_scale():
     np.testing.assert_array_equal(sa[half == 0], last[half == 0])
     assert (sb != last).any()
     a.close(); b.close()
+
+
+def test_fan_in_server_slot_reuse_and_refusal():
+    """Two slots: a third simultaneous client is refused (close code 1013); when a client leaves, the next one gets its slot in
+    the state of a fresh model (first-5 zeroing, empty sample tail, initial feature ring) -- its scores equal a private engine's."""
+    from aiohttp import WSMsgType
+    from aiohttp.test_utils import TestClient, TestServer
+    from openwakeword_amd.model import BatchedModel
+    from openwakeword_amd.serve import FanInServer
+
+    rng = np.random.default_rng(21)
+    heads = {n: W.synthetic_head(n, seed=11 + i) for i, n in enumerate(HEADS)}
+    model = BatchedModel(2, HEADS, weights={"heads": heads, "embedding": W.synthetic_embedding(seed=3)})
+    tap = {}
+    srv = FanInServer(model, threshold=2.0, window_s=0.0, on_scores=lambda slot, k, row: tap.setdefault(slot, []).append(row.copy()))
+    first = (rng.standard_normal(1280 * 12) * 6000).astype(np.int16)
+    second = (rng.standard_normal(1280 * 9) * 2000).astype(np.int16)
+
+    async def run():
+        async with TestClient(TestServer(srv.app())) as tc:
+            a = await tc.ws_connect("/ws"); await a.receive()
+            b = await tc.ws_connect("/ws"); await b.receive()
+            c = await tc.ws_connect("/ws")
+            msg = await c.receive()
+            assert msg.type in (WSMsgType.CLOSE, WSMsgType.CLOSING, WSMsgType.CLOSED) and c.close_code == 1013
+            await a.send_str("16000")
+            await a.send_bytes(first.tobytes())                       # one message, twelve chunks
+            while len(tap.get(0, [])) < 12:
+                await asyncio.sleep(0.01)
+            await a.close()
+            while 0 in srv.clients:
+                await asyncio.sleep(0.01)
+            n_before = len(tap[0])
+            d = await tc.ws_connect("/ws"); await d.receive()        # takes over slot 0
+            assert sorted(srv.clients) == [0, 1]
+            await d.send_bytes(second.tobytes())
+            while len(tap[0]) < n_before + 9:
+                await asyncio.sleep(0.01)
+            await d.close(); await b.close()
+            return n_before
+
+    n_before = asyncio.run(asyncio.wait_for(run(), 60))
+    model.close()
+    for audio, got in ((first, tap[0][:n_before]), (second, tap[0][n_before:])):
+        e = _engine(1)
+        want = np.stack([e.step(audio[None, k * 1280:(k + 1) * 1280])[0] for k in range(audio.size // 1280)])
+        e.close()
+        np.testing.assert_array_equal(np.stack(got), want)
+    assert (np.stack(tap[0][n_before:n_before + 5]) == 0).all()        # model.py:331-333 for the new owner of the slot
