@@ -47,8 +47,8 @@ PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA dense peak
 PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
 # f16 MFMAs (v_mfma_f32_16x16x32_f16, 16384 flop each) the fp16-split kernels execute per stream-step, channel padding included
 # (round 2: the layers with a 72-channel input run K-merged -- 7 instead of 9 k-steps per output tile -- i.e. layers b, c, d of
-#  stage C: 810 instead of 990, and layer a of stage D: 306 instead of 324)
-HX_MFMAS = {"stageA": 672, "stageB": 756, "stageC": 810, "stageD": 306, "stageE": 182}
+#  stage C: 810 instead of 990, and layer a of stage D: 306 instead of 324; layer a of stage C, 48 channels in, 5 instead of 6: 780)
+HX_MFMAS = {"stageA": 672, "stageB": 756, "stageC": 780, "stageD": 306, "stageE": 182}
 PEAK_HBM_GBS = 8000.0
 REALTIME_STEPS_PER_S = 12.5  # one 80 ms frame per stream every 80 ms
 

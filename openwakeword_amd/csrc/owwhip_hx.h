@@ -393,32 +393,46 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #ifndef OWH_KMERGE_MEL
 #define OWH_KMERGE_MEL 1
 #endif
-template <int KSI, int NT, int F>
-__device__ __forceinline__ void merge_mel_rems(const Op (&in)[NT][KSI], Op (&M)[NT]) {
+// NPR = operand dwords (f16 pairs) of the remainder tile per lane: 1 for a half tile (72 = 64 + 8), 2 for a full one (48 = 32 + 16: the
+// three taps' 16-channel remainders fill 2 k-steps instead of 3; 8 more operand registers per tile, so only where the budget has them:
+// layer a of stage C, OWH_KMERGE_MEL2)
+#ifndef OWH_KMERGE_MEL2
+#define OWH_KMERGE_MEL2 1
+#endif
+template <int KSI, int NT, int F, int NPR>
+__device__ __forceinline__ void merge_mel_rems(const Op (&in)[NT][KSI], Op (&M)[NT][(3 * NPR + 3) / 4]) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     static_assert(kInterleave || F == 16, "the operand shift relies on the zero fill at the stream edges");
-    constexpr int SH = 16 / F;
+    constexpr int SH = 16 / F, NMK = (3 * NPR + 3) / 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const unsigned h = __builtin_bit_cast(u32x4, in[t][KSI - 1].h)[0], l = __builtin_bit_cast(u32x4, in[t][KSI - 1].l)[0];
-        u32x4 mh, ml;
-        mh[0] = __builtin_amdgcn_update_dpp(0, h, 0x110 + SH, 0xf, 0xf, true);  mh[1] = h;
-        mh[2] = __builtin_amdgcn_update_dpp(0, h, 0x100 + SH, 0xf, 0xf, true);  mh[3] = 0u;
-        ml[0] = __builtin_amdgcn_update_dpp(0, l, 0x110 + SH, 0xf, 0xf, true);  ml[1] = l;
-        ml[2] = __builtin_amdgcn_update_dpp(0, l, 0x100 + SH, 0xf, 0xf, true);  ml[3] = 0u;
-        M[t].h = __builtin_bit_cast(f16x8, mh); M[t].l = __builtin_bit_cast(f16x8, ml);
-        pin_op(M[t]);
+        const u32x4 sh = __builtin_bit_cast(u32x4, in[t][KSI - 1].h), sl = __builtin_bit_cast(u32x4, in[t][KSI - 1].l);
+        unsigned h[NMK * 4], l[NMK * 4];
+#pragma unroll
+        for (int i = 0; i < NMK * 4; ++i) {                   // pair index i = tap * NPR + v (pack_hx_tm)
+            const int tap = i / NPR, v = i % NPR;
+            if (i >= 3 * NPR) { h[i] = 0u; l[i] = 0u; }
+            else if (tap == 0) { h[i] = __builtin_amdgcn_update_dpp(0, sh[v], 0x110 + SH, 0xf, 0xf, true); l[i] = __builtin_amdgcn_update_dpp(0, sl[v], 0x110 + SH, 0xf, 0xf, true); }
+            else if (tap == 2) { h[i] = __builtin_amdgcn_update_dpp(0, sh[v], 0x100 + SH, 0xf, 0xf, true); l[i] = __builtin_amdgcn_update_dpp(0, sl[v], 0x100 + SH, 0xf, 0xf, true); }
+            else { h[i] = sh[v]; l[i] = sl[v]; }
+        }
+#pragma unroll
+        for (int mk = 0; mk < NMK; ++mk) {
+            M[t][mk].h = __builtin_bit_cast(f16x8, u32x4{h[4 * mk], h[4 * mk + 1], h[4 * mk + 2], h[4 * mk + 3]});
+            M[t][mk].l = __builtin_bit_cast(f16x8, u32x4{l[4 * mk], l[4 * mk + 1], l[4 * mk + 2], l[4 * mk + 3]});
+            pin_op(M[t][mk]);
+        }
     }
 }
-template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
-__device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT], f32x4 (&out)[NT][NCTO], float* wbuf,
+template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
+__device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], float* wbuf,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
                                              lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int SH = 16 / F, KSF = KSI - 1;
-    constexpr int NBLK = (3 * KSF + 1) * 2;
+    constexpr int NBLK = (3 * KSF + NMK) * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
         const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
@@ -442,16 +456,17 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
                 }
             }
 #pragma unroll
-            for (int ks = 0; ks < KSF + (ti == 2 ? 1 : 0); ++ks) {
-                const int blk = ks < KSF ? (tap * KSF + ks) * 2 : 3 * KSF * 2;
+            for (int ks = 0; ks < KSF + (ti == 2 ? NMK : 0); ++ks) {
+                const int mk = ks < KSF ? 0 : ks - KSF;
+                const int blk = ks < KSF ? (tap * KSF + ks) * 2 : (3 * KSF + mk) * 2;
                 const f16x8 ah = lds_h(cur, blk + 0, lane);
                 const f16x8 al = lds_h(cur, blk + 1, lane);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].h : M[t].h, acc[t]);
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].h : M[t][mk].h, acc[t]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].l : M[t].l, acc[t]);
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].l : M[t][mk].l, acc[t]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(al, ks < KSF ? in[t][ks].h : M[t].h, acc[t]);
+                for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(al, ks < KSF ? in[t][ks].h : M[t][mk].h, acc[t]);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -711,9 +726,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
     constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
     // 1x3 layers whose 72-channel input leaves a half remainder tile, in the K-merged form (conv_mel_hxm): layer a of stage D, c of C
-    constexpr bool MMA = OWH_KMERGE_MEL && kInterleave && C::HIN && NCTI % 2 == 1 && NCTI >= 3;
+    constexpr bool MMA2 = OWH_KMERGE_MEL && OWH_KMERGE_MEL2 && kInterleave && !C::HIN && NCTI % 2 == 1 && NCTI >= 3 && C::WPS == 2;   // C layer a (48 in)
+    constexpr bool MMA = (OWH_KMERGE_MEL && kInterleave && C::HIN && NCTI % 2 == 1 && NCTI >= 3) || MMA2;
+    constexpr int NPRA = MMA2 ? 2 : 1, NMKA = (3 * NPRA + 3) / 4;
     constexpr bool MMC = OWH_KMERGE_MEL && kInterleave && C::HOUT && NCT % 2 == 1 && NCT >= 3;
-    constexpr int NBAM = MMA ? (3 * (KSA - 1) + 1) * 2 : NBA, NBCM = MMC ? (3 * (KS - 1) + 1) * 2 : NB;
+    constexpr int NBAM = MMA ? (3 * (KSA - 1) + NMKA) * 2 : NBA, NBCM = MMC ? (3 * (KS - 1) + 1) * 2 : NB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
@@ -752,9 +769,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 
     // conv a: 1x3, CIN -> C
     if constexpr (MMA) {
-        Op Mx[R];
-        merge_mel_rems<KSA, R, F>(Xo, Mx);
-        conv_mel_hxm<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
+        Op Mx[R][NMKA];
+        merge_mel_rems<KSA, R, F, NPRA>(Xo, Mx);
+        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
     } else
     conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
@@ -809,9 +826,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
     if constexpr (MMC) {
-        Op Mc[R];
-        merge_mel_rems<KS, R, F>(Ao, Mc);
-        conv_mel_hxm<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+        Op Mc[R][1];
+        merge_mel_rems<KS, R, F, 1>(Ao, Mc);
+        conv_mel_hxm<KS, 1, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     } else
     conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
