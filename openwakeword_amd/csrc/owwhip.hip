@@ -945,7 +945,8 @@ int oww_commit(oww_ctx* h) {
                 // 1x3 layers with a 72-channel input (stage C layer c, stage D layer a): owh::conv_mel_hxm, same packing rule
                 const bool mel_merged = OWH_KMERGE_MEL && owh::kInterleave && L.kh == 1 && L.kw == 3 &&
                                         ((L.cin + 15) / 16) % 2 == 1 && (L.cin + 15) / 16 >= 3 &&
-                                        (L.cin % 16 == 8 || (OWH_KMERGE_MEL2 && l == 7 && OWH_WPS_C == 2));    // (l == 7: stage C layer a, 48 -> 72)
+                                        (L.cin % 16 == 8 || (OWH_KMERGE_MEL2 && l == 7 && OWH_WPS_C == 2) ||   // (l == 7: stage C layer a, 48 -> 72)
+                                         (OWH_KMERGE_MEL2B && l == 5));                                   // (l == 5: stage B layer c, A/B switch)
                 if (l == 0) pack_hx_conv0(q, pk);
                 else if (time_merged || mel_merged) pack_hx_tm(q, L.cin, L.cout, pk);
                 else pack_hx(q, 3, L.cin, L.cout, pk);

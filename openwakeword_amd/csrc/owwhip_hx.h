@@ -729,8 +729,13 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     constexpr bool MMA2 = OWH_KMERGE_MEL && OWH_KMERGE_MEL2 && kInterleave && !C::HIN && NCTI % 2 == 1 && NCTI >= 3 && C::WPS == 2;   // C layer a (48 in)
     constexpr bool MMA = (OWH_KMERGE_MEL && kInterleave && C::HIN && NCTI % 2 == 1 && NCTI >= 3) || MMA2;
     constexpr int NPRA = MMA2 ? 2 : 1, NMKA = (3 * NPRA + 3) / 4;
-    constexpr bool MMC = OWH_KMERGE_MEL && kInterleave && C::HOUT && NCT % 2 == 1 && NCT >= 3;
-    constexpr int NBAM = MMA ? (3 * (KSA - 1) + NMKA) * 2 : NBA, NBCM = MMC ? (3 * (KS - 1) + 1) * 2 : NB;
+#ifndef OWH_KMERGE_MEL2B
+#define OWH_KMERGE_MEL2B 0     // layer c of stage B (48 -> 48) in the same form: see DESIGN.md 5.2 for the measurement
+#endif
+    constexpr bool MMC2 = OWH_KMERGE_MEL && OWH_KMERGE_MEL2B && !C::HOUT && NCT % 2 == 1 && NCT >= 3 && !LAST;      // B layer c
+    constexpr bool MMC = (OWH_KMERGE_MEL && kInterleave && C::HOUT && NCT % 2 == 1 && NCT >= 3) || MMC2;
+    constexpr int NPRC = MMC2 ? 2 : 1, NMKC = (3 * NPRC + 3) / 4;
+    constexpr int NBAM = MMA ? (3 * (KSA - 1) + NMKA) * 2 : NBA, NBCM = MMC ? (3 * (KS - 1) + NMKC) * 2 : NB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
@@ -826,9 +831,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
     if constexpr (MMC) {
-        Op Mc[R][1];
-        merge_mel_rems<KS, R, F, 1>(Ao, Mc);
-        conv_mel_hxm<KS, 1, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+        Op Mc[R][NMKC];
+        merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
+        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     } else
     conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
     if (DBG && p.dbg && active) {
