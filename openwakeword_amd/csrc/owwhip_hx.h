@@ -289,7 +289,7 @@ using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, OWH_WPS_D>;
 using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
 #ifndef OWH_OCT_SCHEDBAR
-#define OWH_OCT_SCHEDBAR 1
+#define OWH_OCT_SCHEDBAR 0     // a scheduling barrier after every output tile: C +1.6 %, D / E +0.5 % slower with it (and 12 bytes of scratch in C)
 #endif
 #if OWH_OCT_SCHEDBAR
 #define OWH_OCT_SB() __builtin_amdgcn_sched_barrier(0)
@@ -505,7 +505,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #ifndef OWH_PIPE_VALU
 #define OWH_PIPE_VALU 2
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane,
@@ -558,15 +558,13 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
                 pin(out[r][oct - 1]);
             }
         }
-#if OWH_PIPE
-        if (oct > 0 && oct < NCTO) {
+        if (PIPE && oct > 0 && oct < NCTO) {
 #pragma unroll
             for (int i = 0; i < 9 * KSI * NR; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, OWH_PIPE_VALU, 0);
             }
         }
-#endif
         if (oct < NCTO) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) prev[r] = acc[r];
@@ -725,6 +723,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     using TK = TimeK<NCT, C::HOUT>;
     constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
     constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
+    constexpr bool PIPE = OWH_PIPE != 0;
     // 1x3 layers whose 72-channel input leaves a half remainder tile, in the K-merged form (conv_mel_hxm): layer a of stage D, c of C
     constexpr bool MMA2 = OWH_KMERGE_MEL && OWH_KMERGE_MEL2 && kInterleave && !C::HIN && NCTI % 2 == 1 && NCTI >= 3 && C::WPS == 2;   // C layer a (48 in)
     constexpr bool MMA = (OWH_KMERGE_MEL && kInterleave && C::HIN && NCTI % 2 == 1 && NCTI >= 3) || MMA2;
@@ -820,7 +819,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -876,7 +875,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
