@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OWW_ABI_VERSION 2
+#define OWW_ABI_VERSION 3
 
 #define OWW_OK            0
 #define OWW_EINVAL       -1   /* bad argument */

@@ -8,7 +8,7 @@ import os
 from . import _build
 
 _lib = None
-ABI_VERSION = 2          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
+ABI_VERSION = 3          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
 ERANGE = -5
 
 
