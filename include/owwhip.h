@@ -162,6 +162,9 @@ int  oww_range_status(oww_ctx* h, int clear);
  * unmodified until the matching oww_collect returns; use page-locked memory (oww_host_alloc, hipHostMalloc,
  * torch pin_memory) -- pageable memory works but makes the upload synchronous.  Results are identical to oww_step. */
 int  oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks);
+/* oww_submit for the streams with stream_on[s] != 0 only (one chunk; see oww_step_masked): the serving edge's pipelined form.
+ * stream_on: host uint8 [S], read before the call returns. */
+int  oww_submit_masked(oww_ctx* h, const int16_t* pcm, const uint8_t* stream_on);
 int  oww_collect(oww_ctx* h, float* scores);
 int  oww_host_alloc(void** out, size_t nbytes);   /* page-locked host memory for PCM / score buffers */
 int  oww_host_free(void* p);

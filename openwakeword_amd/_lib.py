@@ -41,6 +41,7 @@ SYMBOLS = {
     "oww_sync": (C.c_int, [_P]),
     "oww_range_status": (C.c_int, [_P, C.c_int]),
     "oww_submit": (C.c_int, [_P, _P, C.c_int32]),
+    "oww_submit_masked": (C.c_int, [_P, _P, _P]),
     "oww_collect": (C.c_int, [_P, _P]),
     "oww_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "oww_host_free": (C.c_int, [_P]),

@@ -301,6 +301,7 @@ struct oww_ctx {
     // host-fed pipeline (oww_submit / oww_collect): two steps in flight, uploads and score downloads on their own streams
     struct IngestSlot {
         int16_t* d_pcm = nullptr; float* d_scores = nullptr; float* h_scores = nullptr;
+        uint8_t* h_on = nullptr;     // page-locked staging of a masked submit's participation mask
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
         bool busy = false;
     } slot[2];
@@ -662,6 +663,7 @@ void free_all(oww_ctx* h) {
     for (auto& sl : h->slot) {
         fr(sl.d_pcm); fr(sl.d_scores);
         if (sl.h_scores) { (void)hipHostFree(sl.h_scores); sl.h_scores = nullptr; }
+        if (sl.h_on) { (void)hipHostFree(sl.h_on); sl.h_on = nullptr; }
         for (hipEvent_t* e : {&sl.up, &sl.done, &sl.down}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         sl.busy = false;
     }
@@ -1331,6 +1333,7 @@ static int ensure_ingest(oww_ctx* h) {
         HIPCHK(hipMalloc(&sl.d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax * sizeof(int16_t)));
         HIPCHK(hipMalloc(&sl.d_scores, nb));
         HIPCHK(hipHostMalloc((void**)&sl.h_scores, nb, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&sl.h_on, h->S, hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
@@ -1338,7 +1341,18 @@ static int ensure_ingest(oww_ctx* h) {
     return 0;
 }
 
-int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) {
+static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const uint8_t* stream_on);
+
+int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) { return submit_impl(h, pcm, n_chunks, nullptr); }
+
+int oww_submit_masked(oww_ctx* h, const int16_t* pcm, const uint8_t* stream_on) {
+    if (!stream_on) return fail(OWW_EINVAL, "oww_submit_masked: stream_on is null");
+    if (h && h->committed && (!h->hx || !h->fuse || !h->generic_nets.empty()))
+        return fail(OWW_EINVAL, "oww_submit_masked: needs the fp16-split kernels with the fused front end (see oww_step_masked)");
+    return submit_impl(h, pcm, 1, stream_on);
+}
+
+static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const uint8_t* stream_on) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_submit: handle not committed");
     if (!pcm) return fail(OWW_EINVAL, "oww_submit: pcm is null");
     if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_submit: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
@@ -1352,7 +1366,18 @@ int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) {
     HIPCHK(hipMemcpyAsync(sl.d_pcm, pcm, n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, h->up_stream));
     HIPCHK(hipEventRecord(sl.up, h->up_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, sl.up, 0));
-    if (int rc = launch_step(h, sl.d_pcm, n_chunks)) return rc;
+    if (stream_on) {                                   // (the mask is small: copied on the compute stream, ordered before this step's kernels)
+        if (!h->d_on) {
+            HIPCHK(hipMalloc(&h->d_on, h->Spad));
+            HIPCHK(hipMemsetAsync(h->d_on, 0, h->Spad, h->stream));
+        }
+        memcpy(sl.h_on, stream_on, h->S);              // the caller's array is free again when this call returns
+        HIPCHK(hipMemcpyAsync(h->d_on, sl.h_on, h->S, hipMemcpyHostToDevice, h->stream));
+        h->on_now = h->d_on;
+    }
+    const int rc_step = launch_step(h, sl.d_pcm, n_chunks);
+    h->on_now = nullptr;
+    if (rc_step) return rc_step;
     const size_t nb = (size_t)h->S * h->NL * sizeof(float);
     if (nb) HIPCHK(hipMemcpyAsync(sl.d_scores, h->d_scores, nb, hipMemcpyDeviceToDevice, h->stream));   // d_scores is rewritten by the next step
     HIPCHK(hipEventRecord(sl.done, h->stream));

@@ -222,15 +222,21 @@ class StreamEngine:
                                       C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None, 1))
 
     # ---- host-fed pipeline: upload of step t+1 overlaps the kernels of step t (oww_submit / oww_collect) ----
-    def submit(self, pcm: np.ndarray) -> None:
+    def submit(self, pcm: np.ndarray, stream_on: Optional[np.ndarray] = None) -> None:
         """Enqueue one step on host PCM int16 [S, 1280*k] and return at once.  At most two steps in flight; the array
         must stay alive and unmodified until the matching collect() (use `pinned_empty` buffers for an asynchronous
-        upload).  Same results as step()."""
+        upload).  Same results as step(); with `stream_on` ([S], one chunk) as step_masked()."""
         if not isinstance(pcm, np.ndarray) or pcm.dtype != np.int16 or not pcm.flags["C_CONTIGUOUS"]:
             raise ValueError("submit expects a C-contiguous int16 ndarray")
         if pcm.ndim != 2 or pcm.shape[0] != self.n_streams or pcm.shape[1] % CHUNK or pcm.shape[1] == 0:
             raise ValueError(f"pcm must be [n_streams={self.n_streams}, 1280*k], got {pcm.shape}")
-        _lib.check(self._lib.oww_submit(self._h, _ptr(pcm), pcm.shape[1] // CHUNK))
+        if stream_on is None:
+            _lib.check(self._lib.oww_submit(self._h, _ptr(pcm), pcm.shape[1] // CHUNK))
+        else:
+            on = np.ascontiguousarray(np.asarray(stream_on) != 0, dtype=np.uint8)
+            if on.shape != (self.n_streams,) or pcm.shape[1] != CHUNK:
+                raise ValueError(f"a masked submit takes pcm [n_streams, 1280] and stream_on [n_streams], got {pcm.shape}, {on.shape}")
+            _lib.check(self._lib.oww_submit_masked(self._h, _ptr(pcm), _ptr(on)))
         self._inflight.append(pcm)                      # keeps the buffer alive until collected
 
     def collect(self, out: Optional[np.ndarray] = None) -> np.ndarray:

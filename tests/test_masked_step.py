@@ -259,3 +259,23 @@ def test_fan_in_server_slot_reuse_and_refusal():
         e.close()
         np.testing.assert_array_equal(np.stack(got), want)
     assert (np.stack(tap[0][n_before:n_before + 5]) == 0).all()        # model.py:331-333 for the new owner of the slot
+
+
+def test_masked_submit_pipeline_equals_masked_steps():
+    """oww_submit_masked with two steps in flight gives what blocking oww_step_masked calls give."""
+    rng = np.random.default_rng(31)
+    S, T = 96, 14
+    pcm = _pcm(rng, S, T)
+    on = rng.random((T, S)) < 0.7
+    a, b = _engine(S), _engine(S)
+    want = np.stack([a.step_masked(pcm[t], on[t]) for t in range(T)])
+    bufs = [b.pinned_empty((S, 1280)) for _ in range(2)]
+    got = []
+    for t in range(T):
+        bufs[t % 2][:] = pcm[t]
+        b.submit(bufs[t % 2], on[t])
+        if t >= 1:
+            got.append(b.collect().copy())
+    got.append(b.collect().copy())
+    np.testing.assert_array_equal(np.stack(got), want)
+    a.close(); b.close()
