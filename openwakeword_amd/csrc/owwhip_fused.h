@@ -145,7 +145,9 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         float* sx = xr;
 #endif
         float* pw0 = xr + 128;
-        float* pw1 = xr + 256;
+        float* pw1 = xr + 257;                    // (one word off pw0's bank phase: the two frames' tap reads below are 2-way instead of
+                                                  //  4-way bank-conflicted; rows pw0 [128, 248) and pw1 [257, 377) stay inside the
+                                                  //  words 128..383 the last FFT stage leaves unused)
         const float* s_hann = fl + FA_OFF_HANN + z;
         const float* s_tw1 = fl + FA_OFF_TW1 + z;   // [re / im][k 8][lane 64]: exp(-2 pi i lane k / 512)
         const float* s_tw2 = fl + FA_OFF_TW2 + z;   // [re / im][k 8][m0 8]:    exp(-2 pi i m0 k / 64)
