@@ -11,7 +11,8 @@ single model's streaming state.  This module keeps the example's wire protocol -
 
 -- and changes what happens behind it: every connection owns one stream slot of a `BatchedModel` (its own sample tail, conv
 histories, rings and counters on the device), the handler only appends (resampled) samples to the connection's queue, and a single
-pump coroutine gathers one 1280-sample chunk from every connection that has one and runs ONE `oww_step_masked` for all of them.
+pump coroutine gathers one 1280-sample chunk from every connection that has one and runs ONE masked step (`oww_submit_masked`) for
+all of them, two steps in flight (upload of step t+1 while the kernels of step t run).
 A connection without a full chunk sits the step out bit-exactly (no zero padding, no skipped audio), so each client gets exactly the
 scores a private `openwakeword.Model` would have produced on its own audio in 1280-sample calls.
 
@@ -24,7 +25,10 @@ from __future__ import annotations
 
 import argparse
 import asyncio
+import collections
 import json
+import queue
+import threading
 from fractions import Fraction
 from typing import Dict, List, Optional
 
@@ -49,7 +53,7 @@ def to_16k(pcm: np.ndarray, sample_rate: int) -> np.ndarray:
 
 
 class _Client:
-    __slots__ = ("slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed")
+    __slots__ = ("slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed", "in_flight")
 
     def __init__(self, slot: int, ws):
         self.slot, self.ws, self.rate = slot, ws, 16000
@@ -57,6 +61,7 @@ class _Client:
         self.n_pending = 0
         self.n_steps = 0
         self.closed = False
+        self.in_flight = 0            # submitted steps whose scores for this client have not been dispatched yet
 
     def push(self, x: np.ndarray) -> None:
         if x.size:
@@ -79,12 +84,54 @@ class _Client:
         self.n_pending -= CHUNK
 
 
+class _GpuWorker(threading.Thread):
+    """The one thread that talks to the handle (the C ABI serialises nothing itself: one caller per handle).  Jobs run in the order
+    they were posted; `call` returns an asyncio future of the job's result."""
+
+    def __init__(self, loop: asyncio.AbstractEventLoop):
+        super().__init__(daemon=True, name="owwhip-gpu")
+        self.loop = loop
+        self.jobs: "queue.Queue" = queue.Queue()
+
+    def call(self, fn, *args, **kw) -> "asyncio.Future":
+        fut = self.loop.create_future()
+        self.jobs.put((fut, fn, args, kw))
+        return fut
+
+    def run(self) -> None:
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            fut, fn, args, kw = job
+            try:
+                res, err = fn(*args, **kw), None
+            except BaseException as e:              # delivered to the awaiting coroutine
+                res, err = None, e
+            self.loop.call_soon_threadsafe(_settle, fut, res, err)
+
+    def stop(self) -> None:
+        self.jobs.put(None)
+
+
+def _settle(fut, res, err) -> None:
+    if fut.cancelled():
+        return
+    if err is not None:
+        fut.set_exception(err)
+    else:
+        fut.set_result(res)
+
+
 class FanInServer:
     """`model`: a BatchedModel; its n_streams is the number of clients that can be connected at once (further connections are
     refused with close code 1013).  `window_s`: how long the pump waits after the first chunk of a round becomes available for other
     connections' chunks to arrive before it steps (0 = step at once; real-time clients deliver one chunk per 80 ms, so a few ms
     gathers nearly everyone into the same step).  `on_scores(slot, step_index, scores_row)`: optional tap, called for every
-    stream-step (used by the tests)."""
+    stream-step (used by the tests).
+
+    Steps go through the host-fed pipeline (`oww_submit_masked` / `oww_collect`): while the kernels of step t run, the pump already
+    gathers and uploads step t+1 from page-locked buffers; at most two steps are in flight, scores are dispatched in step order."""
 
     def __init__(self, model, threshold: float = 0.5, window_s: float = 0.01, on_scores=None):
         self.model = model
@@ -95,9 +142,10 @@ class FanInServer:
         self.clients: Dict[int, _Client] = {}
         self._have_chunk: Optional[asyncio.Event] = None
         self._pump_task: Optional[asyncio.Task] = None
-        self._gpu: Optional[asyncio.Lock] = None     # one caller at a time on the handle (pump step vs. a new connection's reset)
-        self._pcm = np.zeros((model.n_streams, CHUNK), dtype=np.int16)
-        self._on = np.zeros(model.n_streams, dtype=np.uint8)
+        self._gpu: Optional[_GpuWorker] = None
+        self._pcm = [model.engine.pinned_empty((model.n_streams, CHUNK)) for _ in range(2)]
+        for b in self._pcm:
+            b[:] = 0
         self.n_steps = 0              # batched steps taken
         self.n_stream_steps = 0       # sum over steps of the streams that took part
 
@@ -110,9 +158,11 @@ class FanInServer:
         return app
 
     async def _start(self, app) -> None:
+        loop = asyncio.get_running_loop()
         self._have_chunk = asyncio.Event()
-        self._gpu = asyncio.Lock()
-        self._pump_task = asyncio.get_running_loop().create_task(self._pump())
+        self._gpu = _GpuWorker(loop)
+        self._gpu.start()
+        self._pump_task = loop.create_task(self._pump())
 
     async def _stop(self, app) -> None:
         if self._pump_task:
@@ -121,6 +171,8 @@ class FanInServer:
                 await self._pump_task
             except asyncio.CancelledError:
                 pass
+        if self._gpu:
+            self._gpu.stop()
 
     async def handle(self, request):
         ws = web.WebSocketResponse()
@@ -129,10 +181,9 @@ class FanInServer:
             await ws.close(code=1013, message=b"all stream slots are taken")
             return ws
         slot = self.free.pop()
-        # a slot handed to a new caller starts from Model()'s initial state, VAD history included; after any step still in
-        # flight that carried the slot's previous owner
-        async with self._gpu:
-            self.model.reset([slot], reset_vad=bool(self.model.engine.has_vad))
+        # a slot handed to a new caller starts from Model()'s initial state, VAD history included; the job queue orders the reset
+        # after every step already submitted
+        await self._gpu.call(self.model.reset, [slot], reset_vad=bool(self.model.engine.has_vad))
         c = _Client(slot, ws)
         self.clients[slot] = c
         try:
@@ -160,43 +211,48 @@ class FanInServer:
         return ws
 
     def _reap(self) -> None:
-        for slot in [s for s, c in self.clients.items() if c.closed and c.n_pending < CHUNK]:
+        for slot in [s for s, c in self.clients.items() if c.closed and c.n_pending < CHUNK and c.in_flight == 0]:
             del self.clients[slot]
             self.free.append(slot)
 
-    # ---- the one place the GPU is driven from
+    # ---- the one place steps are put together
     async def _pump(self) -> None:
-        loop = asyncio.get_running_loop()
+        keep = self.model._keep
+        flying: "collections.deque" = collections.deque()        # ready lists of the submitted, not yet collected steps
         while True:
-            await self._have_chunk.wait()
-            if self.window_s > 0:
-                await asyncio.sleep(self.window_s)
+            if not flying:
+                await self._have_chunk.wait()
+                if self.window_s > 0:
+                    await asyncio.sleep(self.window_s)
             self._have_chunk.clear()
-            async with self._gpu:
-                self._reap()
-                ready = [c for c in self.clients.values() if c.n_pending >= CHUNK]
-                if not ready:
-                    continue
-                self._on[:] = 0
-                for c in ready:
-                    c.pop_chunk(self._pcm[c.slot])
-                    self._on[c.slot] = 1
-                # (blocking ctypes call: off the event loop, so that sockets keep draining while the kernels run)
-                scores = await loop.run_in_executor(None, self.model.predict_active, self._pcm, self._on)
-            self.n_steps += 1
-            self.n_stream_steps += len(ready)
-            for c in ready:
-                row = scores[c.slot]
-                if self.on_scores is not None:
-                    self.on_scores(c.slot, c.n_steps, row)
-                c.n_steps += 1
-                hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
-                if hits and not c.closed:
-                    try:
-                        await c.ws.send_str(json.dumps({"activations": hits}))
-                    except (ConnectionError, RuntimeError):
-                        c.closed = True
             self._reap()
+            ready = [c for c in self.clients.values() if c.n_pending >= CHUNK]
+            if ready:
+                buf = self._pcm[self.n_steps % 2]                  # (its previous step, n_steps - 2, has been collected)
+                on = np.zeros(self.model.n_streams, dtype=np.uint8)
+                for c in ready:
+                    c.pop_chunk(buf[c.slot])
+                    c.in_flight += 1
+                    on[c.slot] = 1
+                await self._gpu.call(self.model.engine.submit, buf, on)
+                flying.append(ready)
+                self.n_steps += 1
+                self.n_stream_steps += len(ready)
+            if flying and (len(flying) == 2 or not ready):
+                scores = (await self._gpu.call(self.model.engine.collect))[:, keep]
+                for c in flying.popleft():
+                    c.in_flight -= 1
+                    row = scores[c.slot]
+                    if self.on_scores is not None:
+                        self.on_scores(c.slot, c.n_steps, row)
+                    c.n_steps += 1
+                    hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
+                    if hits and not c.closed:
+                        try:
+                            await c.ws.send_str(json.dumps({"activations": hits}))
+                        except (ConnectionError, RuntimeError):
+                            c.closed = True
+                self._reap()
             if any(c.n_pending >= CHUNK for c in self.clients.values()):
                 self._have_chunk.set()          # somebody sent more than one chunk: go again without waiting for a message
 
