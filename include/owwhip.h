@@ -174,6 +174,14 @@ const float* oww_scores_dev(const oww_ctx* h);     /* device [S][n_labels], vali
  * model.py:313-317; max over chunks for n_chunks > 1): host fp32 [S][n_labels].  Blocking.  Lets a host
  * shim run the reference's own post-processing (Model.predict with short / unaligned calls). */
 int  oww_get_raw(oww_ctx* h, float* out);
+/* Rate conversion of every stream's message on the device, the batched form of the serving example's per-message
+ * resampy.resample(data, sample_rate, 16000) (examples/web/streaming_server.py:57-58): a polyphase FIR,
+ *   out[s][j] = sat_int16(rint(sum_k taps[(j p) % q][k] * in[s][(j p) / q + k - n_taps / 2 + 1])),   samples outside the message = 0,
+ * with p / q = input rate / 16000 in lowest terms, taps float [q][n_taps] on the host (n_taps even; the Kaiser-windowed sinc bank of
+ * openwakeword_amd/resample.py::design, or any other) and n_out = n_in * q / p.  in: int16 [S][n_in], out: int16 [S][n_out], host or
+ * device.  Stateless per call, like the example; asynchronous when out is a device pointer. */
+int  oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, int32_t p, int32_t q, const float* taps, int32_t n_taps,
+                  int16_t* out, int out_on_device, int32_t n_out);
 
 /* ---- stage-level entry points (the reference's per-stage closures; used for parity tests and for
  *      AudioFeatures._get_melspectrogram / embed_clips style callers).  Host pointers. ---------------

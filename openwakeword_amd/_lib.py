@@ -53,6 +53,7 @@ SYMBOLS = {
     "oww_reset_vad": (C.c_int, [_P, _P, C.c_int32]),
     "oww_scores_dev": (_P, [_P]),
     "oww_get_raw": (C.c_int, [_P, _P]),
+    "oww_resample": (C.c_int, [_P, _P, C.c_int, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int, C.c_int32]),
     "oww_mel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_mel_clips": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "oww_embed": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),

@@ -323,6 +323,8 @@ struct oww_ctx {
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
     int* h_range = nullptr;          // sticky f16-range flag: one page-locked, device-mapped word the f16-split kernels raise
     int* d_range = nullptr;          // the same word as the kernels address it
+    void* d_rs = nullptr; size_t rs_bytes = 0;     // oww_resample scratch: [taps | in | out] as needed
+    std::vector<float> rs_taps;                    // the padded filter bank of the last oww_resample call (upload source)
     uint8_t* d_on = nullptr;         // oww_step_masked: [Spad] participation mask of the step being launched (pad streams 0)
     const uint8_t* on_now = nullptr; // = d_on (or the caller's device mask) while a masked step is being launched, else nullptr
     int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
@@ -659,6 +661,7 @@ void free_all(oww_ctx* h) {
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
     if (h->d_on) { (void)hipFree(h->d_on); h->d_on = nullptr; }
+    if (h->d_rs) { (void)hipFree(h->d_rs); h->d_rs = nullptr; h->rs_bytes = 0; }
     if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
     for (auto& sl : h->slot) {
         fr(sl.d_pcm); fr(sl.d_scores);
@@ -1523,6 +1526,61 @@ int oww_range_status(oww_ctx* h, int clear) {
 }
 
 const float* oww_scores_dev(const oww_ctx* h) { return h ? h->d_scores : nullptr; }
+
+int oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, int32_t p, int32_t q, const float* taps, int32_t n_taps,
+                 int16_t* out, int out_on_device, int32_t n_out) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_resample: handle not committed");
+    if (!in || !out || !taps) return fail(OWW_EINVAL, "oww_resample: null argument");
+    if (n_in < 1 || p < 1 || q < 1 || n_taps < 2 || (n_taps & 1) || n_taps > 4096 || q > 65536)
+        return fail(OWW_EINVAL, "oww_resample: bad argument (n_in=%d p=%d q=%d n_taps=%d)", n_in, p, q, n_taps);
+    if (n_out != (int32_t)(((long long)n_in * q) / p) || n_out < 1)
+        return fail(OWW_EINVAL, "oww_resample: n_out must be n_in * q / p = %lld, got %d", ((long long)n_in * q) / p, n_out);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int ntp = (n_taps + 3) / 4 * 4;
+    // outputs per workgroup: as many as a 48 KB input span allows, at most a chunk's worth (the filter bank is staged once per workgroup)
+    int opb = RS_NT * 5;
+    auto span_of = [&](int o) { return (int)(((long long)(o - 1) * p) / q) + 1 + n_taps + 4; };   // (+ 4: the zero-padded taps read 3 words on)
+    while (opb > RS_NT && (size_t)span_of(opb) * sizeof(float) > 48 * 1024) opb -= RS_NT;
+    opb = std::min(opb, (n_out + RS_NT - 1) / RS_NT * RS_NT);
+    const int span = span_of(opb);
+    const size_t lds_x = (size_t)((span + 3) / 4 * 4) * sizeof(float), lds_t = (size_t)q * ntp * sizeof(float);
+    if (lds_x > 96 * 1024) return fail(OWW_EINVAL, "oww_resample: input rate too high for the staging buffer (p / q = %d / %d)", p, q);
+    const int taps_in_lds = lds_x + lds_t <= 150 * 1024;
+    const size_t lds = lds_x + (taps_in_lds ? lds_t : 0);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t b_taps = ((size_t)q * ntp * sizeof(float) + 255) / 256 * 256;
+    const size_t b_in = in_on_device ? 0 : ((size_t)h->S * n_in * sizeof(int16_t) + 255) / 256 * 256;
+    const size_t b_out = out_on_device ? 0 : (size_t)h->S * n_out * sizeof(int16_t);
+    if (b_taps + b_in + b_out > h->rs_bytes) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_rs) (void)hipFree(h->d_rs);
+        h->d_rs = nullptr; h->rs_bytes = 0;
+        if (hipMalloc(&h->d_rs, b_taps + b_in + b_out) != hipSuccess) return fail(OWW_ENOMEM, "oww_resample: out of device memory");
+        h->rs_bytes = b_taps + b_in + b_out;
+    }
+    char* base = (char*)h->d_rs;
+    // (stream-ordered upload from a buffer that lives in the handle: an earlier oww_resample may still be reading the old bank)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->rs_taps.assign((size_t)q * ntp, 0.f);
+    for (int r = 0; r < q; ++r) memcpy(&h->rs_taps[(size_t)r * ntp], taps + (size_t)r * n_taps, n_taps * sizeof(float));
+    HIPCHK(hipMemcpyAsync(base, h->rs_taps.data(), h->rs_taps.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ResampleParams a{};
+    a.taps = (const float*)base; a.n_in = n_in; a.n_out = n_out; a.p = p; a.q = q; a.n_taps = n_taps; a.ntp = ntp; a.S = h->S;
+    a.span = span; a.taps_in_lds = taps_in_lds; a.opb = opb;
+    a.in = in;
+    if (!in_on_device) {
+        HIPCHK(hipMemcpyAsync(base + b_taps, in, (size_t)h->S * n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+        a.in = (const int16_t*)(base + b_taps);
+    }
+    a.out = out_on_device ? out : (int16_t*)(base + b_taps + b_in);
+    hipLaunchKernelGGL(resample_kernel, dim3((n_out + opb - 1) / opb, h->S), dim3(RS_NT), lds, h->stream, a);
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) {
+        HIPCHK(hipMemcpyAsync(out, a.out, (size_t)h->S * n_out * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return OWW_OK;
+}
 
 int oww_get_raw(oww_ctx* h, float* out) {
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_raw: handle not committed");

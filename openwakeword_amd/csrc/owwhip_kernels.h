@@ -1260,6 +1260,50 @@ __global__ __launch_bounds__(256) void verifier_kernel(VerifierParams p) {
     }
 }
 
+// polyphase FIR rate conversion of every stream's message to 16 kHz (oww_resample; filter design: openwakeword_amd/resample.py).
+//   out[s][j] = sat_int16(rint(sum_k taps[(j p) % q][k] * in[s][(j p) / q + k - half + 1])),   zero outside the message.
+// A workgroup produces `opb` consecutive outputs of one stream (up to a whole 1280-sample chunk): the input span they touch is staged in LDS once, converted to float
+// (coalesced int16 reads), and so is the filter bank when it fits (rows padded to a multiple of 4 taps so that a lane reads 4 taps with
+// one ds_read_b128; with q = 1 -- 48, 32, 96 kHz -- all lanes read the same row: a broadcast); one thread per output, k-ordered fmaf
+// chain (the order the host restatement documents).
+constexpr int RS_NT = 256;
+struct ResampleParams {
+    const int16_t* in; int16_t* out; const float* taps;   // taps: [q][ntp] (ntp = n_taps rounded up to 4, zero padded)
+    int n_in, n_out, p, q, n_taps, ntp, S, span, taps_in_lds;
+    int opb;                 // outputs per workgroup (a multiple of RS_NT: a whole 1280-sample chunk when the input span fits the LDS)
+};
+__global__ __launch_bounds__(RS_NT) void resample_kernel(ResampleParams a) {
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+    float* xs = rs_lds;                                  // [span]
+    float* ts = rs_lds + (a.span + 3) / 4 * 4;           // [q][ntp] when taps_in_lds
+    const int s = blockIdx.y, j0 = blockIdx.x * a.opb, t = threadIdx.x;
+    const int half = a.n_taps / 2;
+    const int base = (int)(((long long)j0 * a.p) / a.q) - (half - 1);       // input index of xs[0]
+    const int16_t* x = a.in + (size_t)s * a.n_in;
+    for (int i = t; i < a.span; i += RS_NT) {
+        const int g = base + i;
+        xs[i] = (g >= 0 && g < a.n_in) ? (float)x[g] : 0.f;
+    }
+    if (a.taps_in_lds)
+        for (int i = t; i < a.q * a.ntp; i += RS_NT) ts[i] = a.taps[i];
+    __syncthreads();
+    for (int j = j0 + t; j < min(j0 + a.opb, a.n_out); j += RS_NT) {
+        const long long jp = (long long)j * a.p;
+        const int ph = (int)(jp % a.q);
+        const float* xw = xs + ((int)(jp / a.q) - (half - 1) - base);
+        const float* w = (a.taps_in_lds ? ts : a.taps) + (size_t)ph * a.ntp;
+        float acc = 0.f;
+        for (int k = 0; k < a.ntp; k += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w + k);
+            acc = fmaf(w4.x, xw[k], acc);
+            acc = fmaf(w4.y, xw[k + 1], acc);
+            acc = fmaf(w4.z, xw[k + 2], acc);
+            acc = fmaf(w4.w, xw[k + 3], acc);
+        }
+        a.out[(size_t)s * a.n_out + j] = (int16_t)fminf(fmaxf(rintf(acc), -32768.f), 32767.f);
+    }
+}
+
 // forget the VAD score history of the listed streams (ids == nullptr: streams [0, n)); oww_reset itself leaves it alone (model.py:226-230)
 __global__ void vad_ring_reset_kernel(float* ring, uint32_t* n_vad, const int* ids, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -204,6 +204,21 @@ class StreamEngine:
         _lib.check(self._lib.oww_step_masked(self._h, _ptr(pcm), 0, _ptr(on), 0, _ptr(out), 0))
         return out
 
+    def resample(self, pcm: np.ndarray, sample_rate: int) -> np.ndarray:
+        """int16 [S, n_in] at `sample_rate` Hz -> int16 [S, n_in * 16000 // sample_rate] at 16 kHz on the device (oww_resample with the
+        filter bank of resample.design; stateless per call, like the per-message resampy call of examples/web/streaming_server.py:57-58)."""
+        from . import resample as R
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype != np.int16 or pcm.ndim != 2 or pcm.shape[0] != self.n_streams:
+            raise ValueError(f"pcm must be int16 [n_streams={self.n_streams}, n], got {pcm.dtype} {pcm.shape}")
+        if int(sample_rate) == 16000:
+            return pcm
+        p, q, taps = R.design(int(sample_rate))
+        n_out = (pcm.shape[1] * q) // p
+        out = np.empty((self.n_streams, n_out), dtype=np.int16)
+        _lib.check(self._lib.oww_resample(self._h, _ptr(pcm), 0, pcm.shape[1], p, q, _ptr(taps), taps.shape[1], _ptr(out), 0, n_out))
+        return out
+
     def step_raw(self, pcm: np.ndarray) -> np.ndarray:
         """Like step(), but returns the head outputs before post-processing (model.py:313-317)."""
         pcm = np.ascontiguousarray(pcm)

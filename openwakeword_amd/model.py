@@ -517,9 +517,13 @@ class BatchedModel:
         if reset_vad:
             self.engine.reset_vad(stream_ids)
 
-    def predict_batch(self, pcm: np.ndarray) -> np.ndarray:
+    def predict_batch(self, pcm: np.ndarray, sample_rate: int = 16000) -> np.ndarray:
+        """`sample_rate` != 16000: every stream's message is converted on the device first (engine.resample; e.g. 640 samples at 8 kHz,
+        3840 at 48 kHz or 3528 at 44.1 kHz make one 1280-sample chunk)."""
         if not isinstance(pcm, np.ndarray):
             raise ValueError(f"The input audio data (x) must by a Numpy array, instead received an object of type {type(pcm)}.")
+        if int(sample_rate) != 16000:
+            pcm = self.engine.resample(pcm, sample_rate)
         return self.engine.step(pcm)[:, self._keep]
 
     def predict_active(self, pcm: np.ndarray, active) -> np.ndarray:
