@@ -353,9 +353,20 @@ def main():
             eng.close()
             eng32 = StreamEngine(S, heads, emb, device=local_rank, use_mfma=1, hip_stream=stream.cuda_stream, **vad_kw)
             eng32.reset()
-            dt_f, _ = timed_run(torch, dist, eng32, pool, scores, 20, 5, dev, 1, None, timing=False)
+            dt_f, kt_f = timed_run(torch, dist, eng32, pool, scores, 20, 5, dev, 1, None, timing=True)
             extras["fp32_exact"] = {"kernels": "mfma_rr_fp32", "steps": 20, "warmup": 5, "ms_per_step": round(1e3 * dt_f / 20, 4),
                                     "value": round(S * 20 / dt_f, 1), "unit": "frames/s", "dtype": "f32"}
+            # this family still runs the log-mel front end as its own launch: the HBM figure the north star asks for on "the mel
+            # kernel" (in the default family its rows never reach HBM, see fused_front).  Algorithmic bytes per stream-step
+            # (SURVEY 8d): 2,560 B of new PCM + 960 B tail read + 960 B tail written + 1,024 B of mel rows written
+            if kt_f and kt_f["mel"]["launches"]:
+                mel_ms = kt_f["mel"]["ms"] / kt_f["mel"]["launches"]
+                gbs = S * 5504 / (mel_ms * 1e-3) / 1e9
+                extras["fp32_exact"]["mel_kernel"] = {"avg_ms": round(mel_ms, 4), "bytes_per_stream_step": 5504, "achieved": round(gbs, 1),
+                                                      "unit": "GB/s", "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                                      "fp32_valu_tflops": round(S * 0.10e6 / (mel_ms * 1e-3) / 1e12, 2),
+                                                      "note": "separate mel launch (fp32 kernel families, multi-chunk calls, clip embedding); "
+                                                              "FFT butterflies and LDS transposes bound it, not HBM"}
             eng32.close()
             eng = None
         # ---- resident_1m: a million streams in ONE handle on this GPU, in a child process (own 73 GB of state)
