@@ -62,3 +62,19 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(_lib.OwwError):
         engine.StreamEngine(2, {"alexa": W.synthetic_head("alexa")})
+
+
+def test_integration_stubs_compile_and_bind_only_declared_symbols():
+    """INTEGRATION.md section 1 (executed on the GPU by tests/test_seam_gpu.py): here, without a GPU, the printed stubs must at
+    least be valid Python, quote the header's ABI version, and call nothing the header does not declare."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"<!-- stub:(\w+) -->\s*```python\n(.*?)```", text, re.S)
+    assert [t for t, _ in blocks] == ["features", "heads"]
+    names = set(declared_symbols())
+    for tag, body in blocks:
+        src = body if tag == "features" else "def _install(idx, T, n_out, mdl_name):\n" + body
+        compile(src, f"INTEGRATION.md:{tag}", "exec")
+        for sym in re.findall(r"lib\.(oww_[a-z_0-9]+)", body):
+            assert sym in names, f"INTEGRATION.md stub calls {sym}, which include/owwhip.h does not declare"
+    assert f"lib.oww_abi_version() == {_lib.ABI_VERSION}" in text
+    assert f"C ABI version {_lib.ABI_VERSION} " in text
