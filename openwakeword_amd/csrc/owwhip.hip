@@ -100,7 +100,7 @@ void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                     }
 }
 
-// the f16 halves of 2^8 * w must stay finite: |w| < 255 (trained conv / linear weights are orders of magnitude below)
+// the f16 halves of 2^8 * w must stay finite: |w| < 255 (trained linear weights are orders of magnitude below); heads and VAD
 bool hx_in_range(const float* w, size_t n) {
     for (size_t i = 0; i < n; ++i) if (!(std::fabs(w[i]) * owh::WSCALE < 65000.f)) return false;
     return true;
@@ -120,10 +120,24 @@ inline int hx_row_channel(int tile, int row, int C) {            // channel in r
     return e < 2 ? tile * 16 + 2 * j + e : -1;
 }
 
+// one weight as an f16 (hi, lo) pair: w * mul formed in double, hi = f16(v), lo = f16(v - hi) (22 bits together).
+// mul = colmul[cout] for the embedding CNN (folded BatchNorm scale x the layer's activation-scale ratio, see fold_cnn), else 2^8.
+struct HxFold {
+    const double* colmul = nullptr;      // per output channel; nullptr = owh::WSCALE for every channel
+    double absmax = 0.0;                 // largest |w * mul| seen (range check by the caller)
+    inline void split(float w, int co, _Float16& hi, _Float16& lo) {
+        const double v = (double)w * (colmul ? colmul[co] : (double)owh::WSCALE);
+        absmax = std::max(absmax, std::fabs(v));
+        hi = (_Float16)v;
+        lo = (_Float16)(v - (double)hi);
+    }
+};
+
 // fp16-split operand order (owwhip_hx.h): blocks [oct][tap][ks][part hi/lo] of 64 lanes x 8 halves; lane (i, g), half q
 // <-> weight of the input channel in row 4g + q%4 of channel tile 2ks + q/4 and the output channel in row i of tile oct
-// (hx_row_channel), pre-scaled by 2^8
-void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out) {
+// (hx_row_channel)
+void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out, HxFold* fold = nullptr) {
+    HxFold dflt; if (!fold) fold = &dflt;
     const int ks_n = ((cin + 15) / 16 + 1) / 2, ncto = (cout + 15) / 16;
     std::vector<_Float16> hbuf((size_t)ncto * ntaps * ks_n * 2 * 64 * 8, (_Float16)0.f);
     for (int oct = 0; oct < ncto; ++oct)
@@ -135,8 +149,8 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                         const int ci = 2 * ks + q / 4 < (cin + 15) / 16 ? hx_row_channel(2 * ks + q / 4, 4 * g + q % 4, cin) : -1;
                         const int co = hx_row_channel(oct, i, cout);
                         if (ci < 0 || co < 0) continue;
-                        const float v = w[((size_t)tap * cin + ci) * cout + co] * owh::WSCALE;
-                        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                        _Float16 hi, lo;
+                        fold->split(w[((size_t)tap * cin + ci) * cout + co], co, hi, lo);
                         const size_t blk = (((size_t)oct * ntaps + tap) * ks_n + ks) * 2;
                         hbuf[(blk * 64 + lane) * 8 + q] = hi;
                         hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
@@ -147,15 +161,15 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
 // K-merged 3x1 (time) layer of a stage with an odd number of channel tiles (owh::conv_time_hxm): per output tile the blocks
 // [tap][full k-step][part], then [merged k-step][part]; merged k-step mk, lane (i, g), half q: pair index pi = 4 mk + q/2 carries
 // tap pi / NPR, pair v = pi % NPR of the remainder tile, i.e. its row 4g + 2v + q%2
-void pack_hx_tm(const float* w, int cin, int cout, std::vector<float>& out) {
+void pack_hx_tm(const float* w, int cin, int cout, std::vector<float>& out, HxFold* fold) {
     const int ncti = (cin + 15) / 16, ncto = (cout + 15) / 16;
     const bool half = cin % 16 == 8;
     const int ksf = ncti / 2, npr = half ? 1 : 2, nmk = (3 * npr + 3) / 4, nb = (3 * ksf + nmk) * 2;
     std::vector<_Float16> hbuf((size_t)ncto * nb * 64 * 8, (_Float16)0.f);
     auto put = [&](size_t blk, int lane, int q, int tap, int ci, int co) {
         if (ci < 0 || co < 0) return;
-        const float v = w[((size_t)tap * cin + ci) * cout + co] * owh::WSCALE;
-        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        _Float16 hi, lo;
+        fold->split(w[((size_t)tap * cin + ci) * cout + co], co, hi, lo);
         hbuf[(blk * 64 + lane) * 8 + q] = hi;
         hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
     };
@@ -202,15 +216,15 @@ void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, std::vector<float>
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
 }
 // conv0 (3x3, one input channel): one k-step, k = tap index (9 of 32 used)
-void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out) {
+void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out, HxFold* fold) {
     std::vector<_Float16> hbuf((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
     for (int oct = 0; oct < 2; ++oct)
         for (int lane = 0; lane < 64; ++lane)
             for (int q = 0; q < 8; ++q) {
                 const int i = lane & 15, g = lane >> 4, k = 8 * g + q, co = hx_row_channel(oct, i, 24);
                 if (k >= 9 || co < 0) continue;
-                const float v = w[k * 24 + co] * owh::WSCALE;
-                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                _Float16 hi, lo;
+                fold->split(w[k * 24 + co], co, hi, lo);
                 hbuf[((size_t)(oct * 2 + 0) * 64 + lane) * 8 + q] = hi;
                 hbuf[((size_t)(oct * 2 + 1) * 64 + lane) * 8 + q] = lo;
             }
@@ -328,6 +342,12 @@ struct oww_ctx {
     uint8_t* d_on = nullptr;         // oww_step_masked: [Spad] participation mask of the step being launched (pad streams 0)
     const uint8_t* on_now = nullptr; // = d_on (or the caller's device mask) while a masked step is being launched, else nullptr
     int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
+    // f16-split family: the output of layer l is carried multiplied by 2^hx_e[l], its input arrives multiplied by 2^hx_ein[l]
+    // (oww_commit: calibrate_hx; owwhip_hx.h act1).  Inside a stage hx_ein[l] = hx_e[l - 1]; the pooled hand-over between two stages
+    // (and the pooled input of conv19) is re-scaled by 2^hx_xexp[stage], the embedding by 2^-hx_e[19] when it is stored.
+    int hx_e[20] = {}, hx_ein[20] = {}, hx_xexp[5] = {};
+    float hx_absmax[20] = {};        // largest |activation| of each layer in the calibration run (exact-fp32 kernels)
+    float hx_selftest_err = 0.f, hx_selftest_ref = 0.f, hx_selftest_score_err = 0.f;   // commit-time f16-split vs exact-fp32 comparison
     bool fuse = false;               // f16-split family: mel front end fused into stage A for one-chunk streaming steps (owwhip_fused.h)
     const int16_t* fuse_pcm = nullptr;   // set by launch_step for the duration of a fused step
     // custom verifiers on the device (oww_set_verifier)
@@ -464,6 +484,8 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         for (int i = 0; i < 3; ++i) { p.scale[i] = h->d_scale[i]; p.shift[i] = h->d_shift[i]; p.dbg_off[i] = dbg_off[i]; }
         p.xout = h->d_xA; p.n_streams = n_active; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
+        for (int i = 0; i < 3; ++i) { p.clampv[i] = -0.4f * ldexpf(1.f, h->hx_e[i]); p.dbg_mul[i] = ldexpf(1.f, -h->hx_e[i]); }
+        p.xmul = ldexpf(1.f, h->hx_xexp[0]);
         p.range_flag = HX ? h->d_range : nullptr;
         p.stream_on = h->on_now;
         const int grid = std::min((n_active + 3) / 4, 768);           // persistent: 3 workgroups of 4 waves per CU
@@ -486,7 +508,11 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         for (int i = 0; i < 4; ++i) {
             p.w[i] = h->d_conv[first_layer + i]; p.scale[i] = h->d_scale[first_layer + i];
             p.shift[i] = h->d_shift[first_layer + i]; p.dbg_off[i] = dbg_off[first_layer + i];
+            p.clampv[i] = -0.4f * ldexpf(1.f, h->hx_e[first_layer + i]); p.dbg_mul[i] = ldexpf(1.f, -h->hx_e[first_layer + i]);
         }
+        p.dbg_mul[4] = ldexpf(1.f, -h->hx_e[19]);
+        p.xmul = ldexpf(1.f, h->hx_xexp[first_layer / 4 + 1]);      // first_layer 3, 7, 11, 15 -> hand-over 1..4
+        p.emb_mul = ldexpf(1.f, -h->hx_e[19]);
         p.n_groups = (n_active + spt - 1) / spt; p.S = h->Spad;
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         p.range_flag = HX ? h->d_range : nullptr;
@@ -781,6 +807,180 @@ int park_state(oww_ctx* h, int n_streams, bool save) {
     return 0;
 }
 
+// ---- f16-split family: commit-time calibration and self-test against the exact-fp32 kernels -------------------------------------
+// The reference's graphs are fp32 (onnxruntime CPU kernels, utils.py:84-93): they have no range to leave.  The f16-split kernels
+// carry every activation as an f16 (hi, lo) pair, which is exact to 22 bits only inside the f16 exponent range, so oww_commit
+//  (1) runs 32 probe streams (silence ... full-scale noise and square waves) plus the all-ones mel history through a scratch handle
+//      of the exact-fp32 family with per-layer dumps and records every layer's largest |activation|,
+//  (2) gives every layer the power-of-two scale K = 2^e that puts that maximum at 512..1024 -- a factor 64 below the f16 overflow
+//      and 2^13 above the point where the low half goes subnormal -- and folds K, the BatchNorm scale and shift into the packed
+//      weights / accumulator start values (fold_cnn; owwhip_hx.h act1),
+//  (3) replays the probes through the handle's own f16-split kernels and compares the embeddings (and, with heads loaded, the raw
+//      head outputs) with the fp32 run: weights for which the two differ by more than the north-star tolerance are refused with
+//      OWW_ERANGE at commit instead of scoring differently later.
+constexpr int CAL_NP = 32, CAL_T = 16;
+struct HxCalib {
+    std::vector<int16_t> pcm;        // [CAL_T][CAL_NP][1280]
+    std::vector<float> ref_emb;      // [CAL_T][CAL_NP][96]   exact-fp32 embeddings of the probe run
+    std::vector<float> ref_raw;      // [CAL_T][CAL_NP][NL]   exact-fp32 raw head outputs
+    int NL = 0;
+};
+
+void make_probe_pcm(std::vector<int16_t>& pcm) {
+    pcm.assign((size_t)CAL_T * CAL_NP * OWW_CHUNK, 0);
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto u01 = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((st >> 11) + 1) * (1.0 / 9007199254740993.0); };
+    const double amps[5] = {30, 300, 3000, 12000, 32767};
+    for (int i = 1; i < CAL_NP; ++i) {                 // stream 0: silence
+        const double amp = amps[i % 5];
+        for (int n = 0; n < CAL_T * OWW_CHUNK; ++n) {
+            double v;
+            if (i % 3 == 0) v = ((n / (8 << (i % 4))) % 2) ? amp : -amp;                        // square waves, 1 kHz .. 125 Hz
+            else v = std::nearbyint(amp * std::sqrt(-2.0 * std::log(u01())) * std::cos(6.283185307179586 * u01()));
+            v = std::min(32767.0, std::max(-32768.0, v));
+            pcm[((size_t)(n / OWW_CHUNK) * CAL_NP + i) * OWW_CHUNK + n % OWW_CHUNK] = (int16_t)v;
+        }
+    }
+}
+
+// one probe step on handle t: mel of the chunk (separate kernel), CNN, frame counters, optionally the heads
+int probe_step(oww_ctx* t, const int16_t* d_chunk, bool heads) {
+    if (int rc = launch_mel(t, d_chunk, CAL_NP, OWW_CHUNK, 8, 1, t->d_mel, nullptr)) return rc;
+    if (int rc = run_cnn(t, CAL_NP, 256, 0)) return rc;
+    if (heads && t->NL > 0) {
+        const bool save = t->post_in_heads_now;
+        t->post_in_heads_now = false;
+        const int rc = run_heads(t, CAL_NP, false, nullptr, -1, t->d_raw, 0);
+        t->post_in_heads_now = save;
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(advance_kernel, dim3((t->Spad + 255) / 256), dim3(256), 0, t->stream, t->d_nfeat, t->Spad, (const uint8_t*)nullptr);
+    return 0;
+}
+
+int calibrate_hx(oww_ctx* h, HxCalib& cal) {
+    make_probe_pcm(cal.pcm);
+    oww_config c2 = h->cfg;
+    c2.n_streams = CAL_NP; c2.max_chunks = 1; c2.use_mfma = 1; c2.debug_layers = 1; c2.stream = nullptr;
+    c2.feature_ring = h->TR;
+    oww_ctx* t = nullptr;
+    if (int rc = oww_create(&c2, &t)) return rc;
+    int rc = 0;
+    unsigned* d_max = nullptr; int* d_off = nullptr; int16_t* d_chunk = nullptr;
+    do {
+        if ((rc = oww_load_mel(t, h->mel_blob.data(), h->mel_blob.size() * sizeof(float)))) break;
+        if ((rc = oww_load_embedding(t, h->emb_blob.data(), h->emb_blob.size() * sizeof(float)))) break;
+        for (const HeadHost& hh : h->heads) {
+            std::vector<float> blob(8 + hh.blob.size());
+            const int32_t hdr[8] = {hh.kind, hh.T, hh.hidden, hh.n_out, hh.has_ln, 0, 0, 0};
+            memcpy(blob.data(), hdr, sizeof hdr);
+            memcpy(blob.data() + 8, hh.blob.data(), hh.blob.size() * sizeof(float));
+            if ((rc = oww_add_head(t, blob.data(), blob.size() * sizeof(float))) < 0) break;
+            rc = 0;
+        }
+        if (rc) break;
+        if ((rc = oww_commit(t))) break;
+        cal.NL = t->NL;
+        int off[21]; off[0] = 0;
+        for (int l = 0; l < 20; ++l) off[l + 1] = off[l] + kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2];
+        if (hipMalloc(&d_max, 20 * sizeof(unsigned)) != hipSuccess || hipMalloc(&d_off, sizeof off) != hipSuccess ||
+            hipMalloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_commit: out of device memory (calibration)"); break; }
+        if (hipMemsetAsync(d_max, 0, 20 * sizeof(unsigned), t->stream) != hipSuccess ||
+            hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration setup failed"); break; }
+        auto absmax = [&]() { hipLaunchKernelGGL(layer_absmax_kernel, dim3(20, CAL_NP), dim3(256), 0, t->stream, t->d_dbg, (size_t)DBG_FLOATS, d_off, d_max); };
+        // (a) the all-ones mel history every stream starts from (utils.py:165): the handle sits in that steady state after its commit
+        hipLaunchKernelGGL(fill_kernel, dim3(CAL_NP), dim3(256), 0, t->stream, t->d_mel, (size_t)CAL_NP * 256, 1.0f);
+        if ((rc = run_cnn(t, CAL_NP, 256, 0))) break;
+        absmax();
+        // (b) the probe audio
+        cal.ref_emb.assign((size_t)CAL_T * CAL_NP * 96, 0.f);
+        cal.ref_raw.assign((size_t)CAL_T * CAL_NP * std::max(t->NL, 1), 0.f);
+        for (int it = 0; it < CAL_T && !rc; ++it) {
+            if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)it * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
+            if ((rc = probe_step(t, d_chunk, true))) break;
+            absmax();
+            if (hipMemcpyAsync(&cal.ref_emb[(size_t)it * CAL_NP * 96], t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+                (t->NL > 0 && hipMemcpyAsync(&cal.ref_raw[(size_t)it * CAL_NP * t->NL], t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+        }
+        if (rc) break;
+        unsigned mx[20];
+        if (hipMemcpyAsync(mx, d_max, sizeof mx, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration run failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        for (int l = 0; l < 20; ++l) {
+            float m; memcpy(&m, &mx[l], 4);
+            if (!std::isfinite(m)) { rc = fail(OWW_EINVAL, "oww_commit: layer %d of the embedding network produces non-finite activations in exact fp32 -- the weights are broken", l); break; }
+            h->hx_absmax[l] = m;
+        }
+        if (rc) break;
+        // Scale ladder.  acc = sum W' X needs no multiply after it only if W' = s w 2^(e_out - e_in), so the weights' magnitude is
+        // pinned by the exponent step of the layer; their low halves stay precise (abs error 2^-25 against sums of magnitude
+        // 2^(e_out) |y|) when that step is >= ~2.  Inside a stage the activation maxima therefore climb 2^3 (pooled input) ->
+        // 2^5 -> 2^7 -> 2^9 -> 2^11 (a factor 32 below the f16 overflow for the loudest probe) and the pooled hand-over, which
+        // is multiplied once per stored value anyway, brings the next stage's input back to 2^3.
+        auto ex = [&](int l) { int e2 = 0; if (h->hx_absmax[l] > 0.f) std::frexp(h->hx_absmax[l], &e2); return e2; };   // max < 2^ex
+        auto cl = [](int e2) { return std::min(100, std::max(-100, e2)); };
+        const int first[5] = {0, 3, 7, 11, 15};
+        for (int st = 0; st < 5; ++st) {
+            const int n = st == 0 ? 3 : 4;
+            for (int i = 0; i < n; ++i) {
+                const int l = first[st] + i;
+                h->hx_e[l] = cl((st == 0 ? 7 : 5) + 2 * i - ex(l));
+                h->hx_ein[l] = i == 0 ? (st == 0 ? 0 : cl(3 - ex(l - 1))) : h->hx_e[l - 1];     // (max-pooling keeps the maximum)
+            }
+        }
+        h->hx_ein[19] = cl(3 - ex(18));
+        h->hx_e[19] = h->hx_ein[19] + 2;                        // conv19: no activation, its output is un-scaled when the embedding is stored
+        for (int st = 0; st < 5; ++st) {
+            const int last = st == 0 ? 2 : first[st] + 3, nxt = last + 1;
+            h->hx_xexp[st] = h->hx_ein[nxt] - h->hx_e[last];
+        }
+    } while (0);
+    if (d_max) (void)hipFree(d_max);
+    if (d_off) (void)hipFree(d_off);
+    if (d_chunk) (void)hipFree(d_chunk);
+    const std::string keep = g_err;
+    (void)oww_destroy(t);
+    if (rc) g_err = keep;
+    (void)hipSetDevice(h->cfg.device);
+    return rc;
+}
+
+// replay of the probes on the handle's own (f16-split) kernels; leaves the first CAL_NP streams dirty -- the caller resets all state
+int selftest_hx(oww_ctx* h, const HxCalib& cal) {
+    int16_t* d_chunk = nullptr;
+    if (hipMalloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) return fail(OWW_ENOMEM, "oww_commit: out of device memory (self-test)");
+    std::vector<float> emb((size_t)CAL_T * CAL_NP * 96), raw((size_t)CAL_T * CAL_NP * std::max(h->NL, 1));
+    int rc = 0;
+    float* saved_dbg = h->d_dbg; h->d_dbg = nullptr;
+    for (int it = 0; it < CAL_T && !rc; ++it) {
+        if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)it * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
+        if ((rc = probe_step(h, d_chunk, true))) break;
+        if (hipMemcpyAsync(&emb[(size_t)it * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            (h->NL > 0 && hipMemcpyAsync(&raw[(size_t)it * CAL_NP * h->NL], h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+    }
+    h->d_dbg = saved_dbg;
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(OWW_EHIP, "oww_commit: self-test run failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(d_chunk);
+    if (rc) return rc;
+    float err = 0.f, ref = 0.f, serr = 0.f;
+    bool finite = true;
+    for (size_t i = 0; i < emb.size(); ++i) {
+        finite = finite && std::isfinite(emb[i]);
+        err = std::max(err, std::fabs(emb[i] - cal.ref_emb[i])); ref = std::max(ref, std::fabs(cal.ref_emb[i]));
+    }
+    if (h->NL > 0 && cal.NL == h->NL)
+        for (size_t i = 0; i < raw.size(); ++i) { finite = finite && std::isfinite(raw[i]); serr = std::max(serr, std::fabs(raw[i] - cal.ref_raw[i])); }
+    h->hx_selftest_err = err; h->hx_selftest_ref = ref; h->hx_selftest_score_err = serr;
+    if (getenv("OWW_DEBUG_CALIB")) fprintf(stderr, "commit self-test: max |emb - fp32| %.3g on |emb| <= %.3g, max |raw score - fp32| %.3g\n", (double)err, (double)ref, (double)serr);
+    const float tol = 1e-3f;                     // the north-star score tolerance
+    if (!finite || err > tol * std::max(1.f, ref) || serr > tol || (h->h_range && *(volatile int*)h->h_range)) {
+        if (h->h_range) *(volatile int*)h->h_range = 0;
+        return fail(OWW_ERANGE, "oww_commit: with these weights the fp16-split kernels (use_mfma = 3) differ from the exact-fp32 kernels by %.3g on "
+                    "embeddings of magnitude %.3g and by %.3g on raw scores over the probe set (tolerance %.0e): create the handle with "
+                    "use_mfma = 1", (double)err, (double)ref, (double)serr, (double)tol);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -930,6 +1130,14 @@ int oww_commit(oww_ctx* h) {
     h->TR = h->cfg.feature_ring > 0 ? std::max(h->cfg.feature_ring, maxT) : maxT;
     h->generic_hmax = hmax;
 
+    // ---- f16-split family: per-layer activation scales from a calibration run on the exact-fp32 kernels (calibrate_hx) ----
+    HxCalib cal;
+    if (h->hx) {
+        if (int rc = calibrate_hx(h, cal)) return rc;
+        if (getenv("OWW_DEBUG_CALIB"))
+            for (int l = 0; l < 20; ++l) fprintf(stderr, "calib layer %2d: max|a| %-12.5g e_in %4d e_out %4d\n", l, h->hx_absmax[l], h->hx_ein[l], h->hx_e[l]);
+    }
+
     // ---- device weight image ----
     HostBuf hb;
     const size_t o_hann = hb.add(h->mel_blob.data(), 400);
@@ -942,9 +1150,14 @@ int oww_commit(oww_ctx* h) {
         for (int l = 0; l < 20; ++l) {
             const LayerDef& L = kLayers[l];
             const size_t nw = (size_t)L.kh * L.kw * L.cin * L.cout;
+            const float* bn_scale = l < 19 ? q + nw : nullptr;             // folded inference BatchNorm of this layer (blob order: w, scale, shift)
             if (!h->mfma) o_conv[l] = hb.add(q, nw);
             else if (h->hx) {
-                if (!hx_in_range(q, nw)) return fail(OWW_EINVAL, "conv layer %d: weight magnitude too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1", l);
+                // fold_cnn: W' = s w 2^(e_out - e_in) per output channel (calibrate_hx's scale ladder; e_in = 0 for the mel input)
+                std::vector<double> colmul(L.cout);
+                const int de = h->hx_e[l] - h->hx_ein[l];
+                for (int c = 0; c < L.cout; ++c) colmul[c] = std::ldexp(bn_scale ? (double)bn_scale[c] : 1.0, de);
+                HxFold fold; fold.colmul = colmul.data();
                 const bool time_merged = OWH_KMERGE && L.kh == 3 && L.kw == 1 && ((L.cin + 15) / 16) % 2 == 1 &&
                                          (L.cin % 16 == 8 || OWH_KMERGE_B);                     // stage C (and B): layers b, d
                 // 1x3 layers with a 72-channel input (stage C layer c, stage D layer a): owh::conv_mel_hxm, same packing rule
@@ -952,9 +1165,12 @@ int oww_commit(oww_ctx* h) {
                                         ((L.cin + 15) / 16) % 2 == 1 && (L.cin + 15) / 16 >= 3 &&
                                         (L.cin % 16 == 8 || (OWH_KMERGE_MEL2 && l == 7 && OWH_WPS_C == 2) ||   // (l == 7: stage C layer a, 48 -> 72)
                                          (OWH_KMERGE_MEL2B && l == 5));                                   // (l == 5: stage B layer c, A/B switch)
-                if (l == 0) pack_hx_conv0(q, pk);
-                else if (time_merged || mel_merged) pack_hx_tm(q, L.cin, L.cout, pk);
-                else pack_hx(q, 3, L.cin, L.cout, pk);
+                if (l == 0) pack_hx_conv0(q, pk, &fold);
+                else if (time_merged || mel_merged) pack_hx_tm(q, L.cin, L.cout, pk, &fold);
+                else pack_hx(q, 3, L.cin, L.cout, pk, &fold);
+                if (!(fold.absmax < 65000.0))
+                    return fail(OWW_ERANGE, "conv layer %d: folded weight magnitude %.3g (BatchNorm scale x weight x activation-scale ratio 2^%d) is outside "
+                                "the f16 range of the fp16-split kernels (use_mfma = 3); use use_mfma = 1", l, fold.absmax, de);
                 o_conv[l] = hb.add(pk);
             }
             else if (h->rr && l > 0) { pack_rr(q, 3, L.cin, L.cout, pk); o_conv[l] = hb.add(pk); }
@@ -973,11 +1189,17 @@ int oww_commit(oww_ctx* h) {
             if (l < 19) {
                 // zero padded to whole 16-channel tiles: the register-resident kernels evaluate the pad channels (as zeros)
                 std::vector<float> pad((size_t)(L.cout + 15) / 16 * 16, 0.f);
-                if (h->hx) pad_hx_rows(q, L.cout, owh::WUNSCALE, pad);       // tile row order; the f16-split weights carry a factor 2^8
+                if (h->hx) {
+                    // f16-split family: the scale lives in the weights.  Slot "scale" is only read by conv0: the third operand of the
+                    // med3 that applies its ReLU in the folded form (+inf where the BatchNorm scale is >= 0, -inf where it is negative)
+                    std::vector<float> bound(L.cout);
+                    for (int c = 0; c < L.cout; ++c) bound[c] = q[c] < 0.f ? -INFINITY : INFINITY;
+                    pad_hx_rows(bound.data(), L.cout, 1.0f, pad);
+                }
                 else memcpy(pad.data(), q, L.cout * sizeof(float));
                 o_scale[l] = hb.add(pad); q += L.cout;
                 std::fill(pad.begin(), pad.end(), 0.f);
-                if (h->hx) pad_hx_rows(q, L.cout, 1.0f, pad);
+                if (h->hx) pad_hx_rows(q, L.cout, std::ldexp(1.0f, h->hx_e[l]), pad);       // accumulator start values K h, tile row order
                 else memcpy(pad.data(), q, L.cout * sizeof(float));
                 o_shift[l] = hb.add(pad); q += L.cout;
             }
@@ -1202,6 +1424,15 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(hipStreamSynchronize(h->stream));
         // the warm-up already drove the network with an all-ones mel history: weights that overflow the f16 range there are refused now
         if (int rc = range_check(h, "oww_commit")) return rc;
+        // f16-split family: replay the calibration probes and hold the result to the exact-fp32 run (refuses weights the split loses)
+        if (h->hx && !getenv("OWW_NO_COMMIT_SELFTEST")) {
+            if (int rc = selftest_hx(h, cal)) return rc;
+            HIPCHK(hipMemsetAsync(h->d_mel, 0, SP * 8 * h->kmax * 32 * sizeof(float), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_emb, 0, SP * 96 * sizeof(float), h->stream));
+            HIPCHK(hipMemsetAsync(h->d_raw, 0, SP * std::max(h->NL, 1) * sizeof(float), h->stream));
+            if (int rc = do_reset(h, nullptr, (int)SP, nullptr)) return rc;
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
     }
     h->committed = true;
     return OWW_OK;

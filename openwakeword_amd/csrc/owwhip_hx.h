@@ -26,37 +26,28 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float WSCALE = 256.0f;            // weights are stored as f16 halves of 2^8 * w
 constexpr float WUNSCALE = 1.0f / 256.0f;
 
-// Optional (OWH_PKF32=1, off): BatchNorm + activation and the masked tap combine on register pairs with v_pk_fma_f32 /
-// v_pk_mul_f32.  17 % fewer VALU instructions in stage C, but measured 1-2 % SLOWER per step: a packed fp32 instruction
-// occupies the VALU for two passes on this part, and the extra DPP hazard nops cost more than the saved issue slots.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef OWH_PKF32
-#define OWH_PKF32 0
-#endif
-#ifndef OWH_MASKSEL
-#define OWH_MASKSEL 1      // stream-boundary masks of the 1x3 tap combine as selects; 0: as 0/1 multipliers (v_mul / v_fma: one VALU
-                           // instruction fewer per value, yet stage D measured 18 % and stage E 3 % SLOWER -- kept as an A/B switch)
-#endif
-template <bool BN>
-__device__ __forceinline__ f32x4 bn_act(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift,
-                                        int oct, int j) {
-    if (!BN) return v;
-#if OWH_PKF32
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + oct * 16 + 4 * j);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + oct * 16 + 4 * j);
-    f32x4 r;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x2 y = __builtin_elementwise_fma(f32x2{v[2 * h], v[2 * h + 1]}, f32x2{sc[2 * h], sc[2 * h + 1]},
-                                                  f32x2{sh[2 * h], sh[2 * h + 1]});
-        const f32x2 t = y * 0.2f;
-        r[2 * h] = fmaxf(fmaxf(t[0], y[0]), -0.4f);
-        r[2 * h + 1] = fmaxf(fmaxf(t[1], y[1]), -0.4f);
-    }
-    return r;
-#else
-    return owr::bn_act<BN>(v, scale, shift, oct, j);
-#endif
+// BatchNorm in the f16-split family is FOLDED: the per-channel scale (sign included) goes into the f16-split weights, the shift is
+// the accumulator's start value, and every layer's activations are carried multiplied by a per-layer power of two K = 2^e chosen at
+// oww_commit from a calibration run on the exact-fp32 kernels (owwhip.hip: calibrate_hx) so that they sit in the middle of the f16
+// range whatever the weights' own scale is:
+//      acc = sum_k W'_k X_k + K h,   W' = s w K_out / K_in,  X = K_in a(y_in)   =>   acc = K_out y
+//      K a(y) = max(max(0.2 acc, acc), -0.4 K)                 (the activation is positively homogeneous up to its clamp constant)
+// Two VALU per value (v_mul, v_max3) instead of three, no silent underflow for small-valued networks, and max-pooling commutes
+// with the (monotone) activation.  Results differ from the unfolded evaluation by fp32 round-off (s w is formed in double and split
+// into hi + lo, 22 bits, like the plain weights were).
+__device__ __forceinline__ float act1(float x, float cl) {
+    return fmaxf(fmaxf(0.2f * x, x), cl);      // v_mul (paired: v_pk_mul) + v_max3
+}
+// activation of one output tile; HALF: registers 2, 3 are padding and stay zero
+template <bool ACT, bool HALF>
+__device__ __forceinline__ f32x4 act_t(const f32x4 v, float cl) {
+    if (!ACT) return HALF ? f32x4{v[0], v[1], 0.f, 0.f} : v;
+    if (HALF) return f32x4{act1(v[0], cl), act1(v[1], cl), 0.f, 0.f};
+    return f32x4{act1(v[0], cl), act1(v[1], cl), act1(v[2], cl), act1(v[3], cl)};
+}
+// the accumulator's start value of output tile oct: K * BatchNorm shift in tile row order (zero in padding rows); nullptr = 0
+__device__ __forceinline__ f32x4 acc_init(const float* init, int oct, int j) {
+    return init ? *reinterpret_cast<const f32x4*>(init + oct * 16 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // operand pair (hi, lo) of one k-step of one position tile
@@ -193,16 +184,6 @@ __device__ __forceinline__ void store_tile_h(const f32x4 (&t)[NCT], float* __res
         }
 }
 
-// folded BatchNorm + activation of one output tile; HALF: registers 2, 3 are padding and stay zero
-template <bool BN, bool HALF>
-__device__ __forceinline__ f32x4 bn_act_t(const f32x4 v, const float* __restrict__ scale, const float* __restrict__ shift, int oct, int j) {
-    if (!HALF) return bn_act<BN>(v, scale, shift, oct, j);
-    if (!BN) return f32x4{v[0], v[1], 0.f, 0.f};
-    const float s0 = scale[oct * 16 + 4 * j], s1 = scale[oct * 16 + 4 * j + 1];
-    const float h0 = shift[oct * 16 + 4 * j], h1 = shift[oct * 16 + 4 * j + 1];
-    return f32x4{owr::leaky_clamp(v[0] * s0 + h0), owr::leaky_clamp(v[1] * s1 + h1), 0.f, 0.f};
-}
-
 // Position order inside a 16-position tile of stages C, D, E (F = 8, 4, 2 mel positions per stream, SPT = 16 / F streams per tile).
 // The fp32 family keeps a stream's positions together (position p = F * stream + mel), so a +-1 mel shift of the per-tap
 // accumulators of a 1x3 layer is a DPP row shift by one lane plus a select that zeroes what crossed a stream boundary: 2 extra
@@ -229,7 +210,7 @@ template <int N> __device__ __forceinline__ float dpp_shl_zero(float x) {
 // debug dump of the f16-split family (cf. owr::dump_tile): a half last tile keeps channel 16 ct + 2j + e in register e < 2
 template <int NCT, int F, int C>
 __device__ __forceinline__ void dump_tile_ht(const f32x4 (&t)[NCT], float* __restrict__ dbg, size_t stride, int off, int s_first,
-                                             int row, int S, int lane) {
+                                             int row, int S, int lane, float mul) {
     const int pos = lane & 15, j = lane >> 4;
     const int sp = tile_stream<F>(pos), f = tile_mel<F>(pos), s = s_first + sp;
     if (s >= S) return;
@@ -239,7 +220,7 @@ __device__ __forceinline__ void dump_tile_ht(const f32x4 (&t)[NCT], float* __res
         for (int e = 0; e < 4; ++e) {
             int c = ct * 16 + 4 * j + e;
             if (C % 16 == 8 && ct == NCT - 1) c = e < 2 ? ct * 16 + 2 * j + e : C;
-            if (c < C) dbg[(size_t)s * stride + off + (row * F + f) * C + c] = t[ct][e];
+            if (c < C) dbg[(size_t)s * stride + off + (row * F + f) * C + c] = t[ct][e] * mul;      // (mul = 1 / K of the layer: dumps are in true units)
         }
 }
 
@@ -303,15 +284,14 @@ using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
-                                            const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
+                                            const float* __restrict__ init, float cl, int wave, int lane,
                                             lanemask_t& bad) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
-    // stream-boundary masks as 0/1 values (used as select conditions, or as multipliers with OWH_MASKSEL=0)
     // (interleaved order: the row shift by SH = 16 / F lanes zero-fills exactly the stream-edge lanes and the masks are not used)
     constexpr int SH = kInterleave ? 16 / F : 1;
     constexpr bool MASKS = F < 16 && !kInterleave;
-    const float mfirst = (pos & (F - 1)) == 0 ? 0.f : 1.f, mlast = (pos & (F - 1)) == F - 1 ? 0.f : 1.f;
+    const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
@@ -324,19 +304,19 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
             const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
             f32x4 acc[NT];
+            f32x4 I = {0.f, 0.f, 0.f, 0.f};
+            if (ti == 2) I = acc_init(BN ? init : nullptr, oct, j);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 else {
+                    // the centre chain starts from the folded BatchNorm shift plus the shifted tap-0 sums (one v_add_f32 dpp)
 #pragma unroll
-#if OWH_MASKSEL
                     for (int e = 0; e < 4; ++e) {
                         if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
-                        const float l = dpp_shr_zero<SH>(accs[0][t][e]); acc[t][e] = (MASKS && mfirst == 0.f) ? 0.f : l;
+                        const float l = dpp_shr_zero<SH>(accs[0][t][e]);
+                        acc[t][e] = I[e] + ((MASKS && first) ? 0.f : l);
                     }
-#else
-                    for (int e = 0; e < 4; ++e) acc[t][e] = MASKS ? dpp_shr_zero<SH>(accs[0][t][e]) * mfirst : dpp_shr_zero<SH>(accs[0][t][e]);
-#endif
                 }
             }
 #pragma unroll
@@ -356,13 +336,9 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-#if OWH_MASKSEL
                         if (HOUT && oct == NCTO - 1 && e >= 2) { res[t][e] = 0.f; continue; }
                         const float hh = dpp_shl_zero<SH>(accs[1][t][e]);
-                        res[t][e] = acc[t][e] + ((MASKS && mlast == 0.f) ? 0.f : hh);
-#else
-                        res[t][e] = MASKS ? fmaf(dpp_shl_zero<SH>(accs[1][t][e]), mlast, acc[t][e]) : acc[t][e] + dpp_shl_zero<SH>(accs[1][t][e]);
-#endif
+                        res[t][e] = acc[t][e] + ((MASKS && last) ? 0.f : hh);
                     }
                 }
             }
@@ -375,8 +351,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (HOUT && oct == NCTO - 1) out[t][oct] = bn_act_t<BN, true>(res[t], scale, shift, oct, j);
-            else out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j);
+            if (HOUT && oct == NCTO - 1) out[t][oct] = act_t<BN, true>(res[t], cl);
+            else out[t][oct] = act_t<BN, false>(res[t], cl);
             pin(out[t][oct]);
         }
         OWH_OCT_SB();
@@ -427,7 +403,7 @@ __device__ __forceinline__ void merge_mel_rems(const Op (&in)[NT][KSI], Op (&M)[
 template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
 __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], float* wbuf,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
-                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
+                                             const float* __restrict__ init, float cl, int wave, int lane,
                                              lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
@@ -444,6 +420,8 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
             const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
             f32x4 acc[NT];
+            f32x4 I = {0.f, 0.f, 0.f, 0.f};
+            if (ti == 2) I = acc_init(BN ? init : nullptr, oct, j);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (ti < 2) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -451,7 +429,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
-                        acc[t][e] = dpp_shr_zero<SH>(accs[0][t][e]);
+                        acc[t][e] = I[e] + dpp_shr_zero<SH>(accs[0][t][e]);
                     }
                 }
             }
@@ -486,8 +464,8 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (HOUT && oct == NCTO - 1) out[t][oct] = bn_act_t<BN, true>(res[t], scale, shift, oct, j);
-            else out[t][oct] = bn_act<BN>(res[t], scale, shift, oct, j);
+            if (HOUT && oct == NCTO - 1) out[t][oct] = act_t<BN, true>(res[t], cl);
+            else out[t][oct] = act_t<BN, false>(res[t], cl);
             pin(out[t][oct]);
         }
         OWH_OCT_SB();
@@ -508,7 +486,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
-                                             const float* __restrict__ scale, const float* __restrict__ shift, float post, int wave, int lane,
+                                             const float* __restrict__ init, float cl, int wave, int lane,
                                              lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
@@ -522,8 +500,9 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
             float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
             if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
             else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+            const f32x4 I = acc_init(BN ? init : nullptr, oct, j);           // folded BatchNorm shift = the chain's start value
 #pragma unroll
-            for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < NR; ++r) acc[r] = I;
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
@@ -552,9 +531,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (BN && HOUT && oct == NCTO) out[r][oct - 1] = bn_act_t<true, true>(prev[r], scale, shift, oct - 1, j);
-                else if (BN) out[r][oct - 1] = bn_act<true>(prev[r], scale, shift, oct - 1, j);
-                else out[r][oct - 1] = prev[r] * post;
+                if (HOUT && oct == NCTO) out[r][oct - 1] = act_t<BN, true>(prev[r], cl);
+                else out[r][oct - 1] = act_t<BN, false>(prev[r], cl);
                 pin(out[r][oct - 1]);
             }
         }
@@ -637,7 +615,7 @@ __device__ __forceinline__ void merge_rems(const RemPairs (&rem)[NR + 2], Op (&M
 template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
 __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1)[KSF], const Op (&in)[NR][KSF], const Op (&M)[NR][NMK],
                                               f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
-                                              const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane,
+                                              const float* __restrict__ init, float cl, int wave, int lane,
                                               lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
@@ -651,8 +629,9 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
             float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
             if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
             else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+            const f32x4 I = acc_init(BN ? init : nullptr, oct, j);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < NR; ++r) acc[r] = I;
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
@@ -686,8 +665,8 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (HOUT && oct == NCTO) out[r][oct - 1] = bn_act_t<BN, true>(prev[r], scale, shift, oct - 1, j);
-                else out[r][oct - 1] = bn_act<BN>(prev[r], scale, shift, oct - 1, j);
+                if (HOUT && oct == NCTO) out[r][oct - 1] = act_t<BN, true>(prev[r], cl);
+                else out[r][oct - 1] = act_t<BN, false>(prev[r], cl);
                 pin(out[r][oct - 1]);
             }
         }
@@ -739,7 +718,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
     __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
-    __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
+    __shared__ __attribute__((aligned(16))) float sbn[4][NCT * 16];      // per layer: K * BatchNorm shift in tile row order = accumulator start values
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
     lanemask_t bad = 0;
@@ -749,8 +728,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     issue_chunk<NBAM, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
-        sbn[l][0][c] = p.scale[l][c];
-        sbn[l][1][c] = p.shift[l][c];
+        sbn[l][c] = p.shift[l][c];
     }
     const int s_first = g * C::SPT;
     // masked steps (oww_step_masked): a stream that sits this step out is computed like any other (the workgroup shares its weight
@@ -775,12 +753,12 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMA) {
         Op Mx[R][NMKA];
         merge_mel_rems<KSA, R, F, NPRA>(Xo, Mx);
-        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
+        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
     } else
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, bad);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane, p.dbg_mul[0]);
     }
     Op Ao[R][KS], H0[KS], H1[KS];
     if constexpr (MERGE) {
@@ -802,7 +780,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -819,11 +797,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane, p.dbg_mul[1]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
@@ -832,12 +810,12 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMC) {
         Op Mc[R][NMKC];
         merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
-        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     } else
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, bad);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
     }
     if constexpr (MERGE) {
         // conv d: 3x1 over [hist_d(2) ; Yc], K-merged form
@@ -858,7 +836,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3][0], sbn[3][1], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -875,11 +853,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], 1.f, wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane);
+        for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane, p.dbg_mul[3]);
     }
 
     if (!LAST && lane_on) {
@@ -901,7 +879,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
                     if (C::HOUT && ct == NCT - 1 && e >= 2) { pm[ct][e] = 0.f; continue; }      // padding registers of the half tile
                     float m = Y[ro * C::PT][ct][e];
                     if (C::PT == 2) m = fmax_nc(m, Y[ro * C::PT + 1][ct][e]);
-                    pm[ct][e] = fmax_nc(m, dpp_shl_zero<SH>(m));
+                    pm[ct][e] = fmax_nc(m, dpp_shl_zero<SH>(m)) * p.xmul;      // (the next stage's input scale: calibrate_hx's ladder)
                 }
             if ((f & 1) == 0) {                                        // one predicated region per pooled row
                 float* xo = p.xout + ((size_t)(gn * RO + pass * (R / C::PT) + ro) * (NCT * 4)) * 64 + j * 16 + posn;
@@ -925,7 +903,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float m = fmax_nc(Y[0][ct][e], Y[1][ct][e]);
-                m = fmax_nc(m, dpp_shl_zero<SH>(m));
+                m = fmax_nc(m, dpp_shl_zero<SH>(m)) * p.xmul;
                 Pl[ct][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, m)));
             }
         float* h19 = p.hist19 + (size_t)g * (2 * NCT * 4 * 64);
@@ -939,7 +917,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         to_ops<NCT>(Pl, Po[0]);
         f32x4 E[1][NCT];
         // (no guard here: an out-of-range input of conv19 yields a NaN embedding, which the heads kernel's guard reports)
-        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, nullptr, WUNSCALE, wave, lane, bad);
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, 0.f, wave, lane, bad);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
         const bool on19 = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (pos & 7), p.S - 1)] != 0);   // lanes 8..15 mirror 0..7
         if (on19) {
             store_tile<NCT>(T1, h19, lane);
@@ -950,9 +928,10 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
             const uint32_t slot = p.nfeat[s] % (uint32_t)p.TR;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                *reinterpret_cast<f32x4*>(p.feat + ((size_t)s * p.TR + slot) * 96 + ct * 16 + 4 * j) = E[0][ct];
-                *reinterpret_cast<f32x4*>(p.emb + (size_t)s * 96 + ct * 16 + 4 * j) = E[0][ct];
-                if (DBG && p.dbg) *reinterpret_cast<f32x4*>(p.dbg + (size_t)s * p.dbg_stride + p.dbg_off[4] + ct * 16 + 4 * j) = E[0][ct];
+                const f32x4 ev = E[0][ct] * p.emb_mul;                    // true units (conv19 runs at its input's scale x 4)
+                *reinterpret_cast<f32x4*>(p.feat + ((size_t)s * p.TR + slot) * 96 + ct * 16 + 4 * j) = ev;
+                *reinterpret_cast<f32x4*>(p.emb + (size_t)s * 96 + ct * 16 + 4 * j) = ev;
+                if (DBG && p.dbg) *reinterpret_cast<f32x4*>(p.dbg + (size_t)s * p.dbg_stride + p.dbg_off[4] + ct * 16 + 4 * j) = ev;
             }
         }
     }
@@ -1013,17 +992,21 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
             for (int oct = 0; oct < 2; ++oct) {
                 const f16x8 ah = lds_h(w0s, oct * 2 + 0, lane), al = lds_h(w0s, oct * 2 + 1, lane);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // conv0 has a ReLU between the convolution and its BatchNorm (s relu(v) + h): with s folded into the weights and the
+                // shift as start value, acc = K s v + K h and K (s relu(v) + h) = max(acc, K h) for s >= 0, min(acc, K h) for s < 0
+                // = med3(acc, K h, +-inf): one VALU (bn[0..31] = the per-channel +-inf, bn[32..63] = K h)
+                const f32x4 I = acc_init(bn + 32, oct, j), B = acc_init(bn, oct, j);
+                f32x4 acc = I;
                 acc = OWH_MFMA(ah, b.h, acc);
                 acc = OWH_MFMA(ah, b.l, acc);
                 acc = OWH_MFMA(al, b.h, acc);
 #pragma unroll
-                for (int e = 0; e < (oct == 1 ? 2 : 4); ++e) acc[e] = fmax_nc(acc[e], 0.f);       // (tile 1 = the half tile: 8 channels)
-                if (oct == 1) Y0[oct] = bn_act_t<true, true>(acc, bn, bn + 32, oct, j);
-                else Y0[oct] = bn_act<true>(acc, bn, bn + 32, oct, j);
+                for (int e = 0; e < (oct == 1 ? 2 : 4); ++e) acc[e] = __builtin_amdgcn_fmed3f(acc[e], I[e], B[e]);       // (tile 1 = the half tile: 8 channels)
+                if (oct == 1) Y0[oct] = act_t<true, true>(acc, p.clampv[0]);
+                else Y0[oct] = act_t<true, false>(acc, p.clampv[0]);
                 pin(Y0[oct]);
             }
-            if (DBG && p.dbg) dump_tile_ht<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane);
+            if (DBG && p.dbg) dump_tile_ht<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane, p.dbg_mul[0]);
             to_ops<2, true>(Y0, Y0o[t]);
         }
         // ---- conv1: 1x3 over two half-row tiles with carries across the seam
@@ -1031,6 +1014,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
         for (int oct = 0; oct < 2; ++oct) {
             f32x4 acc[3][4];
+            const f32x4 I1 = acc_init(bn + 96, oct, j);
 #pragma unroll
             for (int ti = 0; ti < 3; ++ti) {
                 const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
@@ -1041,7 +1025,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (oct == 1 && e >= 2) { acc[1][t][e] = 0.f; continue; }
-                            acc[1][t][e] = (t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]);
+                            acc[1][t][e] = I1[e] + ((t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]));
                         }
                     }
                 }
@@ -1065,11 +1049,11 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
                 }
                 if (oct == 0) { nan_guard(bad, r0[0]); nan_guard(bad, r1[0]); }
                 if (oct == 1) {
-                    Y1[t0][oct] = bn_act_t<true, true>(r0, bn + 64, bn + 96, oct, j);
-                    Y1[t1][oct] = bn_act_t<true, true>(r1, bn + 64, bn + 96, oct, j);
+                    Y1[t0][oct] = act_t<true, true>(r0, p.clampv[1]);
+                    Y1[t1][oct] = act_t<true, true>(r1, p.clampv[1]);
                 } else {
-                    Y1[t0][oct] = bn_act<true>(r0, bn + 64, bn + 96, oct, j);
-                    Y1[t1][oct] = bn_act<true>(r1, bn + 64, bn + 96, oct, j);
+                    Y1[t0][oct] = act_t<true, false>(r0, p.clampv[1]);
+                    Y1[t1][oct] = act_t<true, false>(r1, p.clampv[1]);
                 }
                 pin(Y1[t0][oct]); pin(Y1[t1][oct]);
             }
@@ -1078,7 +1062,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
         if (DBG && p.dbg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                dump_tile_ht<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+                dump_tile_ht<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane, p.dbg_mul[1]);
         }
         Op Y1o[4][1];
 #pragma unroll
@@ -1088,8 +1072,9 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
         for (int oct = 0; oct < 2; ++oct) {
             f32x4 acc[4];
+            const f32x4 I2 = acc_init(bn + 160, oct, j);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) acc[t] = I2;
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const f16x8 ah = lds_h(w2s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w2s, (oct * 3 + tap) * 2 + 1, lane);
@@ -1108,8 +1093,8 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (oct == 1) Y2[t][oct] = bn_act_t<true, true>(acc[t], bn + 128, bn + 160, oct, j);
-                else Y2[t][oct] = bn_act<true>(acc[t], bn + 128, bn + 160, oct, j);
+                if (oct == 1) Y2[t][oct] = act_t<true, true>(acc[t], p.clampv[2]);
+                else Y2[t][oct] = act_t<true, false>(acc[t], p.clampv[2]);
                 pin(Y2[t][oct]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1117,7 +1102,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
         if (DBG && p.dbg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                dump_tile_ht<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane);
+                dump_tile_ht<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane, p.dbg_mul[2]);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1136,7 +1121,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
                 for (int e = 0; e < 4; ++e) {
                     if (ct == 1 && e >= 2) { pm[h][ct][e] = 0.f; continue; }
                     const float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
-                    pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m));
+                    pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m)) * p.xmul;
                 }
         if ((pos & 1) == 0) {                                      // one predicated region for all sixteen stores
 #pragma unroll

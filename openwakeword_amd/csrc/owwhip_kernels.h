@@ -1323,6 +1323,17 @@ __global__ void fill_kernel(float* x, size_t n, float v) {
     if (i < n) x[i] = v;
 }
 
+// largest |x| of every layer's debug dump (oww_commit's calibration of the f16-split family): grid (20 layers, streams), the
+// result as float bit patterns (non-negative floats order like their bit patterns; a NaN ends up above every finite value)
+__global__ void layer_absmax_kernel(const float* __restrict__ dbg, size_t stride, const int* __restrict__ off /*[21]*/, unsigned* __restrict__ out /*[20]*/) {
+    const int l = blockIdx.x;
+    const float* x = dbg + (size_t)blockIdx.y * stride;
+    unsigned m = 0u;
+    for (int i = off[l] + threadIdx.x; i < off[l + 1]; i += blockDim.x) m = max(m, __float_as_uint(fabsf(x[i])));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + l, m);
+}
+
 // reset: copy per-layer templates into the listed streams' state
 struct ResetParams {
     const int* ids;          // device list or null (all)

@@ -492,6 +492,10 @@ struct RStageParams {
     float* dbg;
     size_t dbg_stride;
     int dbg_off[5];
+    float clampv[4];       // f16-split family: -0.4 K of each layer (activation clamp in the layer's scaled domain, owwhip_hx.h act1)
+    float dbg_mul[5];      // f16-split family: 1 / K of each layer (debug dumps are written in true units); [4] = conv19
+    float xmul;            // f16-split family: factor of the pooled hand-over (K of the next stage's input / K of this stage's last layer)
+    float emb_mul;         // f16-split family, last stage: 1 / K of conv19 (embeddings are stored in true units)
     int* range_flag;       // f16-split family: sticky out-of-range flag of the handle (owwhip_hx.h nan_guard); nullptr otherwise
     const uint8_t* stream_on;  // f16-split family, oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
 };
@@ -660,6 +664,7 @@ struct RAParams {
     float* dbg;
     size_t dbg_stride;
     int dbg_off[3];
+    float clampv[3], dbg_mul[3], xmul;   // see RStageParams (f16-split family; there scale[0] = conv0's med3 bound, shift[l] = K * BatchNorm shift)
     int* range_flag;       // see RStageParams::range_flag
     const uint8_t* stream_on;  // see RStageParams::stream_on
 };

@@ -338,10 +338,12 @@ def test_host_fed_pipeline_matches_blocking_steps(emb, heads):
         eng.close()
 
 
-def test_self_test_catches_f16_range_overflow(emb, heads):
-    """StreamEngine.self_test: the deploy-time comparison of the f16-split family with the exact-fp32 family passes on
-    the normal weights and raises on a network whose activations leave the f16 range (one BatchNorm shift of 3e5: the
-    ReLU / max stages swallow the NaNs, so nothing else would flag it)."""
+def test_self_test_and_commit_time_range_handling(emb, heads):
+    """StreamEngine.self_test: the deploy-time comparison of the f16-split family with the exact-fp32 family passes on the normal
+    weights.  A network whose EMBEDDINGS leave the f16 range (one late BatchNorm shift of 3e5 -> embeddings of order 1e6, which the
+    heads' f16-split GEMM cannot carry) is refused when the handle is created: since round 3 oww_commit replays a probe set on
+    the f16-split kernels and compares embeddings and raw scores with an exact-fp32 run of the same weights (the CNN itself would
+    carry these activations: every layer runs at a calibrated power-of-two scale, tests/test_weight_regimes.py)."""
     import copy
     from openwakeword_amd._lib import OwwRangeError
     eng = StreamEngine(4, heads, emb)
@@ -353,8 +355,6 @@ def test_self_test_catches_f16_range_overflow(emb, heads):
     big = copy.deepcopy(emb)
     gamma, beta, mean, var = big["bn"][10]                              # weights.synthetic_embedding: Keras order
     big["bn"][10] = (gamma, np.full_like(beta, 3.0e5), mean, var)
-    # ... and since ABI 2 the f16-split kernels notice it themselves: the commit-time warm-up on the all-ones mel history already
-    # trips the range guard, so such weights are refused when the handle is created
     with pytest.raises(OwwRangeError, match="use_mfma = 1"):
         StreamEngine(4, heads, big)
     eng = StreamEngine(4, heads, big, use_mfma=1)                       # the exact family agrees with itself
