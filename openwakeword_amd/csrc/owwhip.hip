@@ -215,18 +215,19 @@ void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, std::vector<float>
     out.assign(hbuf.size() / 2, 0.f);
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
 }
-// conv0 (3x3, one input channel): one k-step, k = tap index (9 of 32 used)
+// conv0 (3x3, one input channel, K = 9) in the K-folded form of owh::hstageA_stream: the three products of the f16 split share ONE
+// k-step -- k-slot 8g + q of lane (i, g): slots 0..8 = wh[tap] (against xh), 9..17 = wl[tap] (against xh), 18..26 = wh[tap] (against
+// xl), 27..31 = 0.  One 1 KB block per output-channel tile.
 void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out, HxFold* fold) {
-    std::vector<_Float16> hbuf((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
+    std::vector<_Float16> hbuf((size_t)2 * 64 * 8, (_Float16)0.f);
     for (int oct = 0; oct < 2; ++oct)
         for (int lane = 0; lane < 64; ++lane)
             for (int q = 0; q < 8; ++q) {
-                const int i = lane & 15, g = lane >> 4, k = 8 * g + q, co = hx_row_channel(oct, i, 24);
-                if (k >= 9 || co < 0) continue;
+                const int i = lane & 15, g = lane >> 4, slot = 8 * g + q, co = hx_row_channel(oct, i, 24);
+                if (slot >= 27 || co < 0) continue;
                 _Float16 hi, lo;
-                fold->split(w[k * 24 + co], co, hi, lo);
-                hbuf[((size_t)(oct * 2 + 0) * 64 + lane) * 8 + q] = hi;
-                hbuf[((size_t)(oct * 2 + 1) * 64 + lane) * 8 + q] = lo;
+                fold->split(w[(slot % 9) * 24 + co], co, hi, lo);
+                hbuf[((size_t)oct * 64 + lane) * 8 + q] = (slot / 9 == 1) ? lo : hi;
             }
     out.assign(hbuf.size() / 2, 0.f);
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));

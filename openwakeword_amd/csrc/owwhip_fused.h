@@ -23,12 +23,6 @@ namespace owf {
 using owh::lanemask_t;
 using owr::f32x4;
 
-#ifndef OWF_I16_STAGE
-#define OWF_I16_STAGE 0    // 1: sample window staged in LDS as raw int16 -- measured SLOWER (stage 2.26 vs 2.17 ms: 16 ds_read_i16 + more spills); kept as an A/B switch
-#endif
-#ifndef OWF_T_STAGE
-#define OWF_T_STAGE 0      // 1: transposed float staging [8][89] (A/B switch)
-#endif
 #ifndef OWF_B128_STAGE
 #define OWF_B128_STAGE 1   // float staging with two ds_write_b128 per lane (0: scalar stores, paired by the compiler into ds_write2_b32)
 #endif
@@ -49,14 +43,14 @@ struct MelAParams {
 };
 
 // LDS layout (floats)
-constexpr int FA_W0 = 2 * 2 * 256, FA_W12 = 2 * 3 * 2 * 256, FA_BN = 3 * 2 * 32, FA_MT = 11 * 34, FA_Z = 2 * 576;
+constexpr int FA_W0 = 2 * 256, FA_W12 = 2 * 3 * 2 * 256, FA_BN = 3 * 2 * 32, FA_MT = owh::sa::WAVE_HALVES / 2, FA_Z = 2 * 576, FA_GT = 512;
 constexpr int FA_OFF_W0 = 0, FA_OFF_W1 = FA_OFF_W0 + FA_W0, FA_OFF_W2 = FA_OFF_W1 + FA_W12, FA_OFF_BN = FA_OFF_W2 + FA_W12;
 constexpr int FA_OFF_HANN = FA_OFF_BN + FA_BN, FA_OFF_TW1 = FA_OFF_HANN + 400, FA_OFF_TW2 = FA_OFF_TW1 + 2 * 8 * 64;
-constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16 * 32, FA_OFF_MEL = FA_OFF_MS + 32;
+constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16 * 32, FA_OFF_GT = FA_OFF_MS + 32, FA_OFF_MEL = FA_OFF_GT + FA_GT;
 constexpr int FA_OFF_Z = FA_OFF_MEL + FA_WG * FA_MT + ((4 - (FA_WG * FA_MT) % 4) % 4);
 constexpr int FA_LDS_BYTES = (FA_OFF_Z + FA_WG * FA_Z) * 4;
-static_assert(FA_OFF_Z % 4 == 0 && FA_OFF_W1 % 4 == 0 && FA_OFF_W2 % 4 == 0, "16-byte aligned operand blocks");
-static_assert(owk::MEL_WX <= FA_Z && 8 * 89 <= FA_Z, "sample window fits the transpose planes");
+static_assert(FA_OFF_Z % 4 == 0 && FA_OFF_W1 % 4 == 0 && FA_OFF_W2 % 4 == 0 && FA_OFF_GT % 4 == 0 && FA_OFF_MEL % 4 == 0 && FA_MT % 4 == 0, "16-byte aligned blocks");
+static_assert(owk::MEL_WX <= FA_Z, "sample window fits the transpose planes");
 
 // the 672 (+8) samples of pass f2 (frames 2 f2, 2 f2 + 1) of [tail(480) ; pcm(1280)] as raw int16 (lane l: samples 8l.., 512 + 8l..):
 // every piece of 8 samples lies wholly in the tail or wholly in the chunk, and both rows are 16-byte aligned (the host checks)
@@ -117,9 +111,11 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
     }
     for (int i = tid; i < 512; i += NT) t_taps[i] = q.mel_taps[(i & 31) * 16 + (i >> 5)];
     if (tid < 32) s_ms[tid] = q.mel_start[tid] - 2;
-    for (int i = tid; i < FA_WG * FA_MT; i += NT) fl[FA_OFF_MEL + i] = 0.f;
+    for (int i = tid; i < FA_WG * FA_MT; i += NT) fl[FA_OFF_MEL + i] = 0.f;      // (hi / lo planes of every wave: zero columns = the mel-axis padding)
+    owh::stageA_fill_gather_table(reinterpret_cast<int*>(fl + FA_OFF_GT), tid, NT);
     __syncthreads();
-    float* sM = fl + FA_OFF_MEL + wave * FA_MT;
+    _Float16* sP = reinterpret_cast<_Float16*>(fl + FA_OFF_MEL + wave * FA_MT);
+    const int* gtab = reinterpret_cast<const int*>(fl + FA_OFF_GT);
     float* const planes = fl + FA_OFF_Z + wave * FA_Z;
     lanemask_t bad = 0;
 
@@ -139,11 +135,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         const int lane = lane_all + z;            // (the mel phase's lane-derived offsets are iteration-local for the same reason)
         float* xr = planes + z;                   // FFT planes; the sample window and the two power rows alias them (owk::mel_kernel)
         float* xi = xr + 576;
-#if OWF_I16_STAGE
-        int16_t* sx = reinterpret_cast<int16_t*>(xr);   // 680 int16 = the first 340 floats of the re plane
-#else
         float* sx = xr;
-#endif
         float* pw0 = xr + 128;
         float* pw1 = xr + 257;                    // (one word off pw0's bank phase: the two frames' tap reads below are 2-way instead of
                                                   //  4-way bank-conflicted; rows pw0 [128, 248) and pw1 [257, 377) stay inside the
@@ -164,24 +156,15 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
             wave_sync();                         // the previous pass's readers of the planes / power rows are done (same wave)
-            // the window is staged as the raw int16 samples (one conflict-free 16-byte write per lane; the float form cost four
-            // 8-way-conflicting ds_write2_b32 per lane) and converted when the lanes pick up their strided samples
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = lane * 8 + u * 512;
-#if OWF_I16_STAGE
-                if (i < owk::MEL_WX) *reinterpret_cast<int4*>(sx + i) = raw[u];
-#else
                 if (i < owk::MEL_WX) {
                     // two 16-byte stores per lane (2-way bank conflicts) instead of the eight scalar ones the compiler pairs into
-                    // ds_write2_b32 at a stride of 8 floats (8-way conflicts: a quarter of this kernel's LDS-active cycles)
+                    // ds_write2_b32 at a stride of 8 floats (8-way conflicts: a quarter of this kernel's LDS-active cycles).
+                    // (staging the raw int16, or a transposed [8][89] float window, measured slower: round 2)
                     const int16_t* h = reinterpret_cast<const int16_t*>(&raw[u]);
-#if OWF_T_STAGE
-                    // transposed window [8][89]: sample 8 m + e at row e, column m -- the writes of a lane go to eight rows (each
-                    // store instruction covers consecutive columns: conflict-free), the strided reads below stay nearly conflict-free
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sx[e * 89 + (i >> 3)] = (float)h[e];
-#elif OWF_B128_STAGE
+#if OWF_B128_STAGE
                     *reinterpret_cast<f32x4*>(sx + i) = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                     *reinterpret_cast<f32x4*>(sx + i + 4) = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
 #else
@@ -189,7 +172,6 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                     for (int e = 0; e < 8; ++e) sx[i + e] = (float)h[e];
 #endif
                 }
-#endif
             }
             if (f2 < 3) fetch_pass(tail_row, pcm_row, f2 + 1, lane, raw);     // next pass's samples fly during this FFT
             wave_sync();
@@ -199,13 +181,8 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 const int n = 64 * n2 + lane;
                 const bool in = (n >= 56) && (n < 456);
                 const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
-#if OWF_T_STAGE
-                re[n2] = w * sx[(n & 7) * 89 + (n >> 3)];
-                im[n2] = w * sx[(n & 7) * 89 + 20 + (n >> 3)];
-#else
-                re[n2] = w * (float)sx[n];
-                im[n2] = w * (float)sx[160 + n];
-#endif
+                re[n2] = w * sx[n];
+                im[n2] = w * sx[160 + n];
             }
             dft8(re, im);
 #pragma unroll
@@ -282,7 +259,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
             const float v = (db[f2] == INFINITY) ? 1.0f : fmaxf(db[f2], floor_db) / 10.0f + 2.0f;
-            sM[(2 + 2 * f2 + hf) * 34 + 1 + mbin] = v;
+            owh::stageA_put_mel(sP, 2 + 2 * f2 + hf, mbin, v);       // rows 2..9 of the wave's planes, as (hi, lo) f16 halves
             if (q.mel_out) q.mel_out[((size_t)s * 8 + 2 * f2 + hf) * 32 + mbin] = v;
         }
         // new 480-sample tail = the last 480 samples of the chunk (every tail read of this step has completed: its data was used)
@@ -290,10 +267,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                            *reinterpret_cast<const int4*>(q.pcm + (size_t)s * 1280 + 800 + lane * 8);
         wave_sync();
         __builtin_amdgcn_sched_barrier(0);       // the mel phase ends here: none of its values stays live into stage A
-        int goff[8];                              // conv0 operand gather offsets (see owh::hstageA_kernel), formed per iteration
-#pragma unroll
-        for (int qq = 0; qq < 8; ++qq) { const int k = min(8 * (lane >> 4) + qq, 8); goff[qq] = (k / 3) * 34 + (k % 3) + (lane & 15); }
-        owh::hstageA_stream<DBG, true>(q.a, s, sM, sW0, sW1, sW2, sbn, goff, bad, lane_all);
+        owh::hstageA_stream<DBG, true>(q.a, s, sP, sW0, sW1, sW2, sbn, gtab, bad, lane_all);
         __builtin_amdgcn_sched_barrier(0);
     }
     owh::raise_range_flag(bad, q.a.range_flag);

@@ -941,140 +941,206 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage A (parameters and layouts: owr::RAParams; w0 / w1 / w2 = hx-packed, hist2 tiles in plain D order)
+// stage A (parameters: owr::RAParams; w0 = conv0 in the K-folded form of pack_hx_conv0, w1 / w2 = hx-packed)
+//
+// Round-3 form.  The 32 mel bins of a row are split over the row's two position tiles by PARITY: position p of tile h is mel bin
+// 2p + h (rounds 1-2: bin 16h + p).  The +-1 mel neighbours of a position then sit in the OTHER tile of the row -- in the same
+// lane, or one lane over with the zero padding of the mel axis falling exactly on the lane a row shift leaves without a source:
+//   conv1 (1x3):  out_T0[p] = W0 X_T1[p-1] + W1 X_T0[p] + W2 X_T1[p]       out_T1[p] = W0 X_T0[p] + W1 X_T1[p] + W2 X_T0[p+1]
+//     -> per tile ONE main chain (start value K h, two taps, six MFMAs) + one side chain (three MFMAs) that enters through a single
+//        v_add_f32 dpp: 1 VALU per value for the tap combine (rounds 1-2: 5.3 -- two shifts with carries across the seam + adds);
+//   pool 2x2:     the four values of a pooling window sit in the SAME lane of the row pair's four tiles: three max, no shift, and the
+//                 16 pooled bins of a row fill one whole tile of stage B's input (unpredicated, fully coalesced stores);
+//   the activation of conv2 runs after the pooling (the fold makes acc = K y with K > 0: max-pooling commutes with it): 1/4 of the values.
+// conv0 (3x3, ONE input channel, K = 9): the three products of the f16 split share a single k-step,
+//        k-slots 0..8 = xh_tap wh_tap, 9..17 = xh_tap wl_tap, 18..26 = xl_tap wh_tap   (27 of 32 slots; pack_hx_conv0)
+//   so conv0 is one MFMA per output tile instead of three, and its B operand is gathered as f16 halves straight from two LDS planes
+//   (hi / lo of the mel rows, split ONCE when a row is written) -- no VALU split per tap position (rounds 1-2: 12 VALU per tile).
+// The conv1 outputs of the last two rows (conv2's history) and the last two mel rows live in HBM in operand form -- (hi, lo) f16
+// pairs, the same 4 bytes per value as fp32 -- so nothing is split again when a step starts.
 // ------------------------------------------------------------------------------------------------
-// one stream-step of stage A for the wave: mel rows (LDS tile sM: rows 0, 1 = history, 2..9 = the step's eight new rows, one zero
-// column either side) -> conv0, conv1, conv2, pool -> stage B input; updates the stream's conv2 / mel histories.  MEL_IN_LDS:
-// the caller has already put the new rows into sM (fused mel front end, owh::hmelA_kernel), else they are read from p.mel.
-template <bool DBG, bool MEL_IN_LDS>
-__device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, float* sM, const float* sW0, const float* sW1,
-                                               const float* sW2, const float* sbn0, const int (&goff)[8], lanemask_t& bad, int lane) {
-    using namespace owr;
+namespace sa {
+constexpr int RS = 34;                 // halves per mel row in a plane: 32 bins + a zero column either side
+constexpr int PLANE = 344;             // 10 rows (2 history + 8 new) x 34, rounded up to a multiple of 8 halves
+constexpr int WAVE_HALVES = 2 * PLANE; // hi plane, lo plane
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// gather offsets of conv0's B operand (bytes into a wave's planes, tile row 0 / parity 0): lane (p, g), half q <-> k-slot 8g + q
+__device__ __forceinline__ void stageA_fill_gather_table(int* gtab /*[64][8]*/, int tid, int nt) {
+    for (int i = tid; i < 512; i += nt) {
+        const int lane = i >> 3, q = i & 7, p = lane & 15, g = lane >> 4, slot = 8 * g + q;
+        const int tap = slot % 9, plane = slot >= 18 ? 1 : 0;
+        gtab[i] = slot < 27 ? 2 * (plane * sa::PLANE + (tap / 3) * sa::RS + (tap % 3) + 2 * p) : 0;
+    }
+}
+// one mel value -> its (hi, lo) halves in the planes
+__device__ __forceinline__ void stageA_put_mel(_Float16* sP, int row, int bin, float v) {
+    const _Float16 hi = (_Float16)v;
+    sP[row * sa::RS + 1 + bin] = hi;
+    sP[sa::PLANE + row * sa::RS + 1 + bin] = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ f32x4 mfma3(const f16x8 ah, const f16x8 al, const Op& x, f32x4 c) {
+    c = OWH_MFMA(ah, x.h, c);
+    c = OWH_MFMA(ah, x.l, c);
+    return OWH_MFMA(al, x.h, c);
+}
+// debug dump of a stage-A tile (parity order): position p of tile h <-> mel bin 2p + h
+__device__ __forceinline__ void dump_tile_a(const f32x4 (&t)[2], float* __restrict__ dbg, size_t stride, int off, int s, int row, int h,
+                                            int S, int lane, float mul) {
+    if (s >= S) return;
     const int pos = lane & 15, j = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = ct == 0 ? 4 * j + e : (e < 2 ? 16 + 2 * j + e : 24);
+            if (c < 24) dbg[(size_t)s * stride + off + (row * 32 + 2 * pos + h) * 24 + c] = t[ct][e] * mul;
+        }
+}
+
+// one stream-step of stage A for the wave.  sP: the wave's planes; rows 0, 1 = history (filled here), rows 2..9 = the step's eight new
+// rows (MEL_IN_LDS: already written by the caller -- the fused mel front end, owf::hmelA_kernel -- else read from p.mel).
+template <bool DBG, bool MEL_IN_LDS>
+__device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _Float16* sP, const float* sW0, const float* sW1,
+                                               const float* sW2, const float* sbn0, const int* gtab, lanemask_t& bad, int lane) {
+    using namespace owr;
+    const int j = lane >> 4;
     int z = 0;
     asm volatile("" : "+s"(z));
     const float* w0s = sW0 + z;
     const float* w1s = sW1 + z;
     const float* w2s = sW2 + z;
     const float* bn = sbn0 + z;
-    const float* mel = MEL_IN_LDS ? nullptr : p.mel + (size_t)s * p.mel_stride + p.mel_off;
-    float* hm = p.hist_mel + (size_t)s * 64;
-    float* h2 = p.hist2 + (size_t)s * (2 * 2 * 8 * 64);
-    if (MEL_IN_LDS) {
-        sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hm[lane];        // rows 2..9 were written by the caller (fused mel front end)
-    } else {
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mel + lane * 4);
-        const float hv = hm[lane];
+    unsigned* hm = reinterpret_cast<unsigned*>(p.hist_mel) + (size_t)s * 64;           // (hi | lo << 16) of the last two mel rows
+    unsigned* h2 = reinterpret_cast<unsigned*>(p.hist2) + (size_t)s * (2 * 2 * 8 * 64);   // [row 2][parity 2][dword 8: 3 hi, 3 lo, 2 unused][64]
+    {
+        const unsigned w = hm[lane];
+        const int o = (lane >> 5) * sa::RS + 1 + (lane & 31);
+        reinterpret_cast<unsigned short*>(sP)[o] = (unsigned short)(w & 0xffffu);
+        reinterpret_cast<unsigned short*>(sP)[sa::PLANE + o] = (unsigned short)(w >> 16);
+    }
+    if (!MEL_IN_LDS) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.mel + (size_t)s * p.mel_stride + p.mel_off + lane * 4);
         const int row = lane >> 3, col = (lane & 7) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sM[(2 + row) * 34 + 1 + col + e] = m4[e];
-        sM[(lane >> 5) * 34 + 1 + (lane & 31)] = hv;
+        for (int e = 0; e < 4; ++e) stageA_put_mel(sP, 2 + row, col + e, m4[e]);
     }
-    Op Yh[2][2][1];                               // conv1 output rows r-2, r-1 in operand form: [row][half][ks]
-    f32x4 Yf[2][2][2];                            // the same rows in fp32 (become the stored history)
+    int go[8];
+    {
+        const u32x4 g0 = *reinterpret_cast<const u32x4*>(gtab + z + lane * 8), g1 = *reinterpret_cast<const u32x4*>(gtab + z + lane * 8 + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { go[q] = (int)g0[q]; go[4 + q] = (int)g1[q]; }
+    }
+    Op Yh[2][2];                                  // conv1 output rows r-2, r-1 in operand form: [row][parity]
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { load_tile_h<2, true>(Yf[r][h], h2 + (r * 2 + h) * 512, lane); to_ops<2, true>(Yf[r][h], Yh[r][h]); }
+        for (int h = 0; h < 2; ++h) {
+            const unsigned* src = h2 + (r * 2 + h) * 512 + lane;
+            Yh[r][h].h = __builtin_bit_cast(f16x8, u32x4{src[0], src[64], src[128], 0u});
+            Yh[r][h].l = __builtin_bit_cast(f16x8, u32x4{src[192], src[256], src[320], 0u});
+        }
+    const char* planes = reinterpret_cast<const char*>(sP);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                 // rows 2q, 2q+1
+    for (int q = 0; q < 4; ++q) {                 // conv rows 2q, 2q+1; tile t = 2 * (row & 1) + parity
         OWR_SB();
-        // ---- conv0 (K = 9 -> one k-step)
+        // ---- conv0: one K-folded MFMA per output tile
         Op Y0o[4][1];
+        {
+            const f16x8 a0 = lds_h(w0s, 0, lane), a1 = lds_h(w0s, 1, lane);
+            const f32x4 I0 = acc_init(bn + 32, 0, j), I1 = acc_init(bn + 32, 1, j), B0 = acc_init(bn, 0, j), B1 = acc_init(bn, 1, j);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = 2 * q + (t >> 1), h = t & 1;
-            f32x4 b0, b1;
+            for (int t = 0; t < 4; ++t) {
+                const int r = 2 * q + (t >> 1), h = t & 1;
+                const char* base = planes + (r * sa::RS + h) * 2;
+                typedef unsigned short u16;
+                u32x4 bw;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { b0[e] = sM[r * 34 + h * 16 + goff[e]]; b1[e] = sM[r * 34 + h * 16 + goff[4 + e]]; }
-            const Op b = split_pair(b0, b1);
-            f32x4 Y0[2];
-#pragma unroll
-            for (int oct = 0; oct < 2; ++oct) {
-                const f16x8 ah = lds_h(w0s, oct * 2 + 0, lane), al = lds_h(w0s, oct * 2 + 1, lane);
+                for (int v = 0; v < 4; ++v)
+                    bw[v] = (unsigned)*reinterpret_cast<const u16*>(base + go[2 * v]) | ((unsigned)*reinterpret_cast<const u16*>(base + go[2 * v + 1]) << 16);
+                const f16x8 b = __builtin_bit_cast(f16x8, bw);
                 // conv0 has a ReLU between the convolution and its BatchNorm (s relu(v) + h): with s folded into the weights and the
                 // shift as start value, acc = K s v + K h and K (s relu(v) + h) = max(acc, K h) for s >= 0, min(acc, K h) for s < 0
                 // = med3(acc, K h, +-inf): one VALU (bn[0..31] = the per-channel +-inf, bn[32..63] = K h)
-                const f32x4 I = acc_init(bn + 32, oct, j), B = acc_init(bn, oct, j);
-                f32x4 acc = I;
-                acc = OWH_MFMA(ah, b.h, acc);
-                acc = OWH_MFMA(ah, b.l, acc);
-                acc = OWH_MFMA(al, b.h, acc);
+                f32x4 Y0[2];
+                Y0[0] = OWH_MFMA(a0, b, I0);
+                Y0[1] = OWH_MFMA(a1, b, I1);
 #pragma unroll
-                for (int e = 0; e < (oct == 1 ? 2 : 4); ++e) acc[e] = __builtin_amdgcn_fmed3f(acc[e], I[e], B[e]);       // (tile 1 = the half tile: 8 channels)
-                if (oct == 1) Y0[oct] = act_t<true, true>(acc, p.clampv[0]);
-                else Y0[oct] = act_t<true, false>(acc, p.clampv[0]);
-                pin(Y0[oct]);
+                for (int e = 0; e < 4; ++e) Y0[0][e] = __builtin_amdgcn_fmed3f(Y0[0][e], I0[e], B0[e]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) Y0[1][e] = __builtin_amdgcn_fmed3f(Y0[1][e], I1[e], B1[e]);       // (tile 1 = the half tile: 8 channels)
+                Y0[0] = act_t<true, false>(Y0[0], p.clampv[0]);
+                Y0[1] = act_t<true, true>(Y0[1], p.clampv[0]);
+                pin(Y0[0]); pin(Y0[1]);
+                if (DBG && p.dbg) dump_tile_a(Y0, p.dbg, p.dbg_stride, p.dbg_off[0], s, r, h, p.S, lane, p.dbg_mul[0]);
+                to_ops<2, true>(Y0, Y0o[t]);
             }
-            if (DBG && p.dbg) dump_tile_ht<2, 16, 24>(Y0, p.dbg + h * 16 * 24, p.dbg_stride, p.dbg_off[0], s, r * 2, p.S, lane, p.dbg_mul[0]);
-            to_ops<2, true>(Y0, Y0o[t]);
         }
-        // ---- conv1: 1x3 over two half-row tiles with carries across the seam
+        // ---- conv1: 1x3 over the row's two parity tiles (see the header of this section)
         f32x4 Y1[4][2];
 #pragma unroll
         for (int oct = 0; oct < 2; ++oct) {
-            f32x4 acc[3][4];
-            const f32x4 I1 = acc_init(bn + 96, oct, j);
+            const f32x4 I = acc_init(bn + 96, oct, j);
+            const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sd[4], mn[4];                   // side chain / main chain of output tile t
+            {   // tap 0: W0 X_T1 -> side of T0 (enters shifted right), W0 X_T0 -> main of T1
+                const f16x8 ah = lds_h(w1s, (oct * 3 + 0) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + 0) * 2 + 1, lane);
+                sd[0] = OWH_MFMA(ah, Y0o[1][0].h, Z); mn[1] = OWH_MFMA(ah, Y0o[0][0].h, I);
+                sd[2] = OWH_MFMA(ah, Y0o[3][0].h, Z); mn[3] = OWH_MFMA(ah, Y0o[2][0].h, I);
+                sd[0] = OWH_MFMA(ah, Y0o[1][0].l, sd[0]); mn[1] = OWH_MFMA(ah, Y0o[0][0].l, mn[1]);
+                sd[2] = OWH_MFMA(ah, Y0o[3][0].l, sd[2]); mn[3] = OWH_MFMA(ah, Y0o[2][0].l, mn[3]);
+                sd[0] = OWH_MFMA(al, Y0o[1][0].h, sd[0]); mn[1] = OWH_MFMA(al, Y0o[0][0].h, mn[1]);
+                sd[2] = OWH_MFMA(al, Y0o[3][0].h, sd[2]); mn[3] = OWH_MFMA(al, Y0o[2][0].h, mn[3]);
+            }
+            {   // tap 2: W2 X_T0 -> side of T1 (enters shifted left), W2 X_T1 -> main of T0
+                const f16x8 ah = lds_h(w1s, (oct * 3 + 2) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + 2) * 2 + 1, lane);
+                sd[1] = OWH_MFMA(ah, Y0o[0][0].h, Z); mn[0] = OWH_MFMA(ah, Y0o[1][0].h, I);
+                sd[3] = OWH_MFMA(ah, Y0o[2][0].h, Z); mn[2] = OWH_MFMA(ah, Y0o[3][0].h, I);
+                sd[1] = OWH_MFMA(ah, Y0o[0][0].l, sd[1]); mn[0] = OWH_MFMA(ah, Y0o[1][0].l, mn[0]);
+                sd[3] = OWH_MFMA(ah, Y0o[2][0].l, sd[3]); mn[2] = OWH_MFMA(ah, Y0o[3][0].l, mn[2]);
+                sd[1] = OWH_MFMA(al, Y0o[0][0].h, sd[1]); mn[0] = OWH_MFMA(al, Y0o[1][0].h, mn[0]);
+                sd[3] = OWH_MFMA(al, Y0o[2][0].h, sd[3]); mn[2] = OWH_MFMA(al, Y0o[3][0].h, mn[2]);
+            }
+            {   // tap 1: the centre tap of every tile
+                const f16x8 ah = lds_h(w1s, (oct * 3 + 1) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + 1) * 2 + 1, lane);
 #pragma unroll
-            for (int ti = 0; ti < 3; ++ti) {
-                const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
+                for (int t = 0; t < 4; ++t) mn[t] = OWH_MFMA(ah, Y0o[t][0].h, mn[t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (ti < 2) acc[tap][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    else {
+                for (int t = 0; t < 4; ++t) mn[t] = OWH_MFMA(ah, Y0o[t][0].l, mn[t]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (oct == 1 && e >= 2) { acc[1][t][e] = 0.f; continue; }
-                            acc[1][t][e] = I1[e] + ((t & 1) ? dpp_shr1_carry(acc[0][t][e], acc[0][t - 1][e]) : dpp_shr1_zero(acc[0][t][e]));
-                        }
-                    }
-                }
-                const f16x8 ah = lds_h(w1s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + tap) * 2 + 1, lane);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].h, acc[tap][t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(ah, Y0o[t][0].l, acc[tap][t]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[tap][t] = OWH_MFMA(al, Y0o[t][0].h, acc[tap][t]);
+                for (int t = 0; t < 4; ++t) mn[t] = OWH_MFMA(al, Y0o[t][0].h, mn[t]);
             }
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int t0 = 2 * rr, t1 = 2 * rr + 1;
-                f32x4 r0, r1;
+            for (int t = 0; t < 4; ++t) {
+                f32x4 r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (oct == 1 && e >= 2) { r0[e] = 0.f; r1[e] = 0.f; continue; }
-                    r0[e] = acc[1][t0][e] + dpp_shl1_carry(acc[2][t0][e], acc[2][t1][e]);
-                    r1[e] = acc[1][t1][e] + dpp_shl1_zero(acc[2][t1][e]);
+                    if (oct == 1 && e >= 2) { r[e] = 0.f; continue; }
+                    r[e] = mn[t][e] + ((t & 1) ? dpp_shl1_zero(sd[t][e]) : dpp_shr1_zero(sd[t][e]));
                 }
-                if (oct == 0) { nan_guard(bad, r0[0]); nan_guard(bad, r1[0]); }
-                if (oct == 1) {
-                    Y1[t0][oct] = act_t<true, true>(r0, p.clampv[1]);
-                    Y1[t1][oct] = act_t<true, true>(r1, p.clampv[1]);
-                } else {
-                    Y1[t0][oct] = act_t<true, false>(r0, p.clampv[1]);
-                    Y1[t1][oct] = act_t<true, false>(r1, p.clampv[1]);
-                }
-                pin(Y1[t0][oct]); pin(Y1[t1][oct]);
+                if (oct == 0) nan_guard(bad, r[0]);
+                if (oct == 1) Y1[t][oct] = act_t<true, true>(r, p.clampv[1]);
+                else Y1[t][oct] = act_t<true, false>(r, p.clampv[1]);
+                pin(Y1[t][oct]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (DBG && p.dbg) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dump_tile_ht<2, 16, 24>(Y1[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[1], s, (2 * q + (t >> 1)) * 2, p.S, lane, p.dbg_mul[1]);
+            for (int t = 0; t < 4; ++t) dump_tile_a(Y1[t], p.dbg, p.dbg_stride, p.dbg_off[1], s, 2 * q + (t >> 1), t & 1, p.S, lane, p.dbg_mul[1]);
         }
         Op Y1o[4][1];
 #pragma unroll
         for (int t = 0; t < 4; ++t) to_ops<2, true>(Y1[t], Y1o[t]);
-        // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1]
-        f32x4 Y2[4][2];
+        // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1], then pool 2x2 (same lane of the four tiles), then the activation
+        f32x4 PA[2];
 #pragma unroll
         for (int oct = 0; oct < 2; ++oct) {
+            const f32x4 I = acc_init(bn + 160, oct, j);
             f32x4 acc[4];
-            const f32x4 I2 = acc_init(bn + 160, oct, j);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = I2;
+            for (int t = 0; t < 4; ++t) acc[t] = I;
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 const f16x8 ah = lds_h(w2s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w2s, (oct * 3 + tap) * 2 + 1, lane);
@@ -1083,7 +1149,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int src = (t >> 1) + tap, h = t & 1;
-                        const Op& b = src < 2 ? Yh[src][h][0] : Y1o[(src - 2) * 2 + h][0];
+                        const Op& b = src < 2 ? Yh[src][h] : Y1o[(src - 2) * 2 + h][0];
                         acc[t] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[t]);
                     }
             }
@@ -1091,68 +1157,69 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, fl
 #pragma unroll
                 for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
             }
+            if (DBG && p.dbg) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (oct == 1) Y2[t][oct] = act_t<true, true>(acc[t], p.clampv[2]);
-                else Y2[t][oct] = act_t<true, false>(acc[t], p.clampv[2]);
-                pin(Y2[t][oct]);
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 y[2] = {};
+                    y[oct] = oct == 1 ? act_t<true, true>(acc[t], p.clampv[2]) : act_t<true, false>(acc[t], p.clampv[2]);
+                    const int pos = lane & 15;
+#pragma unroll
+                    for (int e = 0; e < (oct == 1 ? 2 : 4); ++e) {
+                        const int c = oct == 0 ? 4 * j + e : 16 + 2 * j + e;
+                        if (s < p.S) p.dbg[(size_t)s * p.dbg_stride + p.dbg_off[2] + ((2 * q + (t >> 1)) * 32 + 2 * pos + (t & 1)) * 24 + c] = y[oct][e] * p.dbg_mul[2];
+                    }
+                }
             }
+            f32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (oct == 1 && e >= 2) { m[e] = 0.f; continue; }
+                m[e] = fmax_nc(fmax_nc(acc[0][e], acc[1][e]), fmax_nc(acc[2][e], acc[3][e]));
+            }
+            m = oct == 1 ? act_t<true, true>(m, p.clampv[2]) : act_t<true, false>(m, p.clampv[2]);
+            PA[oct] = m * p.xmul;                 // stage B's input scale (calibrate_hx's ladder)
+            pin(PA[oct]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (DBG && p.dbg) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dump_tile_ht<2, 16, 24>(Y2[t], p.dbg + (t & 1) * 16 * 24, p.dbg_stride, p.dbg_off[2], s, (2 * q + (t >> 1)) * 2, p.S, lane, p.dbg_mul[2]);
-        }
+        for (int h = 0; h < 2; ++h) { Yh[0][h] = Y1o[h][0]; Yh[1][h] = Y1o[2 + h][0]; }
+        // ---- stage B input row q: the 16 pooled bins are the 16 positions of one tile
+        float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64) + lane;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            Yh[0][h][0] = Y1o[h][0]; Yh[1][h][0] = Y1o[2 + h][0];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) { Yf[0][h][ct] = Y1[h][ct]; Yf[1][h][ct] = Y1[2 + h][ct]; }
-        }
-        // ---- pool 2x2 -> stage B input row q
-        float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64) + j * 16 + (pos >> 1);
-        float pm[2][2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (ct == 1 && e >= 2) { pm[h][ct][e] = 0.f; continue; }
-                    const float m = fmax_nc(Y2[h][ct][e], Y2[2 + h][ct][e]);
-                    pm[h][ct][e] = fmax_nc(m, dpp_shl1_zero(m)) * p.xmul;
-                }
-        if ((pos & 1) == 0) {                                      // one predicated region for all sixteen stores
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (!(ct == 1 && e >= 2)) xo[(ct * 4 + e) * 64 + h * 8] = pm[h][ct][e];
-        }
+        for (int e = 0; e < 4; ++e) xo[e * 64] = PA[0][e];
+        xo[4 * 64] = PA[1][0];
+        xo[5 * 64] = PA[1][1];
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) store_tile_h<2, true>(Yf[r][h], h2 + (r * 2 + h) * 512, lane);
-    hm[lane] = sM[(8 + (lane >> 5)) * 34 + 1 + (lane & 31)];
+        for (int h = 0; h < 2; ++h) {
+            unsigned* dst = h2 + (r * 2 + h) * 512 + lane;
+            const u32x4 hh = __builtin_bit_cast(u32x4, Yh[r][h].h), ll = __builtin_bit_cast(u32x4, Yh[r][h].l);
+            dst[0] = hh[0]; dst[64] = hh[1]; dst[128] = hh[2];
+            dst[192] = ll[0]; dst[256] = ll[1]; dst[320] = ll[2];
+        }
+    {
+        const int o = (8 + (lane >> 5)) * sa::RS + 1 + (lane & 31);
+        const unsigned short* u = reinterpret_cast<const unsigned short*>(sP);
+        hm[lane] = (unsigned)u[o] | ((unsigned)u[sa::PLANE + o] << 16);
+    }
 }
 
 template <bool DBG>
 __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p) {
     using namespace owr;
-    const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
 
-    // weights: conv0 [2 oct][part 2] (4 KB), conv1 / conv2 [2 oct][3 taps][part 2] (12 KB each); BatchNorms; mel tile
-    __shared__ __attribute__((aligned(16))) float sW0[2 * 2 * 256];
+    // weights: conv0 [2 oct] K-folded blocks (2 KB), conv1 / conv2 [2 oct][3 taps][part 2] (12 KB each); start values; planes; gather table
+    __shared__ __attribute__((aligned(16))) float sW0[2 * 256];
     __shared__ __attribute__((aligned(16))) float sW[2][2 * 3 * 2 * 256];
     __shared__ __attribute__((aligned(16))) float sbn[3][2][32];
-    __shared__ float sMel[4][11 * 34];
-    for (int i = threadIdx.x; i < 2 * 2 * 64; i += 256) reinterpret_cast<f32x4*>(sW0)[i] = reinterpret_cast<const f32x4*>(p.w0)[i];
+    __shared__ __attribute__((aligned(16))) _Float16 sPl[4][sa::WAVE_HALVES];
+    __shared__ __attribute__((aligned(16))) int gtab[512];
+    for (int i = threadIdx.x; i < 2 * 64; i += 256) reinterpret_cast<f32x4*>(sW0)[i] = reinterpret_cast<const f32x4*>(p.w0)[i];
     for (int i = threadIdx.x; i < 2 * 3 * 2 * 64; i += 256) {
         reinterpret_cast<f32x4*>(sW[0])[i] = reinterpret_cast<const f32x4*>(p.w1)[i];
         reinterpret_cast<f32x4*>(sW[1])[i] = reinterpret_cast<const f32x4*>(p.w2)[i];
@@ -1162,18 +1229,14 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
         sbn[l][0][c] = p.scale[l][c];
         sbn[l][1][c] = p.shift[l][c];
     }
-    for (int i = threadIdx.x; i < 4 * 11 * 34; i += 256) sMel[0][i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * sa::WAVE_HALVES; i += 256) sPl[0][i] = (_Float16)0.f;
+    stageA_fill_gather_table(gtab, threadIdx.x, 256);
     __syncthreads();
-    float* sM = sMel[wave];
-    // conv0 operand gather: lane (p, g) supplies taps k = 8g + q, q = 0..7 (k < 9 real, the rest has zero weight)
-    int goff[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int k = min(8 * j + q, 8); goff[q] = (k / 3) * 34 + (k % 3) + pos; }
     lanemask_t bad = 0;
 
     for (int s = gw; s < p.n_streams; s += nw) {
         if (p.stream_on && !p.stream_on[s]) continue;            // masked step: this stream sits it out
-        hstageA_stream<DBG, false>(p, s, sM, sW0, sW[0], sW[1], &sbn[0][0][0], goff, bad, lane);
+        hstageA_stream<DBG, false>(p, s, sPl[wave], sW0, sW[0], sW[1], &sbn[0][0][0], gtab, bad, lane);
     }
     raise_range_flag(bad, p.range_flag);
 }
