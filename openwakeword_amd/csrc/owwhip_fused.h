@@ -45,7 +45,7 @@ struct MelAParams {
 // LDS layout (floats)
 constexpr int FA_W0 = 2 * 256, FA_W12 = 2 * 3 * 2 * 256, FA_BN = 3 * 2 * 32, FA_MT = owh::sa::WAVE_HALVES / 2, FA_Z = 2 * 576, FA_GT = 512;
 constexpr int FA_OFF_W0 = 0, FA_OFF_W1 = FA_OFF_W0 + FA_W0, FA_OFF_W2 = FA_OFF_W1 + FA_W12, FA_OFF_BN = FA_OFF_W2 + FA_W12;
-constexpr int FA_OFF_HANN = FA_OFF_BN + FA_BN, FA_OFF_TW1 = FA_OFF_HANN + 400, FA_OFF_TW2 = FA_OFF_TW1 + 2 * 8 * 64;
+constexpr int FA_OFF_HANN = FA_OFF_BN + FA_BN, FA_OFF_TW1 = FA_OFF_HANN + 512, FA_OFF_TW2 = FA_OFF_TW1 + 2 * 8 * 64;
 constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16 * 32, FA_OFF_GT = FA_OFF_MS + 32, FA_OFF_MEL = FA_OFF_GT + FA_GT;
 constexpr int FA_OFF_Z = FA_OFF_MEL + FA_WG * FA_MT + ((4 - (FA_WG * FA_MT) % 4) % 4);
 constexpr int FA_LDS_BYTES = (FA_OFF_Z + FA_WG * FA_Z) * 4;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         sbn[(l * 2 + 0) * 32 + c] = q.a.scale[l][c];
         sbn[(l * 2 + 1) * 32 + c] = q.a.shift[l][c];
     }
-    for (int i = tid; i < 400; i += NT) t_hann[i] = q.hann[i];
+    for (int i = tid; i < 512; i += NT) t_hann[i] = (i >= 56 && i < 456) ? q.hann[i - 56] : 0.f;      // Hann(400) centred in the 512-point frame
     for (int i = tid; i < 512; i += NT) {
         float sn, cs;
         sincospif(-(float)((i & 63) * (i >> 6)) / 256.f, &sn, &cs);
@@ -179,8 +179,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
 #pragma unroll
             for (int n2 = 0; n2 < 8; ++n2) {
                 const int n = 64 * n2 + lane;
-                const bool in = (n >= 56) && (n < 456);
-                const float w = in ? s_hann[in ? n - 56 : 0] : 0.f;
+                const float w = s_hann[n];               // (zero outside [56, 456): the table is padded to the frame)
                 re[n2] = w * sx[n];
                 im[n2] = w * sx[160 + n];
             }
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 const float* pw = hf ? pw1 : pw0;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc = fmaf(pw[mstart + t], s_taps[t * 32 + mbin], acc);
-                float d = 10.0f * logf(fmaxf(acc, 1e-10f)) / 2.302585092994046f;
+                float d = owk::db10(acc);
                 const bool masked = first && (2 * f2 + hf) < 3;
                 if (!masked) vmax = fmaxf(vmax, d);
                 db[f2] = masked ? INFINITY : d;
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         const float floor_db = vmax - 80.0f;
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
-            const float v = (db[f2] == INFINITY) ? 1.0f : fmaxf(db[f2], floor_db) / 10.0f + 2.0f;
+            const float v = (db[f2] == INFINITY) ? 1.0f : owk::mel_units(db[f2], floor_db);
             owh::stageA_put_mel(sP, 2 + 2 * f2 + hf, mbin, v);       // rows 2..9 of the wave's planes, as (hi, lo) f16 halves
             if (q.mel_out) q.mel_out[((size_t)s * 8 + 2 * f2 + hf) * 32 + mbin] = v;
         }

@@ -45,6 +45,15 @@ __device__ __forceinline__ f32x4 act_t(const f32x4 v, float cl) {
     if (HALF) return f32x4{act1(v[0], cl), act1(v[1], cl), 0.f, 0.f};
     return f32x4{act1(v[0], cl), act1(v[1], cl), act1(v[2], cl), act1(v[3], cl)};
 }
+// owr::pin for a tile whose registers 2, 3 are padding zeros (HALF): only the two live registers pass through the opaque asm -- pinning the
+// constant zeros would materialise them (two v_mov per tile)
+template <bool HALF>
+__device__ __forceinline__ void pin_t(f32x4& v) {
+    if (!HALF) { owr::pin(v); return; }
+    float a = v[0], b = v[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    v = f32x4{a, b, 0.f, 0.f};
+}
 // the accumulator's start value of output tile oct: K * BatchNorm shift in tile row order (zero in padding rows); nullptr = 0
 __device__ __forceinline__ f32x4 acc_init(const float* init, int oct, int j) {
     return init ? *reinterpret_cast<const f32x4*>(init + oct * 16 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -351,9 +360,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
 #endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (HOUT && oct == NCTO - 1) out[t][oct] = act_t<BN, true>(res[t], cl);
-            else out[t][oct] = act_t<BN, false>(res[t], cl);
-            pin(out[t][oct]);
+            if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
+            else { out[t][oct] = act_t<BN, false>(res[t], cl); pin_t<false>(out[t][oct]); }
         }
         OWH_OCT_SB();
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
@@ -464,9 +472,8 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (HOUT && oct == NCTO - 1) out[t][oct] = act_t<BN, true>(res[t], cl);
-            else out[t][oct] = act_t<BN, false>(res[t], cl);
-            pin(out[t][oct]);
+            if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
+            else { out[t][oct] = act_t<BN, false>(res[t], cl); pin_t<false>(out[t][oct]); }
         }
         OWH_OCT_SB();
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
@@ -531,9 +538,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (HOUT && oct == NCTO) out[r][oct - 1] = act_t<BN, true>(prev[r], cl);
-                else out[r][oct - 1] = act_t<BN, false>(prev[r], cl);
-                pin(out[r][oct - 1]);
+                if (HOUT && oct == NCTO) { out[r][oct - 1] = act_t<BN, true>(prev[r], cl); pin_t<true>(out[r][oct - 1]); }
+                else { out[r][oct - 1] = act_t<BN, false>(prev[r], cl); pin_t<false>(out[r][oct - 1]); }
             }
         }
         if (PIPE && oct > 0 && oct < NCTO) {
@@ -665,9 +671,8 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (HOUT && oct == NCTO) out[r][oct - 1] = act_t<BN, true>(prev[r], cl);
-                else out[r][oct - 1] = act_t<BN, false>(prev[r], cl);
-                pin(out[r][oct - 1]);
+                if (HOUT && oct == NCTO) { out[r][oct - 1] = act_t<BN, true>(prev[r], cl); pin_t<true>(out[r][oct - 1]); }
+                else { out[r][oct - 1] = act_t<BN, false>(prev[r], cl); pin_t<false>(out[r][oct - 1]); }
             }
         }
 #if OWH_PIPE
@@ -1054,12 +1059,9 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
             for (int t = 0; t < 4; ++t) {
                 const int r = 2 * q + (t >> 1), h = t & 1;
                 const char* base = planes + (r * sa::RS + h) * 2;
-                typedef unsigned short u16;
-                u32x4 bw;
+                f16x8 b;                          // (element-wise f16 loads: ds_read_u16_d16 / _d16_hi fill the operand dwords in place)
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    bw[v] = (unsigned)*reinterpret_cast<const u16*>(base + go[2 * v]) | ((unsigned)*reinterpret_cast<const u16*>(base + go[2 * v + 1]) << 16);
-                const f16x8 b = __builtin_bit_cast(f16x8, bw);
+                for (int v = 0; v < 8; ++v) b[v] = *reinterpret_cast<const _Float16*>(base + go[v]);
                 // conv0 has a ReLU between the convolution and its BatchNorm (s relu(v) + h): with s folded into the weights and the
                 // shift as start value, acc = K s v + K h and K (s relu(v) + h) = max(acc, K h) for s >= 0, min(acc, K h) for s < 0
                 // = med3(acc, K h, +-inf): one VALU (bn[0..31] = the per-channel +-inf, bn[32..63] = K h)
@@ -1072,7 +1074,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
                 for (int e = 0; e < 2; ++e) Y0[1][e] = __builtin_amdgcn_fmed3f(Y0[1][e], I1[e], B1[e]);       // (tile 1 = the half tile: 8 channels)
                 Y0[0] = act_t<true, false>(Y0[0], p.clampv[0]);
                 Y0[1] = act_t<true, true>(Y0[1], p.clampv[0]);
-                pin(Y0[0]); pin(Y0[1]);
+                pin_t<false>(Y0[0]); pin_t<true>(Y0[1]);
                 if (DBG && p.dbg) dump_tile_a(Y0, p.dbg, p.dbg_stride, p.dbg_off[0], s, r, h, p.S, lane, p.dbg_mul[0]);
                 to_ops<2, true>(Y0, Y0o[t]);
             }
@@ -1120,9 +1122,8 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
                     r[e] = mn[t][e] + ((t & 1) ? dpp_shl1_zero(sd[t][e]) : dpp_shr1_zero(sd[t][e]));
                 }
                 if (oct == 0) nan_guard(bad, r[0]);
-                if (oct == 1) Y1[t][oct] = act_t<true, true>(r, p.clampv[1]);
-                else Y1[t][oct] = act_t<true, false>(r, p.clampv[1]);
-                pin(Y1[t][oct]);
+                if (oct == 1) { Y1[t][oct] = act_t<true, true>(r, p.clampv[1]); pin_t<true>(Y1[t][oct]); }
+                else { Y1[t][oct] = act_t<true, false>(r, p.clampv[1]); pin_t<false>(Y1[t][oct]); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1178,7 +1179,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
             }
             m = oct == 1 ? act_t<true, true>(m, p.clampv[2]) : act_t<true, false>(m, p.clampv[2]);
             PA[oct] = m * p.xmul;                 // stage B's input scale (calibrate_hx's ladder)
-            pin(PA[oct]);
+            if (oct == 1) pin_t<true>(PA[oct]); else pin_t<false>(PA[oct]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

@@ -630,6 +630,12 @@ struct MelParams {
     int S;
 };
 
+// dB value and host transform of the mel front end (ipynb cell 15: 10 log10(max(p, 1e-10)); utils.py:180,206: x / 10 + 2) with the two
+// divisions by constants written as multiplications (a true fp32 division is ~10 VALU instructions here; the result moves by <= 1 ulp,
+// i.e. < 1e-5 dB / 1e-6 mel units -- tests hold the rows to 5e-4)
+__device__ __forceinline__ float db10(float p) { return logf(fmaxf(p, 1e-10f)) * 4.3429448190325183f; }
+__device__ __forceinline__ float mel_units(float db, float floor_db) { return fmaf(fmaxf(db, floor_db), 0.1f, 2.0f); }
+
 __device__ __forceinline__ void dft8(float* re, float* im) {
     // forward 8-point DFT, natural order in and out
     const float h = 0.70710678118654752440f;
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 const float* pw = (fr & 1) ? pw1 : pw0;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc = fmaf(pw[mstart + t], taps[t], acc);
-                float db = 10.0f * logf(fmaxf(acc, 1e-10f)) / 2.302585092994046f;
+                float db = db10(acc);
                 const bool masked = first && frame < 3;
                 if (!masked) vmax = fmaxf(vmax, db);
                 if (masked) db = INFINITY;                 // marker: becomes 1.0 below
@@ -867,7 +873,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 if (frame >= p.n_frames) break;
                 float* o = p.out + ((size_t)s * p.n_frames + frame) * 32 + mbin;
                 const float db = (n_groups > 1) ? *o : last_db;
-                *o = (db == INFINITY) ? 1.0f : fmaxf(db, floor_db) / 10.0f + 2.0f;
+                *o = (db == INFINITY) ? 1.0f : mel_units(db, floor_db);
             }
             // new 480-sample tail = last 480 samples of [tail ; pcm]
             if (p.n_samples >= 480) {
@@ -898,7 +904,7 @@ __global__ void clamp_db_rows_kernel(float* x, int per_clip, const float* smax) 
 // per-clip clamp + the host transform of utils.py:180,206 (x/10 + 2): what embed_clips feeds the embedding model
 __global__ void clamp_transform_rows_kernel(float* x, int per_clip, const float* smax) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < per_clip) { float* q = x + (size_t)blockIdx.y * per_clip + i; *q = fmaxf(*q, smax[blockIdx.y] - 80.0f) / 10.0f + 2.0f; }
+    if (i < per_clip) { float* q = x + (size_t)blockIdx.y * per_clip + i; *q = mel_units(*q, smax[blockIdx.y] - 80.0f); }
 }
 
 __global__ void clamp_db_kernel(float* x, size_t n, float floor_db) {
