@@ -48,7 +48,11 @@ PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
 # f16 MFMAs (v_mfma_f32_16x16x32_f16, 16384 flop each) the fp16-split kernels execute per stream-step, channel padding included
 # (round 2: the layers with a 72-channel input run K-merged -- 7 instead of 9 k-steps per output tile -- i.e. layers b, c, d of
 #  stage C: 810 instead of 990, and layer a of stage D: 306 instead of 324; layer a of stage C, 48 channels in, 5 instead of 6: 780)
-HX_MFMAS = {"stageA": 672, "stageB": 756, "stageC": 780, "stageD": 306, "stageE": 182}
+#  round 3: stage A's conv0 is one K-folded MFMA per output tile instead of three: 608 instead of 672)
+HX_MFMAS = {"stageA": 608, "stageB": 756, "stageC": 780, "stageD": 306, "stageE": 182}
+MEL_FLOPS = 100_000         # FFT form of the log-mel front end per stream-step, executed by the fused launch's VALU
+PEAK_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: peak engine clock; 256 CUs x 4 SIMDs
+N_SIMD = 1024
 PEAK_HBM_GBS = 8000.0
 REALTIME_STEPS_PER_S = 12.5  # one 80 ms frame per stream every 80 ms
 
@@ -67,13 +71,43 @@ def pmc_traffic(kernel: str, streams: int, args):
     if args.valu or args.lds_mfma or streams != 131072:
         return None
     key = kernel + ("_rr" if args.fp32 else "_hx")
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
         except Exception:
             continue
     return None
+
+
+def issue_bound(kernel: str, streams: int, avg_ms: float, args):
+    """Composite bound of one launch from the committed PMC pass (profiles/r03_instr.json, tools/pmc.sh on this workload): wave
+    instructions per stream-step by pipe and the SIMD cycles they need at issue.  On this part a wave's VALU and MFMA work add up on
+    its SIMD (tools/ubench/overlap_ubench.hip: a VALU instruction issues in 4 cycles, v_mfma_f32_16x16x32_f16 in 16, no overlap between
+    the waves of a SIMD), so issue cycles = 4 VALU + 16 MFMA per stream-step; LDS and HBM are priced beside it and the largest of the
+    fractions names what binds."""
+    if args.valu or args.lds_mfma or args.fp32 or streams != 131072:
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_instr.json")))[kernel + "_hx"]
+    except Exception:
+        return None
+    per = lambda c: t[c] / streams
+    mfma, valu, lds = per("SQ_INSTS_MFMA"), per("SQ_INSTS_VALU") - per("SQ_INSTS_MFMA"), per("SQ_INSTS_LDS")
+    avail = avg_ms * 1e-3 * PEAK_CLOCK_GHZ * 1e9 * N_SIMD / streams          # SIMD cycles per stream-step at the peak clock
+    issue = 4 * valu + 16 * mfma
+    lds_frac = t["SQ_LDS_IDX_ACTIVE"] / (avg_ms * 1e-3 * PEAK_CLOCK_GHZ * 1e9 * 256)     # LDS-active cycles of the 256 CUs / CU cycles of the launch
+    hbm = pmc_traffic(kernel, streams, args)
+    fr = {"mfma_issue": 16 * mfma / avail, "valu_issue": 4 * valu / avail, "valu_plus_mfma_issue": issue / avail,
+          "lds": lds_frac,
+          "hbm": (hbm["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if hbm else None}
+    binds = max((k for k in ("valu_plus_mfma_issue", "lds", "hbm") if fr[k] is not None), key=lambda k: fr[k])
+    return {"wave_instructions_per_stream_step": {"valu": round(valu, 1), "mfma": round(mfma, 1), "lds": round(lds, 1)},
+            "simd_cycles_per_stream_step": {"available_at_2.4GHz": round(avail, 0), "mfma_issue": round(16 * mfma, 0), "valu_issue": round(4 * valu, 0)},
+            "frac_of_available": {k: (round(v, 4) if v is not None else None) for k, v in fr.items()}, "binds": binds,
+            "lds_bank_conflict_frac": round(t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0), 4),
+            "source": "profiles/r03_instr.json (rocprofv3 --pmc passes of tools/pmc.sh on this workload); the chip holds ~1.95 GHz of its 2.4 GHz "
+                      "peak in this regime (GRBM_GUI_ACTIVE / duration), so ~0.81 of 'available' is the practical ceiling"}
 
 
 def make_pcm_pool(torch, dev, S, n_pool, kind, gen, rank):
@@ -157,6 +191,48 @@ def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank):
             "square waves, Gaussian RMS 30..12000) at random stream ids of this engine x 16 frames vs OracleModel (numpy fp32)"}
 
 
+def quick_config(torch, dev, stream, S, head_names, steps, warmup, vad=False, host=False):
+    """One more configuration timed inside the default run (driver-timed): HBM-resident PCM unless `host` (pinned host buffers through
+    the pipelined oww_submit / oww_collect path); returns ms per step and frames/s."""
+    from openwakeword_amd import weights as W
+    from openwakeword_amd.engine import StreamEngine
+    heads = {n: W.synthetic_head(n, 1234) for n in head_names}
+    kw = dict(vad=W.synthetic_vad(1234), vad_threshold=0.5) if vad else {}
+    eng = StreamEngine(S, heads, W.synthetic_embedding(1234), device=dev.index, use_mfma=3, hip_stream=stream.cuda_stream, **kw)
+    try:
+        eng.reset()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xA11CE + 17)
+        pool = make_pcm_pool(torch, dev, S, 2, "noise", gen, 0)
+        scores = torch.empty(S, eng.n_labels, device=dev, dtype=torch.float32)
+        if not host:
+            dt, _ = timed_run(torch, None, eng, pool, scores, steps, warmup, dev, 1, timing=False)
+        else:
+            host_pool = [torch.empty(S, 1280, dtype=torch.int16, pin_memory=True).copy_(t).numpy() for t in pool]
+            host_scores = torch.empty(S, eng.n_labels, dtype=torch.float32, pin_memory=True).numpy()
+            n_in = 0
+            def pump(n):
+                nonlocal n_in
+                for i in range(n):
+                    eng.submit(host_pool[i % 2])
+                    n_in += 1
+                    if n_in == 2:
+                        eng.collect(host_scores); n_in -= 1
+                while n_in:
+                    eng.collect(host_scores); n_in -= 1
+                torch.cuda.synchronize(dev)
+            pump(warmup)
+            t0 = time.perf_counter()
+            pump(steps)
+            dt = time.perf_counter() - t0
+            scores = torch.from_numpy(host_scores).to(dev)
+        ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item()) and not eng.range_status()
+        return {"streams": S, "heads": list(head_names), "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 4),
+                "value": round(S * steps / dt, 1), "unit": "frames/s", "scores_valid": ok}
+    finally:
+        eng.close()
+
+
 def leg_resident_1m(args):
     """Child-process leg: 1,048,576 streams resident in one handle on one GPU (north star: >= 1 M concurrent streams on a
     node; this shows the whole million also FITS one GPU and what a step of it costs)."""
@@ -176,6 +252,15 @@ def leg_resident_1m(args):
     gen.manual_seed(0xA11CE)
     pool = make_pcm_pool(torch, dev, S, 2, "noise", gen, 0)
     scores = torch.empty(S, eng.n_labels, device=dev, dtype=torch.float32)
+    # the oracle-sampled parity check inside the resident million: 64 probe streams at random ids of THIS
+    # engine x 16 frames; the reference was computed (and cached) by the parent before it touched HIP
+    parity = None
+    if set(heads) <= {"alexa", "hey_mycroft", "hey_jarvis"} and not args.no_parity:
+        try:
+            from oracle import parity_sample as PS
+            parity = parity_check(torch, eng, pool, scores, dev, list(heads), PS.oracle_reference(), 0)
+        except Exception as e:
+            parity = {"error": repr(e)[:200]}
     dt, _ = timed_run(torch, None, eng, pool, scores, args.steps, args.warmup, dev, 1, timing=False)
     free1, _ = torch.cuda.mem_get_info(dev)
     ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item())
@@ -184,7 +269,7 @@ def leg_resident_1m(args):
                       "ms_per_step": round(ms, 3), "value": round(S * args.steps / dt, 1), "unit": "frames/s",
                       "realtime": bool(ms < 80.0), "realtime_budget_ms": 80.0,
                       "device_memory_used_gb": round((free0 - free1) / 2**30, 2), "device_memory_total_gb": round(total / 2**30, 1),
-                      "scores_valid": ok}))
+                      "scores_valid": ok, "parity": parity}))
 
 
 def main():
@@ -369,9 +454,27 @@ def main():
                                                               "FFT butterflies and LDS transposes bound it, not HBM"}
             eng32.close()
             eng = None
-        # ---- resident_1m: a million streams in ONE handle on this GPU, in a child process (own 73 GB of state)
+        # ---- the other BASELINE configurations and the serving-edge forms of the headline one, driver-timed:
+        #      configs[1] 4,096 x hey_jarvis, configs[2] 65,536 x 3 heads, configs[4] = + the VAD stand-in fused into every step,
+        #      and the headline batch with its PCM arriving over PCIe every step (pipelined oww_submit / oww_collect)
         del pool
+        if eng is not None:
+            eng.close()
+            eng = None
         torch.cuda.empty_cache()
+        if family == 3 and not args.vad:
+            try:
+                extras["configs"] = {
+                    "c1_4096x1": quick_config(torch, dev, stream, 4096, ["hey_jarvis"], 50, 10),
+                    "c2_65536x3": quick_config(torch, dev, stream, 65536, head_names, 50, 10),
+                }
+                extras["vad_fused"] = quick_config(torch, dev, stream, S, head_names, 20, 5, vad=True)
+                extras["host_pcm"] = dict(quick_config(torch, dev, stream, S, head_names, 20, 5, host=True),
+                                          note="PCIe-inclusive (pinned host PCM in, scores out, two steps in flight): never the headline value")
+            except Exception as e:
+                extras["configs_error"] = repr(e)[:400]
+            torch.cuda.empty_cache()
+        # ---- resident_1m: a million streams in ONE handle on this GPU, in a child process (own 73 GB of state)
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--leg", "resident_1m", "--streams", str(1 << 20), "--heads", args.heads,
                    "--steps", "10", "--warmup", "3"]
@@ -410,20 +513,23 @@ def main():
             per = {k: (v["ms"] / max(v["launches"], 1)) for k, v in ktimes.items()}
             out["kernel_ms"] = {k: round(v, 4) for k, v in per.items()}
             out["launches_per_step"] = int(round(sum(v["launches"] for v in ktimes.values()) / max(args.steps, 1)))
-            # Dominant kernel for the roofline: the longest of the launches whose bound is the matrix pipe (stages B..E; stage A
-            # too while the mel front end is a separate launch).  With the mel front end FUSED into stage A (default, mel class has
-            # no launches) that launch is a mixed VALU / LDS (FFT) + MFMA kernel: it is reported in full under "fused_front" and
-            # does not stand in for the MFMA roofline.
+            # Roofline kernel = the LONGEST launch of the step (not the longest "matrix-bound" one).  With the mel front end
+            # fused into stage A (default: the mel class has no launches) that launch also carries the FFT / log-mel work; its
+            # algorithmic flops are stage A's + the FFT form of the front end, priced against the matrix peak like every stage, and
+            # "composite" names what actually binds it (VALU + MFMA issue cycles, LDS cycles, HBM bytes).
             fused_front = per["mel"] == 0 and per["stageA"] > 0
-            dom = max((k for k in STAGE_FLOPS if not (fused_front and k == "stageA")), key=lambda k: per[k])
+            dom = max(STAGE_FLOPS, key=lambda k: per[k])
             f16 = family == 3
             peak = PEAK_F16_TFLOPS if f16 else PEAK_FP32_TFLOPS
+
+            def stage_flops(k):
+                return STAGE_FLOPS[k] + (MEL_FLOPS if (fused_front and k == "stageA") else 0)
 
             def stage_roof(k):
                 if per[k] <= 0:
                     return None
-                tf = STAGE_FLOPS[k] * S / (per[k] * 1e-3) / 1e12           # algorithmic (fp32-equivalent) flops only
-                r = {"achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / peak, 4)}
+                tf = stage_flops(k) * S / (per[k] * 1e-3) / 1e12          # algorithmic (fp32-equivalent) flops only
+                r = {"achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / peak, 4), "avg_ms": round(per[k], 4)}
                 if f16:
                     ex = HX_MFMAS[k] * 16384 * S / (per[k] * 1e-3) / 1e12  # what the matrix pipe executes: 3 MFMAs per product + padding
                     r.update({"executed_f16_tflops": round(ex, 1), "executed_frac_of_f16_peak": round(ex / peak, 4),
@@ -431,9 +537,11 @@ def main():
                 return r
 
             d = stage_roof(dom)
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s",
+            out["roofline"] = {"bound": "mfma", "kernel": dom + (" (mel front end + stage A, one launch)" if fused_front and dom == "stageA" else ""),
+                               "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s",
                                "frac": d["frac"], "traffic": pmc_traffic(dom, S, args),
-                               "flops_per_launch": STAGE_FLOPS[dom] * S, "avg_ms": round(per[dom], 4)}
+                               "flops_per_launch": stage_flops(dom) * S, "avg_ms": round(per[dom], 4),
+                               "composite": issue_bound(dom, S, per[dom], args)}
             if f16:
                 out["roofline"].update({k: d[k] for k in ("executed_f16_tflops", "executed_frac_of_f16_peak", "x_fp32_mfma_peak")})
                 out["roofline"]["note"] = ("fp32 products evaluated as 3 f16 MFMAs (hi/lo operand split, fp32 accumulate): 'achieved' counts the "
@@ -444,8 +552,8 @@ def main():
                 out["fused_front"] = {"kernel": "mel front end + stage A in one launch (owwhip_fused.h)", "avg_ms": round(per["stageA"], 4),
                                       "share_of_step": round(per["stageA"] / sum(per.values()), 3),
                                       "mfma": a, "mel_hbm_bytes_per_stream_step": front_bytes,
-                                      "mel_rows_to_hbm": 0, "note": "FFT / log-mel phases are VALU + LDS work on the same waves that then run "
-                                      "stage A's MFMAs; 'mfma' prices the whole launch against the matrix pipe by stage A's flops only"}
+                                      "mel_rows_to_hbm": 0, "composite": issue_bound("stageA", S, per["stageA"], args),
+                                      "note": "FFT / log-mel phases are VALU + LDS work on the same waves that then run stage A's MFMAs"}
             cnn_ms = sum(per[k] for k in STAGE_FLOPS)
             cnn_tf = sum(STAGE_FLOPS.values()) * S / (cnn_ms * 1e-3) / 1e12
             hf = head_flops(heads) * S / (per["heads"] * 1e-3) / 1e12 if per["heads"] > 0 else 0.0
@@ -453,7 +561,7 @@ def main():
             out["roofline_all"] = {
                 "cnn_all_stages": {"achieved": round(cnn_tf, 2), "unit": "TFLOP/s", "frac": round(cnn_tf / peak, 4),
                                    "x_fp32_mfma_peak": round(cnn_tf / PEAK_FP32_TFLOPS, 3)},
-                **{k: stage_roof(k) for k in STAGE_FLOPS},
+                **{k: dict(stage_roof(k) or {}, composite=issue_bound(k, S, per[k], args)) for k in STAGE_FLOPS},
                 "heads": {"achieved": round(hf, 2), "unit": "TFLOP/s", "frac": round(hf / peak, 4)},
                 "mel": ({"bound": "hbm", "achieved": round(MEL_BYTES * S / (mel_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(MEL_BYTES * S / (mel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} if mel_ms else

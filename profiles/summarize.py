@@ -90,8 +90,34 @@ def traffic_json(paths, out_path):
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
 
 
+def instr_json(paths, out_path):
+    """Per-kernel instruction and cycle counters of the full-grid launches (mean per launch) from all --pmc passes -> JSON that
+    bench.py turns into the composite issue bound of the longest launch (VALU / MFMA / LDS instructions per stream-step)."""
+    import json
+    agg = defaultdict(lambda: defaultdict(list))
+    grid = {}
+    for path in paths:
+        rows = list(csv.DictReader(open(path)))
+        gmax = defaultdict(int)
+        for r in rows:
+            gmax[short(r["Kernel_Name"])] = max(gmax[short(r["Kernel_Name"])], int(r["Grid_Size"]))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if int(r["Grid_Size"]) == gmax[k]:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                grid[k] = gmax[k]
+    out = {}
+    for k, v in agg.items():
+        if k.startswith(("stage", "heads_hx", "mel", "vad_")) and "SQ_INSTS_VALU" in v:
+            out[k] = {c: sum(x) / len(x) for c, x in v.items()}
+            out[k]["grid"] = grid[k]
+    json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--traffic":
         traffic_json(sys.argv[3:], sys.argv[2])
+    elif sys.argv[1] == "--instr":
+        instr_json(sys.argv[3:], sys.argv[2])
     else:
         main()

@@ -21,6 +21,7 @@ cd $GRAFT_REPO_ROOT
 find $out -type f ! -name '*.csv' ! -name '*.log' -delete
 python profiles/summarize.py $(find $out/trace -name '*kernel_trace.csv' | head -1) $(find $out/pmc* -name '*counter_collection.csv' | sort) > $out/summary.txt 2>&1
 python profiles/summarize.py --traffic $out/traffic.json $(find $out/pmc4 $out/pmc5 -name '*counter_collection.csv' | sort)
+python profiles/summarize.py --instr $out/instr.json $(find $out/pmc* -name '*counter_collection.csv' | sort)
 cat $out/summary.txt
 tail -3 $out/trace.log $out/pmc1.log | cut -c1-300
 du -sh $out
