@@ -107,15 +107,27 @@ def fold_verifier(verifier):
     steps = getattr(verifier, "steps", None)
     if not steps:
         raise ValueError("the device verifier needs the reference's pipeline (flatten -> StandardScaler -> LogisticRegression) or a (w, bias) pair")
-    scaler = next((st for _, st in steps if hasattr(st, "scale_") and hasattr(st, "mean_")), None)
-    clf = steps[-1][1]
+    # exactly the reference's structure, nothing skipped in silence: [FunctionTransformer (the flatten)] [StandardScaler] classifier.
+    # Any other transformer (PCA, a second scaler, ...) would fold into wrong scores: the caller must then keep the host-side hook
+    # of the single-stream Model (model.py:320-328), which runs any pickled object.
+    body = [st for _, st in steps]
+    clf = body.pop()
+    if body and type(body[0]).__name__ == "FunctionTransformer":
+        body.pop(0)
+    scaler = body.pop(0) if body and type(body[0]).__name__ == "StandardScaler" else None
+    if body:
+        raise ValueError("the device verifier folds only the reference's pipeline flatten -> StandardScaler -> LogisticRegression; "
+                         f"unsupported steps: {[type(st).__name__ for st in body]} (use the host-side hook of openwakeword_amd.Model)")
     if not hasattr(clf, "coef_") or not hasattr(clf, "intercept_") or np.asarray(clf.coef_).shape[0] != 1:
         raise ValueError("the last step of the verifier pipeline must be a fitted binary LogisticRegression")
     coef = np.asarray(clf.coef_, np.float64)[0]
     b = float(np.asarray(clf.intercept_, np.float64)[0])
     if scaler is not None:
-        scale = np.asarray(scaler.scale_, np.float64)
-        mean = np.asarray(scaler.mean_, np.float64)
+        # StandardScaler(with_mean=False) leaves mean_ = None, with_std=False leaves scale_ = None
+        scale = np.ones_like(coef) if getattr(scaler, "scale_", None) is None else np.asarray(scaler.scale_, np.float64)
+        mean = np.zeros_like(coef) if getattr(scaler, "mean_", None) is None else np.asarray(scaler.mean_, np.float64)
+        if scale.shape != coef.shape or mean.shape != coef.shape:
+            raise ValueError(f"verifier pipeline: scaler has {scale.size} features, the classifier {coef.size}")
         b -= float(np.sum(coef * mean / scale))
         coef = coef / scale
     return coef.astype(np.float32), b
@@ -236,7 +248,7 @@ class Model:
         handed to the reference package unchanged and ITS Model object is returned.  Where `openwakeword` (or the runtime it
         imports at module level, vad.py:48) is not importable this raises the reference's own kind of error (ValueError, cf.
         model.py:141) -- there is no silent fall-back to the HIP path or to anything else."""
-        framework = kwargs.get("inference_framework", "hip")
+        framework = kwargs.get("inference_framework", args[6] if len(args) > 6 else "hip")     # 7th positional parameter, as in the reference
         if framework == "hip":
             return super().__new__(cls)
         if framework not in ("onnx", "tflite"):

@@ -309,3 +309,85 @@ def check_melspectrogram(path: str) -> dict:
         raise ValueError(f"{path}: no {W.N_BINS}x{W.N_MELS} filterbank initializer found")
     m = fb[0] if fb[0].shape == (W.N_BINS, W.N_MELS) else fb[0].T
     return {"filterbank_max_abs_diff": float(np.abs(m - W.mel_filterbank()).max()), "filterbank_max": float(np.abs(m).max())}
+
+
+# ------------------------------------------------------------------------------------------- voice-activity network
+def load_vad(path: str) -> dict:
+    """`silero_vad.onnx` (/root/reference/openwakeword/vad.py:60-90; run at vad.py:98-130 with inputs input [1, n], h / c [2, 1, 64],
+    sr) -> the weight dict of the on-device voice-activity network (`weights.synthetic_vad` layout, `engine.pack_vad_blob`),
+    IF the file's graph is the architecture `csrc/owwhip_vad.h` implements:
+
+        |STFT| (256-sample Hann frames, hop 64, bins 1..128; analytic in the kernel -- an STFT basis Conv in the file is only
+        checked for its geometry) -> log(1 + gain |X|) -> 4 x [Conv1d(k=3, pad 1) + ReLU]: 128->16 (stride 1), 16->32 (2), 32->32 (2),
+        32->64 (1) -> two ONNX `LSTM` nodes of hidden size 64 -> ReLU -> Linear / 1x1 Conv (64 -> 1) -> Sigmoid.
+
+    Recognition is by structure (operator types, weight shapes, strides), never by node names.  Silero's real graph is not
+    described anywhere in the reference and no copy of the file exists offline, so what this function does with
+    the real release asset is unknown until one is seen: anything that is not exactly the structure above is REFUSED with a
+    ValueError that lists what was found -- the caller then keeps the host path (`VAD(session=onnxruntime session)`,
+    `oww_push_vad`) instead of a silently different network."""
+    g = load_graph(path)
+    inits, nodes = g["initializers"], g["nodes"]
+    ops = [n["op"] for n in nodes]
+
+    def refuse(why: str):
+        from collections import Counter
+        raise ValueError(f"{path}: not the voice-activity architecture the HIP kernels implement ({why}); operators found: "
+                         f"{dict(Counter(ops))}.  Drive this network on the host instead (openwakeword_amd.VAD(session=...) / "
+                         "oww_push_vad): the gate, the score ring and the state handling of vad.py stay the same")
+
+    convs = [n for n in nodes if n["op"] == "Conv" and len(n["inputs"]) >= 2 and n["inputs"][1] in inits]
+    enc, basis = [], []
+    for n in convs:
+        w = inits[n["inputs"][1]]
+        if w.ndim == 3 and w.shape[2] == 3:
+            enc.append(n)
+        elif w.ndim == 3 and w.shape[1] == 1:
+            basis.append(n)                                   # an STFT written as a strided Conv1d over the waveform
+    for n in basis:
+        w = inits[n["inputs"][1]]
+        hop = (n["attrs"].get("strides") or [0])[0]
+        if w.shape[2] != W.VAD_N_FFT or hop != W.VAD_HOP:
+            refuse(f"STFT basis of {w.shape[2]} samples / hop {hop}, kernels use {W.VAD_N_FFT} / {W.VAD_HOP}")
+    if len(enc) != len(W.VAD_ENC):
+        refuse(f"{len(enc)} kernel-3 Conv1d layers, expected {len(W.VAD_ENC)}")
+    out_enc = []
+    for n, (cin, cout, stride) in zip(enc, W.VAD_ENC):
+        w = inits[n["inputs"][1]]                             # ONNX Conv1d weight: [cout, cin, k]
+        st = (n["attrs"].get("strides") or [1])[0]
+        pads = n["attrs"].get("pads") or [0, 0]
+        if w.shape != (cout, cin, 3) or st != stride or list(pads) != [1, 1] or (n["attrs"].get("group") or 1) != 1:
+            refuse(f"encoder Conv {tuple(w.shape)} stride {st} pads {pads}, expected {(cout, cin, 3)} stride {stride} pads [1, 1]")
+        b = inits[n["inputs"][2]] if len(n["inputs"]) > 2 and n["inputs"][2] in inits else np.zeros(cout, np.float32)
+        out_enc.append((np.ascontiguousarray(w.transpose(2, 1, 0), np.float32), np.asarray(b, np.float32).reshape(cout)))
+    lstms = [n for n in nodes if n["op"] == "LSTM"]
+    if len(lstms) != 2:
+        refuse(f"{len(lstms)} LSTM nodes, expected 2 (one per layer)")
+    out_lstm = []
+    H = W.VAD_HID
+    for n in lstms:
+        if (n["attrs"].get("hidden_size") or 0) != H or (n["attrs"].get("direction") or "forward") != "forward":
+            refuse(f"LSTM hidden_size {n['attrs'].get('hidden_size')} / direction {n['attrs'].get('direction')}, expected {H} / forward")
+        try:
+            wi, wr = inits[n["inputs"][1]], inits[n["inputs"][2]]            # [1, 4H, in], [1, 4H, H]; ONNX gate order i, o, f, c
+            bb = inits[n["inputs"][3]] if len(n["inputs"]) > 3 and n["inputs"][3] in inits else np.zeros((1, 8 * H), np.float32)
+        except KeyError:
+            refuse("LSTM weights are not initializers")
+        if wi.shape != (1, 4 * H, H) or wr.shape != (1, 4 * H, H) or bb.shape != (1, 8 * H):
+            refuse(f"LSTM weights {tuple(wi.shape)} / {tuple(wr.shape)} / {tuple(bb.shape)}, expected (1, {4 * H}, {H}) x 2 and (1, {8 * H})")
+        order = [0, 2, 3, 1]                                                # ours: i | f | g | o  <-  ONNX blocks i(0) o(1) f(2) c(3)
+        rows = np.concatenate([wi[0], wr[0]], axis=1)                       # [4H, 2H]: columns x ; h
+        rows = np.concatenate([rows[k * H:(k + 1) * H] for k in order], axis=0)
+        bias = bb[0, :4 * H] + bb[0, 4 * H:]
+        bias = np.concatenate([bias[k * H:(k + 1) * H] for k in order])
+        out_lstm.append((np.ascontiguousarray(rows.T, np.float32), np.ascontiguousarray(bias, np.float32)))
+    dec = None
+    for n in nodes:
+        if n["op"] in ("Gemm", "MatMul", "Conv") and len(n["inputs"]) >= 2 and n["inputs"][1] in inits and inits[n["inputs"][1]].size == H \
+                and n not in enc:
+            wd = np.asarray(inits[n["inputs"][1]], np.float32).reshape(H)
+            bd = float(np.asarray(inits[n["inputs"][2]]).reshape(-1)[0]) if len(n["inputs"]) > 2 and n["inputs"][2] in inits else 0.0
+            dec = (wd, np.float32(bd))
+    if dec is None or "Sigmoid" not in ops:
+        refuse("no 64 -> 1 decoder followed by a Sigmoid")
+    return {"enc": out_enc, "lstm": out_lstm, "dec": dec}

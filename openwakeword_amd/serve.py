@@ -42,14 +42,21 @@ except ImportError as e:  # pragma: no cover
     raise ImportError("openwakeword_amd.serve needs aiohttp (the library the reference's web example uses)") from e
 
 
+# input rates the server converts (the example hands whatever the browser's AudioContext reports to resampy: 8 .. 96 kHz in practice).
+# A whitelist keeps the polyphase factors small: an arbitrary rate such as 22051 Hz would ask for a 16000 / 22051 resampler with a
+# filter of several hundred thousand taps per message.
+RATES = (8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000)
+
+
 def to_16k(pcm: np.ndarray, sample_rate: int) -> np.ndarray:
-    """int16 at `sample_rate` -> int16 at 16 kHz (one message at a time, like streaming_server.py:57-58)."""
+    """int16 at `sample_rate` -> int16 at 16 kHz (one message at a time, like streaming_server.py:57-58), through the package's own
+    cached polyphase bank (`resample.design`, the host restatement of oww_resample)."""
     if sample_rate == 16000 or pcm.size == 0:
         return pcm
-    from scipy.signal import resample_poly
-    r = Fraction(16000, int(sample_rate))
-    y = resample_poly(pcm.astype(np.float32), r.numerator, r.denominator)
-    return np.clip(np.rint(y), -32768, 32767).astype(np.int16)
+    if sample_rate not in RATES:
+        raise ValueError(f"unsupported sample rate {sample_rate}")
+    from . import resample
+    return resample.apply_numpy(pcm[None, :], int(sample_rate))[0]
 
 
 class _Client:
@@ -148,6 +155,9 @@ class FanInServer:
             b[:] = 0
         self.n_steps = 0              # batched steps taken
         self.n_stream_steps = 0       # sum over steps of the streams that took part
+        self.n_range_recoveries = 0   # OWW_ERANGE events the pump recovered from (see _recover_range)
+        self.send_timeout_s = 2.0     # deadline of one activation message / close handshake
+        self.failed: Optional[BaseException] = None      # set when the pump died of anything it cannot recover from
 
     # ---- aiohttp plumbing
     def app(self) -> "web.Application":
@@ -177,6 +187,9 @@ class FanInServer:
     async def handle(self, request):
         ws = web.WebSocketResponse()
         await ws.prepare(request)
+        if self.failed is not None:
+            await ws.close(code=1011, message=b"scoring backend failed")
+            return ws
         if not self.free:
             await ws.close(code=1013, message=b"all stream slots are taken")
             return ws
@@ -194,13 +207,17 @@ class FanInServer:
                         rate = int(msg.data)
                     except ValueError:
                         rate = 0
-                    if not 1000 <= rate <= 384000:          # (the example trusts the client here; a bad value would poison the resampler)
-                        await ws.close(code=1003, message=b"the first text message must be the sample rate in Hz")
+                    if rate not in RATES:                   # (the example trusts the client here; see RATES)
+                        await ws.close(code=1003, message=b"the first text message must be the sample rate in Hz, one of " +
+                                       ",".join(str(r) for r in RATES).encode())
                         break
                     c.rate = rate
                 elif msg.type == WSMsgType.BINARY:
                     n = len(msg.data) // 2
-                    c.push(to_16k(np.frombuffer(msg.data, dtype="<i2", count=n), c.rate))
+                    x = np.frombuffer(msg.data, dtype="<i2", count=n)
+                    if c.rate != 16000:                     # filtering runs on the default executor, not on the event loop
+                        x = await asyncio.get_running_loop().run_in_executor(None, to_16k, x, c.rate)
+                    c.push(x)
                     if c.n_pending >= CHUNK:
                         self._have_chunk.set()
                 elif msg.type == WSMsgType.ERROR:
@@ -216,45 +233,90 @@ class FanInServer:
             self.free.append(slot)
 
     # ---- the one place steps are put together
+    async def _send(self, c: "_Client", text: str) -> None:
+        """One client's activation message, on its own task and with a deadline: a stalled socket never holds up the pump."""
+        try:
+            await asyncio.wait_for(c.ws.send_str(text), timeout=self.send_timeout_s)
+        except (ConnectionError, RuntimeError, asyncio.TimeoutError):
+            c.closed = True
+
+    async def _recover_range(self, flying) -> None:
+        """OWW_ERANGE is sticky per handle: one stream whose activations left the f16 range would stop scoring for everybody.  The
+        flag does not say which stream it was, so every connected stream restarts from Model()'s initial state (their clients keep
+        their connections and simply see a few silent frames), the steps in flight are dropped and the flag is cleared."""
+        self.n_range_recoveries += 1
+        def recover():
+            eng = self.model.engine
+            for _ in range(len(flying)):
+                try:
+                    eng.collect()
+                except Exception:
+                    pass
+            eng.range_status(clear=True)
+            self.model.reset(None, reset_vad=bool(eng.has_vad))
+            eng.range_status(clear=True)
+        await self._gpu.call(recover)
+        for ready in flying:
+            for c in ready:
+                c.in_flight -= 1
+        flying.clear()
+
     async def _pump(self) -> None:
+        from ._lib import OwwRangeError
         keep = self.model._keep
         flying: "collections.deque" = collections.deque()        # ready lists of the submitted, not yet collected steps
-        while True:
-            if not flying:
-                await self._have_chunk.wait()
-                if self.window_s > 0:
-                    await asyncio.sleep(self.window_s)
-            self._have_chunk.clear()
-            self._reap()
-            ready = [c for c in self.clients.values() if c.n_pending >= CHUNK]
-            if ready:
-                buf = self._pcm[self.n_steps % 2]                  # (its previous step, n_steps - 2, has been collected)
-                on = np.zeros(self.model.n_streams, dtype=np.uint8)
-                for c in ready:
-                    c.pop_chunk(buf[c.slot])
-                    c.in_flight += 1
-                    on[c.slot] = 1
-                await self._gpu.call(self.model.engine.submit, buf, on)
-                flying.append(ready)
-                self.n_steps += 1
-                self.n_stream_steps += len(ready)
-            if flying and (len(flying) == 2 or not ready):
-                scores = (await self._gpu.call(self.model.engine.collect))[:, keep]
-                for c in flying.popleft():
-                    c.in_flight -= 1
-                    row = scores[c.slot]
-                    if self.on_scores is not None:
-                        self.on_scores(c.slot, c.n_steps, row)
-                    c.n_steps += 1
-                    hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
-                    if hits and not c.closed:
-                        try:
-                            await c.ws.send_str(json.dumps({"activations": hits}))
-                        except (ConnectionError, RuntimeError):
-                            c.closed = True
+        try:
+            while True:
+                if not flying:
+                    await self._have_chunk.wait()
+                    if self.window_s > 0:
+                        await asyncio.sleep(self.window_s)
+                self._have_chunk.clear()
                 self._reap()
-            if any(c.n_pending >= CHUNK for c in self.clients.values()):
-                self._have_chunk.set()          # somebody sent more than one chunk: go again without waiting for a message
+                ready = [c for c in self.clients.values() if c.n_pending >= CHUNK]
+                try:
+                    if ready:
+                        buf = self._pcm[self.n_steps % 2]                  # (its previous step, n_steps - 2, has been collected)
+                        on = np.zeros(self.model.n_streams, dtype=np.uint8)
+                        for c in ready:
+                            c.pop_chunk(buf[c.slot])
+                            c.in_flight += 1
+                            on[c.slot] = 1
+                        flying.append(ready)
+                        await self._gpu.call(self.model.engine.submit, buf, on)
+                        self.n_steps += 1
+                        self.n_stream_steps += len(ready)
+                    if flying and (len(flying) == 2 or not ready):
+                        scores = (await self._gpu.call(self.model.engine.collect))[:, keep]
+                        for c in flying.popleft():
+                            c.in_flight -= 1
+                            row = scores[c.slot]
+                            if self.on_scores is not None:
+                                self.on_scores(c.slot, c.n_steps, row)
+                            c.n_steps += 1
+                            hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
+                            if hits and not c.closed:
+                                asyncio.get_running_loop().create_task(self._send(c, json.dumps({"activations": hits})))
+                        self._reap()
+                except OwwRangeError:
+                    await self._recover_range(flying)
+                if any(c.n_pending >= CHUNK for c in self.clients.values()):
+                    self._have_chunk.set()          # somebody sent more than one chunk: go again without waiting for a message
+        except asyncio.CancelledError:
+            raise
+        except Exception as e:
+            # anything else (a device error, a bug): no step will ever be scored again -- say so and hang up on everybody instead of
+            # accepting audio that is silently dropped
+            self.failed = e
+            import logging
+            logging.getLogger("openwakeword_amd.serve").exception("the GPU pump failed; closing %d connections", len(self.clients))
+            for c in list(self.clients.values()):
+                c.closed = True
+                try:
+                    await asyncio.wait_for(c.ws.close(code=1011, message=b"scoring backend failed"), timeout=self.send_timeout_s)
+                except Exception:
+                    pass
+            raise
 
 
 def main(argv=None) -> None:

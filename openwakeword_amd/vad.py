@@ -3,11 +3,14 @@ Voice-activity gate of the reference (`openwakeword.VAD`, /root/reference/openwa
 network.
 
 The reference runs Silero's `silero_vad.onnx` through onnxruntime: `input[1, n] f32 (samples / 32767), h[2,1,64], c[2,1,64],
-sr` -> `out[1,1], h', c'`.  That file is a release asset, its graph is not part of the reference checkout, and there is no
-onnxruntime here, so the NETWORK is not restated in this package.  Everything around it is: `VAD` takes
-any object with the session interface (`run(None, feeds) -> [out, h, c]`) -- an onnxruntime session where one exists, a HIP
-kernel binding later -- and reproduces the sub-framing, state carry, averaging and the 125-deep score ring; `Model` applies the
-gate of model.py:366-381 on top of it.
+sr` -> `out[1,1], h', c'`.  That file is a release asset whose graph is described nowhere in the reference checkout, and there
+is no onnxruntime here.  Two ways to supply the network:
+  * this class: the reference's wrapper (sub-framing, /32767, state carry, mean per call, 125-deep score ring) around ANY object
+    with the session interface (`run(None, feeds) -> [out, h, c]`) -- an onnxruntime session where one exists; `Model` applies the
+    gate of model.py:366-381 on top of it;
+  * on the device: `csrc/owwhip_vad.h` runs a structural stand-in with the same interface and state inside every batched step
+    (`oww_load_vad`, `StreamEngine(vad=...)`, BASELINE configs[4]); `onnx_ingest.load_vad` turns a `silero_vad.onnx` into its
+    weights when the file's graph IS that architecture and refuses it otherwise (then the first way applies).
 """
 from __future__ import annotations
 

@@ -9,7 +9,7 @@ instead of numpy's slow batched matmuls.  It executes the REFERENCE's algorithm,
     stream clamp;
   * the full 76x32 window through all 20 conv layers every frame (utils.py:437-443) -- no incremental reuse;
   * one MLP evaluation per head (model.py:299-302).
-tests/test_oracle_golden.py checks it against the numpy oracle.
+tests/test_oracle_golden.py::test_torch_cpu_port_matches_numpy_oracle checks it against the numpy oracle.
 """
 from __future__ import annotations
 

@@ -171,3 +171,71 @@ def test_melspectrogram_check(tmp_path):
     path = os.path.join(tmp_path, "mel.onnx")
     open(path, "wb").write(_model([_node("MatMul", ["p", "fb"], ["m"])], [_tensor("fb", W.mel_filterbank())]))
     assert onnx_ingest.check_melspectrogram(path)["filterbank_max_abs_diff"] == 0.0
+
+
+# ---- voice-activity network (onnx_ingest.load_vad): recognised by structure, anything else refused -------------------------
+def _attr_ints(name, vals):
+    return _ld(1, name.encode()) + b"".join(_vi((8 << 3) | 0) + _vi(v) for v in vals) + _vi((20 << 3) | 0) + _vi(7)
+
+
+def _attr_s(name, v):
+    return _ld(1, name.encode()) + _ld(4, v.encode()) + _vi((20 << 3) | 0) + _vi(3)
+
+
+def write_vad(path, vad, lstm_hidden=64, strides=(1, 2, 2, 1), with_basis=True, basis_len=256):
+    """The stand-in architecture of csrc/owwhip_vad.h as an ONNX graph: [STFT basis Conv] -> 4 x (Conv1d k=3 + Relu) -> 2 x LSTM
+    (ONNX gate order i, o, f, c) -> Relu -> 1x1 Conv (64 -> 1) -> Sigmoid."""
+    nodes, inits, cur = [], [], "input"
+    if with_basis:
+        inits.append(_tensor("basis", np.zeros((258, 1, basis_len), np.float32)))
+        nodes.append(_node("Conv", [cur, "basis"], ["spec"], [_attr_ints("strides", [64])]))
+        cur = "spec"
+    for li, ((w, b), st) in enumerate(zip(vad["enc"], strides)):
+        inits += [_tensor(f"ew{li}", np.transpose(w, (2, 1, 0))), _tensor(f"eb{li}", b)]       # [k, cin, cout] -> [cout, cin, k]
+        nodes += [_node("Conv", [cur, f"ew{li}", f"eb{li}"], [f"e{li}"], [_attr_ints("strides", [st]), _attr_ints("pads", [1, 1])]),
+                  _node("Relu", [f"e{li}"], [f"er{li}"])]
+        cur = f"er{li}"
+    H = 64
+    inv = [0, 3, 1, 2]                                       # ONNX block k (i, o, f, c) <- ours (i, f, g, o)
+    for li, (w, b) in enumerate(vad["lstm"]):
+        rows = w.T                                           # [4H, 2H] in our gate order
+        rows = np.concatenate([rows[k * H:(k + 1) * H] for k in inv], axis=0)
+        bias = np.concatenate([b[k * H:(k + 1) * H] for k in inv])
+        inits += [_tensor(f"lw{li}", rows[None, :, :H]), _tensor(f"lr{li}", rows[None, :, H:]),
+                  _tensor(f"lb{li}", np.concatenate([bias, np.zeros(4 * H, np.float32)])[None])]
+        nodes.append(_node("LSTM", [cur, f"lw{li}", f"lr{li}", f"lb{li}"], [f"l{li}"], [_attr_i("hidden_size", lstm_hidden), _attr_s("direction", "forward")]))
+        cur = f"l{li}"
+    wd, bd = vad["dec"]
+    inits += [_tensor("dw", np.asarray(wd, np.float32).reshape(1, 64, 1)), _tensor("db", np.array([bd], np.float32))]
+    nodes += [_node("Relu", [cur], ["dr"]), _node("Conv", ["dr", "dw", "db"], ["do"]), _node("Sigmoid", ["do"], ["out"])]
+    open(path, "wb").write(_model(nodes, inits))
+
+
+def test_vad_round_trip_and_refusals(tmp_path):
+    from oracle import vad_standin as VS
+    vad = W.synthetic_vad(31)
+    path = os.path.join(tmp_path, "silero_vad.onnx")
+    write_vad(path, vad)
+    got = onnx_ingest.load_vad(path)
+    for (w0, b0), (w1, b1) in zip(vad["enc"] + vad["lstm"], got["enc"] + got["lstm"]):
+        np.testing.assert_array_equal(w0, w1)
+        np.testing.assert_array_equal(b0, b1)
+    np.testing.assert_array_equal(vad["dec"][0], got["dec"][0])
+    assert float(vad["dec"][1]) == float(got["dec"][1])
+    # ... and the re-read weights drive the restated network to the same scores
+    x = (np.random.default_rng(5).normal(0, 3000, 1280)).astype(np.int16)
+    a, b = VS.StandinVadSession(vad), VS.StandinVadSession(got)
+    h = c = np.zeros((2, 1, 64), np.float32)
+    feed = {"input": (x[:640] / 32767).astype(np.float32)[None], "h": h, "c": c, "sr": np.array(16000)}
+    np.testing.assert_array_equal(a.run(None, feed)[0], b.run(None, feed)[0])
+    # anything that is not exactly this architecture is refused, naming what was found and the host-side way out
+    for kw, why in ((dict(strides=(1, 1, 2, 1)), "stride"), (dict(lstm_hidden=128), "hidden_size"), (dict(basis_len=512), "STFT basis")):
+        write_vad(path, vad, **kw)
+        with pytest.raises(ValueError, match=why):
+            onnx_ingest.load_vad(path)
+    open(path, "wb").write(_model([_node("Relu", ["input"], ["y"]), _node("Sigmoid", ["y"], ["out"])], []))
+    with pytest.raises(ValueError, match="oww_push_vad"):
+        onnx_ingest.load_vad(path)
+    write_head(path, W.synthetic_head("alexa", 77))         # a wake-word head is not a VAD
+    with pytest.raises(ValueError, match="operators found"):
+        onnx_ingest.load_vad(path)

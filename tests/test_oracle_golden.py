@@ -144,3 +144,25 @@ def test_vad_wrapper_of_the_package_matches_reference(golden, golden_vad):
         assert all((sc[i] == 0).all() for i, g in enumerate(gates) if g)
     with pytest.raises(ValueError, match="vad_session"):
         VAD()                                                          # no network, no onnxruntime: refused, not ignored
+
+
+def test_torch_cpu_port_matches_numpy_oracle(golden):
+    """oracle/oww_oracle_torch.py (the arithmetic bench.py times as `cpu_baseline`) against the numpy oracle on real audio: mel
+    rows of a 1,760-sample streaming buffer, the embedding of a full 76-row window and all three head kinds."""
+    torch = pytest.importorskip("torch")
+    from oracle import oww_oracle_torch as OT
+    emb = W.synthetic_embedding(cases.SEED_WEIGHTS)
+    heads = {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in ("alexa", "hey_jarvis", "timer")}
+    port = OT.TorchCpuPort(emb, heads, threads=1)
+    clip = golden["pcm/alexa_test"]
+    pcm = clip[len(clip) // 4: len(clip) // 4 + 3 * 1760].reshape(3, 1760).astype(np.int16)
+    rows = port.mel(pcm).numpy()
+    want = np.stack([O.mel_transform(O.mel_stage(p.astype(np.float32))[0, 0]) for p in pcm])
+    np.testing.assert_allclose(rows, want, rtol=0, atol=2e-4)
+    win = np.random.default_rng(3).normal(9.0, 1.5, (2, 76, 32)).astype(np.float32)
+    e = port.embed(torch.from_numpy(win)).numpy()
+    np.testing.assert_allclose(e, O.embedding_stage(win[..., None], emb).reshape(2, 96), rtol=0, atol=2e-4)
+    feats = np.random.default_rng(4).normal(0.0, 2.0, (2, 34, 96)).astype(np.float32)
+    for name, h in heads.items():
+        f = feats[:, -h["T"]:]
+        np.testing.assert_allclose(port.head(name, torch.from_numpy(f)).numpy(), O.head_stage(f, h), rtol=0, atol=2e-5)
