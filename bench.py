@@ -49,7 +49,7 @@ PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
 # (round 2: the layers with a 72-channel input run K-merged -- 7 instead of 9 k-steps per output tile -- i.e. layers b, c, d of
 #  stage C: 810 instead of 990, and layer a of stage D: 306 instead of 324; layer a of stage C, 48 channels in, 5 instead of 6: 780)
 #  round 3: stage A's conv0 is one K-folded MFMA per output tile instead of three: 608 instead of 672)
-HX_MFMAS = {"stageA": 608, "stageB": 756, "stageC": 780, "stageD": 306, "stageE": 182}
+HX_MFMAS = {"stageA": 608, "stageB": 648, "stageC": 780, "stageD": 306, "stageE": 182}
 MEL_FLOPS = 100_000         # FFT form of the log-mel front end per stream-step, executed by the fused launch's VALU
 PEAK_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: peak engine clock; 256 CUs x 4 SIMDs
 N_SIMD = 1024

@@ -136,9 +136,12 @@ struct HxFold {
 // fp16-split operand order (owwhip_hx.h): blocks [oct][tap][ks][part hi/lo] of 64 lanes x 8 halves; lane (i, g), half q
 // <-> weight of the input channel in row 4g + q%4 of channel tile 2ks + q/4 and the output channel in row i of tile oct
 // (hx_row_channel)
-void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out, HxFold* fold = nullptr) {
+// rem2 (cin = odd number of FULL channel tiles, stage B's 48): the last k-step in the two-MFMA form of owh::split_dup -- its empty
+// half carries the same channels again: block part 0 = (wh | wh), part 1 = (wl | 0)
+void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& out, HxFold* fold = nullptr, bool rem2 = false) {
     HxFold dflt; if (!fold) fold = &dflt;
     const int ks_n = ((cin + 15) / 16 + 1) / 2, ncto = (cout + 15) / 16;
+    rem2 = rem2 && ((cin + 15) / 16) % 2 == 1 && cin % 16 == 0;
     std::vector<_Float16> hbuf((size_t)ncto * ntaps * ks_n * 2 * 64 * 8, (_Float16)0.f);
     for (int oct = 0; oct < ncto; ++oct)
         for (int tap = 0; tap < ntaps; ++tap)
@@ -146,14 +149,16 @@ void pack_hx(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                 for (int lane = 0; lane < 64; ++lane)
                     for (int q = 0; q < 8; ++q) {
                         const int i = lane & 15, g = lane >> 4;
-                        const int ci = 2 * ks + q / 4 < (cin + 15) / 16 ? hx_row_channel(2 * ks + q / 4, 4 * g + q % 4, cin) : -1;
+                        const bool dup = rem2 && ks == ks_n - 1 && q >= 4;            // the empty half of the remainder k-step
+                        const int ci = dup ? hx_row_channel(2 * ks, 4 * g + q % 4, cin) :
+                                       (2 * ks + q / 4 < (cin + 15) / 16 ? hx_row_channel(2 * ks + q / 4, 4 * g + q % 4, cin) : -1);
                         const int co = hx_row_channel(oct, i, cout);
                         if (ci < 0 || co < 0) continue;
                         _Float16 hi, lo;
                         fold->split(w[((size_t)tap * cin + ci) * cout + co], co, hi, lo);
                         const size_t blk = (((size_t)oct * ntaps + tap) * ks_n + ks) * 2;
                         hbuf[(blk * 64 + lane) * 8 + q] = hi;
-                        hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
+                        hbuf[((blk + 1) * 64 + lane) * 8 + q] = dup ? (_Float16)0.f : lo;
                     }
     out.assign(hbuf.size() / 2, 0.f);
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
@@ -1168,7 +1173,7 @@ int oww_commit(oww_ctx* h) {
                                          (OWH_KMERGE_MEL2B && l == 5));                                   // (l == 5: stage B layer c, A/B switch)
                 if (l == 0) pack_hx_conv0(q, pk, &fold);
                 else if (time_merged || mel_merged) pack_hx_tm(q, L.cin, L.cout, pk, &fold);
-                else pack_hx(q, 3, L.cin, L.cout, pk, &fold);
+                else pack_hx(q, 3, L.cin, L.cout, pk, &fold, OWH_REM2 && !OWH_KMERGE_B && !OWH_KMERGE_MEL2B && l >= 4 && l <= 6);     // (stage B layers b, c, d)
                 if (!(fold.absmax < 65000.0))
                     return fail(OWW_ERANGE, "conv layer %d: folded weight magnitude %.3g (BatchNorm scale x weight x activation-scale ratio 2^%d) is outside "
                                 "the f16 range of the fp16-split kernels (use_mfma = 3); use use_mfma = 1", l, fold.absmax, de);

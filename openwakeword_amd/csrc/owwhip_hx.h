@@ -148,16 +148,45 @@ __device__ __forceinline__ Op split_some(const f32x4 a, const f32x4 b) {
     return o;
 }
 
+// A k-step that carries ONE full channel tile (an odd last tile of 16 channels: 48 = 32 + 16) leaves half of its 32 k-slots empty.
+// The REM2 form uses them for the f16 split itself: the operand pair becomes
+//      .l = (xh pairs 0, 1 | xl pairs 0, 1)      against weights (wh | wh):  xh wh + xl wh
+//      .h = (xh pairs 0, 1 |  0,  0)             against weights (wl | 0):   xh wl
+// i.e. two MFMAs for that k-step instead of three (pack_hx(..., rem2) packs the weight blocks accordingly).  Stage B: 5 instead of 6
+// MFMAs per tap, output tile and position tile in its three 48-channel-input layers (756 -> 648 per stream-step).
+#ifndef OWH_REM2
+#define OWH_REM2 1
+#endif
+__device__ __forceinline__ Op split_dup(const f32x4 a) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned hp[2], lp[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const float x0 = a[2 * v], x1 = a[2 * v + 1];
+        hp[v] = __builtin_bit_cast(unsigned, f16x2{(_Float16)x0, (_Float16)x1});
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(lp[v]) : "v"(hp[v]), "v"(x0), "v"(x1));
+    }
+    Op o;
+    o.h = __builtin_bit_cast(f16x8, u32x4{hp[0], hp[1], 0u, 0u});
+    o.l = __builtin_bit_cast(f16x8, u32x4{hp[0], hp[1], lp[0], lp[1]});
+    return o;
+}
+
 // operand form of a whole fp32 tile (NCT channel tiles -> KS = ceil(NCT/2) k-steps; an odd last tile pairs with zeros).
-// HALF: the last channel tile is a half tile (8 channels in its registers 0, 1).
-template <int NCT, bool HALF = false>
+// HALF: the last channel tile is a half tile (8 channels in its registers 0, 1).  REM2: see split_dup.
+template <int NCT, bool HALF = false, bool REM2 = false>
 __device__ __forceinline__ void to_ops(const f32x4 (&t)[NCT], Op (&o)[(NCT + 1) / 2]) {
     constexpr int KS = (NCT + 1) / 2;
     constexpr int NP_LAST = (NCT % 2 ? 2 : 4) - (HALF ? 1 : 0);       // valid pairs of the last k-step
+    static_assert(!REM2 || (NCT % 2 == 1 && !HALF), "REM2: an odd, full last channel tile");
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
         const f32x4 b = 2 * k + 1 < NCT ? t[2 * k + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (k == KS - 1 && NP_LAST < 4) o[k] = split_some<NP_LAST>(t[2 * k], b);
+        if (REM2 && k == KS - 1) o[k] = split_dup(t[2 * k]);
+        else if (k == KS - 1 && NP_LAST < 4) o[k] = split_some<NP_LAST>(t[2 * k], b);
         else o[k] = split_pair(t[2 * k], b);
         pin_op(o[k]);
     }
@@ -278,19 +307,11 @@ using HC = owr::RCfg<48, 72, 4, 8, 2, 2, OWH_RC_RP, OWH_WPS_C>;
 using HD = owr::RCfg<72, 96, 2, 4, 1, 2, 2, OWH_WPS_D>;
 using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
-#ifndef OWH_OCT_SCHEDBAR
-#define OWH_OCT_SCHEDBAR 0     // a scheduling barrier after every output tile: C +1.6 %, D / E +0.5 % slower with it (and 12 bytes of scratch in C)
-#endif
-#if OWH_OCT_SCHEDBAR
-#define OWH_OCT_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define OWH_OCT_SB() do {} while (0)
-#endif
 #define OWH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
 // chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
 // 1x3 (mel) layer: NT tiles in operand form -> NT fp32 D tiles (BatchNorm + activation applied)
-template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, bool REM2 = false>
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ init, float cl, int wave, int lane,
@@ -332,6 +353,13 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
             for (int ks = 0; ks < KSI; ++ks) {
                 const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
                 const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                if (REM2 && ks == KSI - 1) {                      // blocks (wh | wh), (wl | 0) against (xh | xl), (xh | 0): see split_dup
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, in[t][ks].l, acc[t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(al, in[t][ks].h, acc[t]);
+                    continue;
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, in[t][ks].h, acc[t]);
 #pragma unroll
@@ -363,7 +391,6 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
             if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
             else { out[t][oct] = act_t<BN, false>(res[t], cl); pin_t<false>(out[t][oct]); }
         }
-        OWH_OCT_SB();
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
     }
 }
@@ -475,7 +502,6 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
             if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
             else { out[t][oct] = act_t<BN, false>(res[t], cl); pin_t<false>(out[t][oct]); }
         }
-        OWH_OCT_SB();
         if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
     }
 }
@@ -490,7 +516,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #ifndef OWH_PIPE_VALU
 #define OWH_PIPE_VALU 2
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0, bool REM2 = false>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
@@ -516,14 +542,16 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
                 for (int ks = 0; ks < KSI; ++ks) {
                     const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
                     const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                    const bool rem = REM2 && ks == KSI - 1;       // two MFMAs: (wh | wh) x (xh | xl), (wl | 0) x (xh | 0)
 #pragma unroll
-                    for (int part = 0; part < 3; ++part)
+                    for (int part = 0; part < (rem ? 2 : 3); ++part)
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
                             const int src = r + tap;
                             const int ri = src >= 2 ? src - 2 : 0;
                             const Op& b = src == 0 ? h0[ks] : (src == 1 ? h1[ks] : in[ri][ks]);
-                            acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[r]);
+                            if (rem) acc[r] = OWH_MFMA(part == 0 ? ah : al, part == 0 ? b.l : b.h, acc[r]);
+                            else acc[r] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[r]);
                         }
                 }
         }
@@ -544,7 +572,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
         }
         if (PIPE && oct > 0 && oct < NCTO) {
 #pragma unroll
-            for (int i = 0; i < 9 * KSI * NR; ++i) {
+            for (int i = 0; i < (9 * KSI - (REM2 ? 3 : 0)) * NR; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, OWH_PIPE_VALU, 0);
             }
@@ -552,8 +580,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
         if (oct < NCTO) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) prev[r] = acc[r];
-            OWH_OCT_SB();
-            if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+                if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
         }
     }
 }
@@ -687,8 +714,7 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
         if (oct < NCTO) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) prev[r] = acc[r];
-            OWH_OCT_SB();
-            if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+                if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
         }
     }
 }
@@ -696,6 +722,9 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
 // ------------------------------------------------------------------------------------------------
 // stages B..E (parameters, geometry and memory layouts: owr::RStageParams / owr::RCfg, channel tiles NOT re-packed)
 // ------------------------------------------------------------------------------------------------
+#ifndef OWH_KMERGE_MEL2B
+#define OWH_KMERGE_MEL2B 0     // layer c of stage B (48 -> 48) in the same form: see DESIGN.md 5.2 for the measurement
+#endif
 template <class C, bool LAST, bool DBG, int WG = OWH_WG>
 __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
@@ -708,13 +737,12 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
     constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
     constexpr bool PIPE = OWH_PIPE != 0;
+    // a full odd last channel tile (stage B: 48 = 32 + 16) in the two-MFMA remainder form of split_dup
+    constexpr bool REM2 = OWH_REM2 && NCT % 2 == 1 && !C::HOUT && !LAST && !(OWH_KMERGE && OWH_KMERGE_B) && !(OWH_KMERGE_MEL && OWH_KMERGE_MEL2B);
     // 1x3 layers whose 72-channel input leaves a half remainder tile, in the K-merged form (conv_mel_hxm): layer a of stage D, c of C
     constexpr bool MMA2 = OWH_KMERGE_MEL && OWH_KMERGE_MEL2 && kInterleave && !C::HIN && NCTI % 2 == 1 && NCTI >= 3 && C::WPS == 2;   // C layer a (48 in)
     constexpr bool MMA = (OWH_KMERGE_MEL && kInterleave && C::HIN && NCTI % 2 == 1 && NCTI >= 3) || MMA2;
     constexpr int NPRA = MMA2 ? 2 : 1, NMKA = (3 * NPRA + 3) / 4;
-#ifndef OWH_KMERGE_MEL2B
-#define OWH_KMERGE_MEL2B 0     // layer c of stage B (48 -> 48) in the same form: see DESIGN.md 5.2 for the measurement
-#endif
     constexpr bool MMC2 = OWH_KMERGE_MEL && OWH_KMERGE_MEL2B && !C::HOUT && NCT % 2 == 1 && NCT >= 3 && !LAST;      // B layer c
     constexpr bool MMC = (OWH_KMERGE_MEL && kInterleave && C::HOUT && NCT % 2 == 1 && NCT >= 3) || MMC2;
     constexpr int NPRC = MMC2 ? 2 : 1, NMKC = (3 * NPRC + 3) / 4;
@@ -727,9 +755,6 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
     lanemask_t bad = 0;
-#ifdef OWH_SETPRIO
-    if (wave & 1) __builtin_amdgcn_s_setprio(OWH_SETPRIO);        // (A/B: static priority for half the waves of a SIMD)
-#endif
     issue_chunk<NBAM, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
@@ -791,25 +816,25 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         f32x4 T0[NCT], T1[NCT];
         load_tile_h<NCT, C::HOUT>(T0, hb, lane);
         load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane);
-        to_ops<NCT, C::HOUT>(T0, H0);
-        to_ops<NCT, C::HOUT>(T1, H1);
+        to_ops<NCT, C::HOUT, REM2>(T0, H0);
+        to_ops<NCT, C::HOUT, REM2>(T1, H1);
     }
     if (lane_on) {
         store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
         store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
+    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[1], s_first, pass * R + r, p.S, lane, p.dbg_mul[1]);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
+    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv c: 1x3
     if constexpr (MMC) {
@@ -817,7 +842,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
         conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     } else
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
@@ -847,18 +872,18 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         f32x4 T0[NCT], T1[NCT];
         load_tile_h<NCT, C::HOUT>(T0, hd, lane);
         load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane);
-        to_ops<NCT, C::HOUT>(T0, H0);
-        to_ops<NCT, C::HOUT>(T1, H1);
+        to_ops<NCT, C::HOUT, REM2>(T0, H0);
+        to_ops<NCT, C::HOUT, REM2>(T1, H1);
     }
     if (lane_on) {
         store_tile_h<NCT, C::HOUT>(Y[R - 2], hd, lane);
         store_tile_h<NCT, C::HOUT>(Y[R - 1], hd + NCT * 4 * 64, lane);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT>(Y[r], Ao[r]);
+    for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
