@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OWW_ABI_VERSION 3
+#define OWW_ABI_VERSION 4
 
 #define OWW_OK            0
 #define OWW_EINVAL       -1   /* bad argument */
@@ -182,6 +182,25 @@ int  oww_get_raw(oww_ctx* h, float* out);
  * device.  Stateless per call, like the example; asynchronous when out is a device pointer. */
 int  oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, int32_t p, int32_t q, const float* taps, int32_t n_taps,
                   int16_t* out, int out_on_device, int32_t n_out);
+
+/* ---- multi-GPU: delivery of the scores to one rank over RCCL (xGMI), for binders without torch.distributed ----------------------
+ * Streams are independent, so N GPUs = N handles in N processes, each owning a contiguous range of the global streams (the
+ * reference's only scale-out, utils.py:502-536 bulk_predict, splits FILES over processes the same way); nothing in the data path
+ * crosses GPUs.  The one exchange is handing the per-stream scores to whoever consumes them:
+ *   oww_comm_id       rank 0: fills id[OWW_COMM_ID_BYTES] (ncclGetUniqueId); the binder ships these bytes to the other ranks by
+ *                     whatever side channel it has (a file, a socket, an environment variable, MPI)
+ *   oww_comm_init     every rank, collectively: joins the communicator (ncclCommInitRank) on the handle's device
+ *   oww_gather_scores enqueued on the handle's stream after a step: every rank sends its fp32 [S_r][n_labels] scores to rank 0,
+ *                     which receives them at out + sum(counts[0..r)) * n_labels (device pointer; counts[r] = streams of rank r, the
+ *                     same array on every rank).  One grouped ncclSend / ncclRecv exchange; asynchronous (oww_sync to wait).
+ *   oww_comm_destroy  leaves the communicator (oww_destroy does it too)
+ * librccl.so is bound at run time by the first of these calls; a process that already holds a copy (e.g. torch's) shares it.
+ * Python: openwakeword_amd.shard.ScoreGather is the torch.distributed form of the same exchange. */
+#define OWW_COMM_ID_BYTES 128
+int  oww_comm_id(void* id);
+int  oww_comm_init(oww_ctx* h, const void* id, int32_t rank, int32_t world);
+int  oww_gather_scores(oww_ctx* h, float* out, const int32_t* counts);
+int  oww_comm_destroy(oww_ctx* h);
 
 /* ---- stage-level entry points (the reference's per-stage closures; used for parity tests and for
  *      AudioFeatures._get_melspectrogram / embed_clips style callers).  Host pointers. ---------------

@@ -8,7 +8,7 @@ import os
 from . import _build
 
 _lib = None
-ABI_VERSION = 3          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
+ABI_VERSION = 4          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
 ERANGE = -5
 
 
@@ -66,6 +66,10 @@ SYMBOLS = {
     "oww_enable_timing": (C.c_int, [_P, C.c_int]),
     "oww_kernel_times": (C.c_int, [_P, _P, _P]),
     "oww_use_graph": (C.c_int, [_P, C.c_int]),
+    "oww_comm_id": (C.c_int, [_P]),
+    "oww_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "oww_gather_scores": (C.c_int, [_P, _P, _P]),
+    "oww_comm_destroy": (C.c_int, [_P]),
 }
 
 

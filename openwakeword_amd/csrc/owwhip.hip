@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -368,6 +369,8 @@ struct oww_ctx {
     int *d_patience = nullptr;
     float* d_threshold = nullptr;
     int debounce_frames = 0;
+    // RCCL communicator of oww_comm_init (multi-GPU delivery of results without Python)
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     // timing
     bool timing = false;
     std::vector<EventRec> ev;
@@ -683,6 +686,50 @@ int dalloc(T** p, size_t n, bool zero = true) {
     return 0;
 }
 
+// ---- RCCL (librccl.so: ncclSend / ncclRecv over xGMI), bound at run time: the library is only needed by callers that shard streams
+//      over GPUs WITHOUT torch.distributed (oww_comm_init / oww_gather_scores); nothing else in libowwhip touches it
+struct RcclId { char b[128]; };           // ncclUniqueId (passed BY VALUE to ncclCommInitRank)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void* lib = nullptr;
+    // a copy the process already holds (torch bundles one) wins: two RCCL instances in one process is asking for trouble
+    for (const char* name : {"librccl.so.1", "librccl.so"}) if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(OWW_ESTATE, "librccl.so could not be loaded: %s", dlerror());
+    Rccl r; r.lib = lib;
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(lib, n); ok = ok && p != nullptr; return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) return fail(OWW_ESTATE, "librccl.so lacks one of ncclGetUniqueId / ncclCommInitRank / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    g_rccl = r;
+    return 0;
+}
+#define RCCLCHK(expr)                                                                                         \
+    do {                                                                                                      \
+        int e__ = (expr);                                                                                     \
+        if (e__ != 0) return fail(OWW_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(e__) : "?"); \
+    } while (0)
+void comm_release(oww_ctx* h);
+
 void free_all(oww_ctx* h) {
     auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     fr(h->d_w); fr(h->d_allnets); fr(h->d_generic); fr(h->d_scratch);
@@ -708,6 +755,7 @@ void free_all(oww_ctx* h) {
     h->ev.clear();
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    comm_release(h);
 }
 
 // one chunk of the streaming step on device-resident mel rows
@@ -985,6 +1033,11 @@ int selftest_hx(oww_ctx* h, const HxCalib& cal) {
                     "use_mfma = 1", (double)err, (double)ref, (double)serr, (double)tol);
     }
     return 0;
+}
+
+void comm_release(oww_ctx* h) {
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
 }
 
 }  // namespace
@@ -2043,6 +2096,65 @@ int oww_use_graph(oww_ctx* h, int on) {
     if (!h) return fail(OWW_EINVAL, "null handle");
     h->want_graph = on != 0;
     if (!on && h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    return OWW_OK;
+}
+
+// ---- multi-GPU delivery of results over RCCL, without torch.distributed -----------------------------------------------------------
+int oww_comm_id(void* id) {
+    if (!id) return fail(OWW_EINVAL, "oww_comm_id: null argument");
+    if (int rc = rccl_load()) return rc;
+    RCCLCHK(g_rccl.GetUniqueId(id));
+    return OWW_OK;
+}
+
+int oww_comm_init(oww_ctx* h, const void* id, int32_t rank, int32_t world) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_comm_init: handle not committed");
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(OWW_EINVAL, "oww_comm_init: bad argument (rank %d of %d)", rank, world);
+    if (h->comm) return fail(OWW_ESTATE, "oww_comm_init: the handle already has a communicator");
+    if (int rc = rccl_load()) return rc;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    RcclId uid;
+    memcpy(uid.b, id, sizeof uid.b);
+    void* comm = nullptr;
+    RCCLCHK(g_rccl.CommInitRank(&comm, world, uid, rank));
+    h->comm = comm; h->comm_rank = rank; h->comm_world = world;
+    return OWW_OK;
+}
+
+int oww_gather_scores(oww_ctx* h, float* out, const int32_t* counts) {
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_gather_scores: handle not committed");
+    if (!h->comm) return fail(OWW_ESTATE, "oww_gather_scores: call oww_comm_init first");
+    if (!counts) return fail(OWW_EINVAL, "oww_gather_scores: counts is null");
+    if (counts[h->comm_rank] != h->S) return fail(OWW_EINVAL, "oww_gather_scores: counts[%d] = %d, this handle owns %d streams", h->comm_rank, counts[h->comm_rank], h->S);
+    if (h->comm_rank == 0 && !out) return fail(OWW_EINVAL, "oww_gather_scores: rank 0 needs the output buffer");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t NL = (size_t)h->NL;
+    if (NL == 0) return OWW_OK;
+    // one grouped exchange on the handle's stream (ordered after the step that produced d_scores): every rank sends its [S_r][NL]
+    // block to rank 0 -- rank 0 to itself as well, so the path is the same RCCL kernel at any world size
+    RCCLCHK(g_rccl.GroupStart());
+    int rc_send = g_rccl.Send(h->d_scores, (size_t)h->S * NL, 7 /* ncclFloat32 */, 0, h->comm, h->stream);
+    int rc_recv = 0;
+    if (h->comm_rank == 0) {
+        size_t off = 0;
+        for (int r = 0; r < h->comm_world && !rc_recv; ++r) {
+            if (counts[r] < 0) { rc_recv = -1; break; }
+            if (counts[r] > 0) rc_recv = g_rccl.Recv(out + off, (size_t)counts[r] * NL, 7, r, h->comm, h->stream);
+            off += (size_t)counts[r] * NL;
+        }
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc_send) RCCLCHK(rc_send);
+    if (rc_recv < 0) return fail(OWW_EINVAL, "oww_gather_scores: negative count");
+    if (rc_recv) RCCLCHK(rc_recv);
+    RCCLCHK(rc_end);
+    return OWW_OK;
+}
+
+int oww_comm_destroy(oww_ctx* h) {
+    if (!h) return OWW_OK;
+    if (h->comm) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->stream); }
+    comm_release(h);
     return OWW_OK;
 }
 

@@ -467,5 +467,26 @@ class StreamEngine:
         _lib.check(self._lib.oww_kernel_times(self._h, ms, n))
         return {KERNEL_CLASSES[i]: {"ms": ms[i], "launches": int(n[i])} for i in range(k)}
 
+    # ---- multi-GPU delivery of the scores over RCCL without torch.distributed (include/owwhip.h: oww_comm_*)
+    @staticmethod
+    def comm_id() -> bytes:
+        """Rank 0: the 128 bytes every rank passes to comm_init (ncclGetUniqueId); ship them by any side channel."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().oww_comm_id(buf))
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int) -> None:
+        if len(comm_id) != 128:
+            raise ValueError("comm_id must be the 128 bytes of StreamEngine.comm_id()")
+        _lib.check(self._lib.oww_comm_init(self._h, C.c_char_p(comm_id), int(rank), int(world)))
+
+    def gather_scores(self, out_dev_ptr: int, counts: Sequence[int]) -> None:
+        """Enqueue the gather of every rank's [S_r, n_labels] scores to rank 0's device buffer `out_dev_ptr` (asynchronous)."""
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        _lib.check(self._lib.oww_gather_scores(self._h, C.c_void_p(int(out_dev_ptr)), _ptr(c)))
+
+    def comm_destroy(self) -> None:
+        _lib.check(self._lib.oww_comm_destroy(self._h))
+
     def use_graph(self, on: bool = True):
         _lib.check(self._lib.oww_use_graph(self._h, int(on)))
