@@ -233,6 +233,41 @@ def quick_config(torch, dev, stream, S, head_names, steps, warmup, vad=False, ho
         eng.close()
 
 
+def masked_leg(torch, dev, stream, S, head_names):
+    """oww_step_masked at 10 % / 50 % / 100 % participation (random streams, mask on the host, PCM resident in HBM): the serving
+    edge's step for the connections that have a full chunk (examples/web/streaming_server.py:49-66)."""
+    from openwakeword_amd import weights as W
+    from openwakeword_amd.engine import StreamEngine
+    heads = {n: W.synthetic_head(n, 1234) for n in head_names}
+    eng = StreamEngine(S, heads, W.synthetic_embedding(1234), device=dev.index, use_mfma=3, hip_stream=stream.cuda_stream)
+    try:
+        eng.reset()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xA11CE + 23)
+        pool = make_pcm_pool(torch, dev, S, 2, "noise", gen, 0)
+        scores = torch.zeros(S, eng.n_labels, device=dev, dtype=torch.float32)
+        rng = np.random.default_rng(17)
+        out = {}
+        for frac in (0.1, 0.5, 1.0):
+            masks = [(rng.random(S) < frac).astype(np.uint8) for _ in range(4)]
+            for i in range(5):
+                eng.step_masked_device(pool[i % 2].data_ptr(), masks[i % 4], scores.data_ptr())
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            n = 20
+            for i in range(n):
+                eng.step_masked_device(pool[i % 2].data_ptr(), masks[i % 4], scores.data_ptr())
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            out[f"participation_{int(frac * 100)}pct"] = {"ms_per_step": round(1e3 * dt / n, 4), "stream_steps_per_s": round(sum(int(m.sum()) for m in masks) / 4 * n / dt, 1)}
+        out["streams"] = S
+        out["scores_valid"] = bool(torch.isfinite(scores).all().item()) and not eng.range_status()
+        out["note"] = "host-side list building included; <= 50 % participation launches only the stage groups that hold a participating stream"
+        return out
+    finally:
+        eng.close()
+
+
 def leg_resident_1m(args):
     """Child-process leg: 1,048,576 streams resident in one handle on one GPU (north star: >= 1 M concurrent streams on a
     node; this shows the whole million also FITS one GPU and what a step of it costs)."""
@@ -469,6 +504,7 @@ def main():
                     "c2_65536x3": quick_config(torch, dev, stream, 65536, head_names, 50, 10),
                 }
                 extras["vad_fused"] = quick_config(torch, dev, stream, S, head_names, 20, 5, vad=True)
+                extras["masked_step"] = masked_leg(torch, dev, stream, S, head_names)
                 extras["host_pcm"] = dict(quick_config(torch, dev, stream, S, head_names, 20, 5, host=True),
                                           note="PCIe-inclusive (pinned host PCM in, scores out, two steps in flight): never the headline value")
             except Exception as e:

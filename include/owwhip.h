@@ -140,8 +140,10 @@ int  oww_sync(oww_ctx* h);
  * stream sits the step out: none of its state moves (sample tail, conv histories, feature and score rings, frame counters,
  * VAD state) and its row of `scores` repeats its previous step's values; its 1280 PCM samples are not read.  A stream
  * stepped k times through any interleaving of masked steps is in the state k plain steps leave it in, bit for bit.
- * A masked step costs what a full step costs (streams share position tiles and the weight stream: those sitting out are computed
- * and not stored).  Default kernel family only (use_mfma = 3 with the fused front end); OWW_EINVAL otherwise. */
+ * Cost: with a HOST mask of which at most half the streams take part, only the stage groups (1 / 2 / 4 / 8 streams of a wave) that
+ * hold a participating stream are launched and the heads run on the participants alone, so the step costs roughly in proportion to
+ * the participation (streams sharing a group with a participant are computed and not stored); a device-resident mask, or more than
+ * half of the streams, runs the full launches.  Default kernel family only (use_mfma = 3 with the fused front end); OWW_EINVAL otherwise. */
 int  oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uint8_t* stream_on, int stream_on_on_device,
                      float* scores, int scores_on_device);
 /* Range guard of the default kernel family (use_mfma = 3 evaluates every fp32 product as three f16 MFMAs on hi/lo-split

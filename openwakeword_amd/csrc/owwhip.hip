@@ -348,6 +348,11 @@ struct oww_ctx {
     std::vector<float> rs_taps;                    // the padded filter bank of the last oww_resample call (upload source)
     uint8_t* d_on = nullptr;         // oww_step_masked: [Spad] participation mask of the step being launched (pad streams 0)
     const uint8_t* on_now = nullptr; // = d_on (or the caller's device mask) while a masked step is being launched, else nullptr
+    // masked step with few participants (host-resident mask, <= half of the streams): lists of the participating streams and of the
+    // stage groups (2 / 4 / 8 / 16 streams) that hold one; the launches of stages B..E, the heads and the VAD LSTM then cover only
+    // those (build_active_lists).  [0] = stream ids (stage B's groups and the heads' positions), [1] C, [2] D, [3] E, [4] VAD LSTM
+    int* d_lists = nullptr; int* h_lists[2] = {nullptr, nullptr}; hipEvent_t lists_ev[2] = {nullptr, nullptr}; size_t lists_cap = 0; unsigned lists_turn = 0;
+    const int* gl_now[5] = {}; int gn_now[5] = {}; bool lists_now = false;
     int k_last = 1;                  // n_chunks of the last step (row stride of d_mel)
     // f16-split family: the output of layer l is carried multiplied by 2^hx_e[l], its input arrives multiplied by 2^hx_ein[l]
     // (oww_commit: calibrate_hx; owwhip_hx.h act1).  Inside a stage hx_ein[l] = hx_e[l - 1]; the pooled hand-over between two stages
@@ -526,6 +531,10 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         p.range_flag = HX ? h->d_range : nullptr;
         p.stream_on = h->on_now;
+        if (HX && h->lists_now) {                                   // spt 1, 2, 4, 8 -> list 0, 1, 2, 3
+            const int k = spt == 1 ? 0 : spt == 2 ? 1 : spt == 4 ? 2 : 3;
+            p.glist = h->gl_now[k]; p.n_groups = h->gn_now[k];
+        }
     };
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
@@ -597,6 +606,8 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 q.feat = base.feat; q.ext = base.ext; q.TR = base.TR; q.T = g.T; q.nfeat = base.nfeat; q.w1hx = g.d_w1hx;
                 q.raw = raw_out; q.NL = h->NL; q.S = n_active; q.accumulate_max = base.accumulate_max;
                 q.range_flag = h->d_range; q.stream_on = h->on_now;
+                if (h->lists_now && !ext) { q.ids = h->gl_now[0]; q.n_ids = h->gn_now[0]; }
+                const int n_pos = q.ids ? q.n_ids : n_active;
                 if (h->post_in_heads_now) {
                     owh::HeadHxPost& pp = q.post;
                     pp.enabled = 1; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred; pp.nfeat = h->d_nfeat;
@@ -610,7 +621,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                     o.w2hx = g.d_w2hx[i]; o.b1 = d.b1; o.ln1g = d.ln1g; o.ln1b = d.ln1b; o.b2 = d.b2; o.ln2g = d.ln2g; o.ln2b = d.ln2b;
                     o.w3 = d.w3; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
                 }
-                const dim3 grid((n_active + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
+                const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
                 const int lds = owh::HX_NBUF * g.n_nets * 8 * 1024;
                 switch (g.n_nets) {
                     case 1: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;
@@ -740,6 +751,12 @@ void free_all(oww_ctx* h) {
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
     if (h->d_on) { (void)hipFree(h->d_on); h->d_on = nullptr; }
+    if (h->d_lists) { (void)hipFree(h->d_lists); h->d_lists = nullptr; }
+    for (int i = 0; i < 2; ++i) {
+        if (h->h_lists[i]) { (void)hipHostFree(h->h_lists[i]); h->h_lists[i] = nullptr; }
+        if (h->lists_ev[i]) { (void)hipEventDestroy(h->lists_ev[i]); h->lists_ev[i] = nullptr; }
+    }
+    h->lists_cap = 0;
     if (h->d_rs) { (void)hipFree(h->d_rs); h->d_rs = nullptr; h->rs_bytes = 0; }
     if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
     for (auto& sl : h->slot) {
@@ -792,11 +809,82 @@ int launch_vad(oww_ctx* h, const int16_t* d_pcm, int n_samples) {
         owv::VadLstmParams p{};
         p.xin = h->d_vadx; p.hc = h->d_vadhc; p.w = h->d_vad_lstmw; p.bias = h->d_vad_lstmb; p.wd = h->d_vad_wd; p.bd = h->vad_bd;
         p.ring = h->d_vadring; p.n_vad = h->d_nvad; p.last = h->d_vadlast; p.S = h->S; p.n_groups = G; p.stream_on = h->on_now;
+        if (h->lists_now) { p.glist = h->gl_now[4]; p.n_groups = h->gn_now[4]; }
         Timed t(h, 9);
-        hipLaunchKernelGGL(owv::vad_lstm_kernel, dim3((G + owv::L_WG - 1) / owv::L_WG), dim3(64 * owv::L_WG), 0, h->stream, p);
+        hipLaunchKernelGGL(owv::vad_lstm_kernel, dim3((p.n_groups + owv::L_WG - 1) / owv::L_WG), dim3(64 * owv::L_WG), 0, h->stream, p);
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// Lists for a masked step with few participants: [stream ids | C groups | D groups | E groups | VAD groups] into one pinned staging
+// buffer, copied to the device on the compute stream (ordered before the step's kernels).  Returns the number of participants, or -1
+// when the dense launches should be used (more than half of the streams take part).
+int build_active_lists(oww_ctx* h, const uint8_t* on) {
+    const int S = h->S;
+    int n_act = 0;
+    for (int s = 0; s < S; ++s) n_act += on[s] != 0;          // (vectorised by the compiler)
+    if (n_act * 2 > S) return -1;
+    const size_t need = (size_t)S + S / 2 + S / 4 + S / 8 + S / 16 + 64;       // (regions of the five lists, see below)
+    if (need > h->lists_cap) {
+        if (h->d_lists) (void)hipFree(h->d_lists);
+        h->d_lists = nullptr;
+        for (int i = 0; i < 2; ++i) {
+            if (h->lists_ev[i]) (void)hipEventSynchronize(h->lists_ev[i]);
+            if (h->h_lists[i]) { (void)hipHostFree(h->h_lists[i]); h->h_lists[i] = nullptr; }
+        }
+        h->lists_cap = 0;
+        if (hipMalloc(&h->d_lists, need * sizeof(int)) != hipSuccess) { fail(OWW_ENOMEM, "oww_step_masked: out of device memory"); return -2; }
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc((void**)&h->h_lists[i], need * sizeof(int), hipHostMallocDefault) != hipSuccess) { fail(OWW_ENOMEM, "oww_step_masked: out of page-locked memory"); return -2; }
+            if (!h->lists_ev[i] && hipEventCreateWithFlags(&h->lists_ev[i], hipEventDisableTiming) != hipSuccess) { fail(OWW_EHIP, "hipEventCreate failed"); return -2; }
+        }
+        h->lists_cap = need;
+    }
+    const unsigned turn = h->lists_turn++ & 1u;
+    (void)hipEventSynchronize(h->lists_ev[turn]);              // the copy that last read this staging buffer has run
+    int* out = h->h_lists[turn];
+    // one pass over the mask, eight streams (one 64-bit word = one stage-E group) at a time; the five lists grow side by side in
+    // fixed regions of the staging buffer and are packed afterwards
+    const size_t base[5] = {0, (size_t)S, (size_t)S + S / 2 + 8, (size_t)S + S / 2 + S / 4 + 16, (size_t)S + S / 2 + S / 4 + S / 8 + 24};
+    int n[5] = {0, 0, 0, 0, 0};
+    const int W8 = S / 8;
+    int last_v = -1;
+    auto visit = [&](int s0, const uint8_t* b, int cnt) {        // streams s0 .. s0+cnt-1 (cnt <= 8), at least one of them on
+        const int g8 = s0 / 8;
+        out[base[3] + n[3]++] = g8;
+        if (g8 / 2 != last_v) { last_v = g8 / 2; out[base[4] + n[4]++] = g8 / 2; }
+        for (int q = 0; q < cnt; q += 4) {
+            bool any4 = false;
+            for (int c = q; c < std::min(cnt, q + 4); c += 2) {
+                bool any2 = false;
+                for (int i = c; i < std::min(cnt, c + 2); ++i) if (b[i]) { out[base[0] + n[0]++] = s0 + i; any2 = true; }
+                if (any2) { out[base[1] + n[1]++] = (s0 + c) / 2; any4 = true; }
+            }
+            if (any4) out[base[2] + n[2]++] = (s0 + q) / 4;
+        }
+    };
+    for (int w = 0; w < W8; ++w) {
+        uint64_t v;
+        memcpy(&v, on + (size_t)w * 8, 8);
+        if (v) visit(w * 8, on + (size_t)w * 8, 8);
+    }
+    if (S % 8) {
+        bool any = false;
+        for (int s = W8 * 8; s < S; ++s) any = any || on[s] != 0;
+        if (any) visit(W8 * 8, on + (size_t)W8 * 8, S - W8 * 8);
+    }
+    size_t off = 0;
+    for (int k = 0; k < 5; ++k) {
+        if (base[k] != off) memmove(out + off, out + base[k], (size_t)n[k] * sizeof(int));
+        h->gl_now[k] = h->d_lists + off; h->gn_now[k] = n[k];
+        off += (size_t)n[k];
+    }
+    if (off) {
+        if (hipMemcpyAsync(h->d_lists, out, off * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) { fail(OWW_EHIP, "oww_step_masked: list upload failed"); return -2; }
+        (void)hipEventRecord(h->lists_ev[turn], h->stream);
+    }
+    return n_act;
 }
 
 int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
@@ -1603,8 +1691,14 @@ int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uin
         d_pcm = h->d_pcm;
     }
     h->on_now = h->d_on;
-    const int rc = launch_step(h, d_pcm, 1);
-    h->on_now = nullptr;
+    int n_act = -1;
+    if (!stream_on_on_device) {                                 // few participants: only their groups are launched (build_active_lists)
+        n_act = build_active_lists(h, stream_on);
+        if (n_act == -2) { h->on_now = nullptr; return OWW_ENOMEM; }
+    }
+    h->lists_now = n_act >= 0;
+    const int rc = n_act == 0 ? 0 : launch_step(h, d_pcm, 1);     // nobody takes part: nothing moves
+    h->on_now = nullptr; h->lists_now = false;
     if (rc) return rc;
     if (scores) {
         const size_t nb = (size_t)h->S * h->NL * sizeof(float);
@@ -1668,8 +1762,14 @@ static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const u
         HIPCHK(hipMemcpyAsync(h->d_on, sl.h_on, h->S, hipMemcpyHostToDevice, h->stream));
         h->on_now = h->d_on;
     }
-    const int rc_step = launch_step(h, sl.d_pcm, n_chunks);
-    h->on_now = nullptr;
+    int n_act = -1;
+    if (stream_on) {
+        n_act = build_active_lists(h, stream_on);
+        if (n_act == -2) { h->on_now = nullptr; return OWW_ENOMEM; }
+    }
+    h->lists_now = n_act >= 0;
+    const int rc_step = n_act == 0 ? 0 : launch_step(h, sl.d_pcm, n_chunks);
+    h->on_now = nullptr; h->lists_now = false;
     if (rc_step) return rc_step;
     const size_t nb = (size_t)h->S * h->NL * sizeof(float);
     if (nb) HIPCHK(hipMemcpyAsync(sl.d_scores, h->d_scores, nb, hipMemcpyDeviceToDevice, h->stream));   // d_scores is rewritten by the next step

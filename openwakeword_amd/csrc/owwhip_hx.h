@@ -754,6 +754,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     __shared__ __attribute__((aligned(16))) float sbn[4][NCT * 16];      // per layer: K * BatchNorm shift in tile row order = accumulator start values
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
+    if (p.glist) g = p.glist[g];          // a masked step with few participants runs only the groups that hold one (owwhip.hip: build_active_lists)
     lanemask_t bad = 0;
     issue_chunk<NBAM, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
@@ -1309,6 +1310,8 @@ struct HeadHxParams {
     int* range_flag;        // sticky f16-range flag of the handle (see nan_guard)
     HeadHxPost post;
     const uint8_t* stream_on;   // oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
+    const int* ids;             // oww_step_masked with few participants: the n_ids participating streams (position k of the launch = stream
+    int n_ids;                  // ids[k]); nullptr = streams 0 .. S-1
 };
 
 __device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
@@ -1390,7 +1393,8 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
     uint32_t slot0[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        s[t] = min((blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos, p.S - 1);
+        const int idx = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
+        s[t] = p.ids ? p.ids[min(idx, p.n_ids - 1)] : min(idx, p.S - 1);
         if (p.ext) { frow[t] = p.feat + (size_t)s[t] * p.T * 96; slot0[t] = 0; }
         else { frow[t] = p.feat + (size_t)s[t] * p.TR * 96; slot0[t] = p.nfeat[s[t]] + (uint32_t)(2 * p.TR - p.T + 1); }
     }
@@ -1488,8 +1492,9 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
     if (j == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int st = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
-            if (st >= p.S) continue;
+            const int idx = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
+            if (idx >= (p.ids ? p.n_ids : p.S)) continue;
+            const int st = p.ids ? p.ids[idx] : idx;
             if (p.stream_on && !p.stream_on[st]) continue;          // sits this step out: scores, rings and counters stay as they are
             const uint32_t cnt = p.post.enabled ? p.post.npred[st] : 0u;
             const int have = cnt < 30u ? (int)cnt : 30;

@@ -498,6 +498,8 @@ struct RStageParams {
     float emb_mul;         // f16-split family, last stage: 1 / K of conv19 (embeddings are stored in true units)
     int* range_flag;       // f16-split family: sticky out-of-range flag of the handle (owwhip_hx.h nan_guard); nullptr otherwise
     const uint8_t* stream_on;  // f16-split family, oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
+    const int* glist;          // f16-split family, oww_step_masked with few participants: the n_groups groups (of this stage's SPT streams)
+                               // that hold at least one participating stream; nullptr = groups 0 .. n_groups-1
 };
 
 // max-pool PT x PF of the stage output and scatter into the next stage's register-dump layout

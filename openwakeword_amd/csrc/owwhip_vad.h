@@ -289,6 +289,7 @@ struct VadLstmParams {
     float* last;            // [S] the score just pushed
     int S, n_groups;
     const uint8_t* stream_on;   // see VadFrontParams::stream_on
+    const int* glist;           // see owr::RStageParams::glist (groups of 16 streams)
 };
 
 constexpr int L_WG = 4;                       // waves per workgroup: they share one weight chunk stream
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64 * L_WG, 2) void vad_lstm_kernel(VadLstmParams p)
     int g = blockIdx.x * L_WG + wave;
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
+    if (p.glist) g = p.glist[g];          // masked step with few participants: only the 16-stream groups that hold one
     issue_chunk<L_CHUNK_BLOCKS, L_WG>(p.w, wbuf, wave, lane);
     for (int i = threadIdx.x; i < 512; i += 64 * L_WG) sb[i] = p.bias[i];
     if (threadIdx.x < 64) swd[threadIdx.x] = p.wd[threadIdx.x];

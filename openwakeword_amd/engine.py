@@ -204,6 +204,15 @@ class StreamEngine:
         _lib.check(self._lib.oww_step_masked(self._h, _ptr(pcm), 0, _ptr(on), 0, _ptr(out), 0))
         return out
 
+    def step_masked_device(self, pcm_dev_ptr: int, stream_on: np.ndarray, scores_dev_ptr: int = 0) -> None:
+        """oww_step_masked on device-resident PCM / scores with the participation mask on the host (asynchronous); with at most
+        half of the streams taking part only their groups are launched."""
+        on = np.ascontiguousarray(stream_on, dtype=np.uint8)
+        if on.shape != (self.n_streams,):
+            raise ValueError(f"stream_on must be [{self.n_streams}]")
+        _lib.check(self._lib.oww_step_masked(self._h, C.c_void_p(int(pcm_dev_ptr)), 1, _ptr(on), 0,
+                                             C.c_void_p(int(scores_dev_ptr)) if scores_dev_ptr else None, 1))
+
     def resample(self, pcm: np.ndarray, sample_rate: int) -> np.ndarray:
         """int16 [S, n_in] at `sample_rate` Hz -> int16 [S, n_in * 16000 // sample_rate] at 16 kHz on the device (oww_resample with the
         filter bank of resample.design; stateless per call, like the per-message resampy call of examples/web/streaming_server.py:57-58)."""

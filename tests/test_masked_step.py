@@ -24,14 +24,16 @@ def _pcm(rng, S, T):
     return (rng.standard_normal((T, S, 1280)) * 4000).astype(np.int16)
 
 
-@pytest.mark.parametrize("S,with_vad", [(40, False), (200, False), (72, True)])
-def test_masked_step_equals_private_sequences(S, with_vad):
+@pytest.mark.parametrize("S,with_vad,frac", [(40, False, 0.6), (200, False, 0.6), (72, True, 0.6),
+                                             (200, False, 0.12), (330, True, 0.1), (1000, False, 0.03)])
+def test_masked_step_equals_private_sequences(S, with_vad, frac):
     """Random participation masks over 40 steps; every stream's k-th active step must equal, BIT FOR BIT, the k-th step of an
-    unmasked engine that is fed the stream's active chunks back to back (S chosen to leave partly filled position tiles)."""
+    unmasked engine that is fed the stream's active chunks back to back (S chosen to leave partly filled position tiles).
+    frac <= 0.5: the library launches only the groups that hold a participating stream (build_active_lists): same results."""
     rng = np.random.default_rng(5)
     T = 40
     pcm = _pcm(rng, S, T)
-    on = rng.random((T, S)) < 0.6
+    on = rng.random((T, S)) < frac
     on[:, 0] = True                      # one stream in every step
     on[:, 1] = False                     # one stream in none
     on[::2, 2] = True
