@@ -374,6 +374,11 @@ struct oww_ctx {
     int *d_patience = nullptr;
     float* d_threshold = nullptr;
     int debounce_frames = 0;
+    // block-pipelined step: the one-chunk fused step of a large handle is launched as n_blocks stream ranges on their own HIP streams
+    // (forked from / joined to the handle's stream with events), so that one block's latency-bound phases and partly filled last
+    // wave rounds overlap the other block's kernels.  blk_s0 / blk_s1 = the range being launched (0 / 0 = everything).
+    int n_blocks = 1; hipStream_t blk_stream[4] = {}; hipEvent_t blk_fork = nullptr, blk_done[4] = {};
+    int blk_s0 = 0, blk_s1 = 0;
     // RCCL communicator of oww_comm_init (multi-GPU delivery of results without Python)
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     // timing
@@ -508,10 +513,11 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
             // mel front end + stage A in one launch: PCM in, pooled stage-A activations out (BASELINE configs[2] "mel+embedding fused")
             owf::MelAParams q{};
             q.a = p; q.a.mel = nullptr; q.a.n_streams = h->S;          // the PCM buffer holds the S real streams only
+            if (h->blk_s1 > 0) { q.a.s_base = h->blk_s0; q.a.n_streams = std::min(h->S, h->blk_s1) - h->blk_s0; }
             q.pcm = h->fuse_pcm; q.tail = h->d_tail; q.nfeat = h->d_nfeat; q.hann = h->d_hann; q.mel_start = h->d_mstart; q.mel_taps = h->d_taps;
             q.mel_out = h->cfg.debug_layers ? h->d_mel : nullptr;
             const int per_cu = std::max(1, std::min(12 / owf::FA_WG, 163840 / owf::FA_LDS_BYTES));     // persistent: 12 waves per CU
-            const int g2 = std::min((h->S + owf::FA_WG - 1) / owf::FA_WG, 256 * per_cu);
+            const int g2 = std::max(1, std::min((q.a.n_streams + owf::FA_WG - 1) / owf::FA_WG, 256 * per_cu));
             hipLaunchKernelGGL(owf::hmelA_kernel<DBG>, dim3(g2), dim3(64 * owf::FA_WG), owf::FA_LDS_BYTES, st, q);
         }
         else if (HX) hipLaunchKernelGGL(owh::hstageA_kernel<DBG>, dim3(std::min((n_active + 3) / 4, 256 * OWH_WPS_A)), dim3(256), 0, st, p);
@@ -531,6 +537,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.dbg = DBG ? h->d_dbg : nullptr; p.dbg_stride = DBG_FLOATS;
         p.range_flag = HX ? h->d_range : nullptr;
         p.stream_on = h->on_now;
+        if (HX && h->blk_s1 > 0) { p.g_base = h->blk_s0 / spt; p.n_groups = (h->blk_s1 - h->blk_s0 + spt - 1) / spt; }
         if (HX && h->lists_now) {                                   // spt 1, 2, 4, 8 -> list 0, 1, 2, 3
             const int k = spt == 1 ? 0 : spt == 2 ? 1 : spt == 4 ? 2 : 3;
             p.glist = h->gl_now[k]; p.n_groups = h->gn_now[k];
@@ -607,7 +614,8 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 q.raw = raw_out; q.NL = h->NL; q.S = n_active; q.accumulate_max = base.accumulate_max;
                 q.range_flag = h->d_range; q.stream_on = h->on_now;
                 if (h->lists_now && !ext) { q.ids = h->gl_now[0]; q.n_ids = h->gn_now[0]; }
-                const int n_pos = q.ids ? q.n_ids : n_active;
+                if (h->blk_s1 > 0 && !ext) { q.s_base = h->blk_s0; q.S = h->blk_s1; }
+                const int n_pos = q.ids ? q.n_ids : q.S - q.s_base;
                 if (h->post_in_heads_now) {
                     owh::HeadHxPost& pp = q.post;
                     pp.enabled = 1; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred; pp.nfeat = h->d_nfeat;
@@ -751,6 +759,11 @@ void free_all(oww_ctx* h) {
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
     if (h->d_on) { (void)hipFree(h->d_on); h->d_on = nullptr; }
+    for (int b = 0; b < 4; ++b) {
+        if (h->blk_stream[b]) { (void)hipStreamSynchronize(h->blk_stream[b]); (void)hipStreamDestroy(h->blk_stream[b]); h->blk_stream[b] = nullptr; }
+        if (h->blk_done[b]) { (void)hipEventDestroy(h->blk_done[b]); h->blk_done[b] = nullptr; }
+    }
+    if (h->blk_fork) { (void)hipEventDestroy(h->blk_fork); h->blk_fork = nullptr; }
     if (h->d_lists) { (void)hipFree(h->d_lists); h->d_lists = nullptr; }
     for (int i = 0; i < 2; ++i) {
         if (h->h_lists[i]) { (void)hipHostFree(h->h_lists[i]); h->h_lists[i] = nullptr; }
@@ -894,7 +907,25 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
     }
     if (h->fuse && k == 1 && (reinterpret_cast<uintptr_t>(d_pcm) & 15) == 0) {      // (the fused front end uses 16-byte sample loads)
         h->fuse_pcm = d_pcm;
-        const int rc = step_chunk(h, 1, 0);
+        int rc = 0;
+        const bool blocks = h->n_blocks > 1 && h->post_in_heads && h->n_verifiers == 0 && !h->lists_now && !h->timing && !h->want_graph && !h->d_dbg;
+        if (blocks) {
+            // fork: the block streams wait for everything already queued on the handle's stream (PCM upload, VAD launches, masks)
+            hipStream_t main_stream = h->stream;
+            if (hipEventRecord(h->blk_fork, main_stream) != hipSuccess) rc = fail(OWW_EHIP, "block fork failed");
+            const int per = (h->Spad / h->n_blocks + 127) / 128 * 128;
+            for (int b = 0; b < h->n_blocks && !rc; ++b) {
+                h->blk_s0 = b * per; h->blk_s1 = b == h->n_blocks - 1 ? h->Spad : std::min(h->Spad, (b + 1) * per);
+                if (h->blk_s0 >= h->blk_s1 || h->blk_s0 >= h->S) break;
+                if (hipStreamWaitEvent(h->blk_stream[b], h->blk_fork, 0) != hipSuccess) { rc = fail(OWW_EHIP, "block fork failed"); break; }
+                h->stream = h->blk_stream[b];
+                rc = step_chunk(h, 1, 0);
+                h->stream = main_stream;
+                if (!rc && (hipEventRecord(h->blk_done[b], h->blk_stream[b]) != hipSuccess || hipStreamWaitEvent(main_stream, h->blk_done[b], 0) != hipSuccess))
+                    rc = fail(OWW_EHIP, "block join failed");
+            }
+            h->stream = main_stream; h->blk_s0 = h->blk_s1 = 0;
+        } else rc = step_chunk(h, 1, 0);
         h->fuse_pcm = nullptr;
         if (rc) return rc;
     } else {
@@ -1534,6 +1565,20 @@ int oww_commit(oww_ctx* h) {
     if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
     if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
+    // block-pipelined step: OFF by default.  Measured with the round-3 kernels at 131,072 x 3 (same box, OWW_BLOCKS = 1 / 2 / 3 / 4):
+    // 6.04 / 6.10 / 6.25 / 6.32 ms per step -- two kernels sharing the chip gain nothing now that the front end no longer stalls
+    // (round 2, two handles on two streams: -3.6 %).  OWW_BLOCKS=2..4 switches it on for large handles (experiments).
+    if (h->hx && h->S >= 16384) {
+        h->n_blocks = 1;
+        if (const char* e = getenv("OWW_BLOCKS")) h->n_blocks = std::min(4, std::max(1, atoi(e)));
+        if (h->n_blocks > 1) {
+            HIPCHK(hipEventCreateWithFlags(&h->blk_fork, hipEventDisableTiming));
+            for (int b = 0; b < h->n_blocks; ++b) {
+                HIPCHK(hipStreamCreateWithFlags(&h->blk_stream[b], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->blk_done[b], hipEventDisableTiming));
+            }
+        }
+    }
     h->fuse = h->hx && !getenv("OWW_NO_FUSE");
     h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
     if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;

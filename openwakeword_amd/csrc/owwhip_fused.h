@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
     for (int s0 = gw; s0 < q.a.n_streams; s0 += nw) {
         // the stream index as an opaque scalar: row addresses are then formed per iteration as SGPR base + lane offset instead of
         // strength-reduced 64-bit per-lane pointers that would stay alive (and spill) across the whole loop body
-        int s = __builtin_amdgcn_readfirstlane(s0);
+        int s = __builtin_amdgcn_readfirstlane(s0 + q.a.s_base);
         asm volatile("" : "+s"(s));
         if (q.a.stream_on && !q.a.stream_on[s]) continue;        // masked step (oww_step_masked): no sample is consumed, no state touched
 

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
     if (p.glist) g = p.glist[g];          // a masked step with few participants runs only the groups that hold one (owwhip.hip: build_active_lists)
+    else g += p.g_base;                   // block-pipelined step: this launch covers groups g_base .. g_base + n_groups - 1
     lanemask_t bad = 0;
     issue_chunk<NBAM, WG>(p.w[0], wbuf, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
@@ -1261,7 +1262,8 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
     __syncthreads();
     lanemask_t bad = 0;
 
-    for (int s = gw; s < p.n_streams; s += nw) {
+    for (int s0 = gw; s0 < p.n_streams; s0 += nw) {
+        const int s = s0 + p.s_base;
         if (p.stream_on && !p.stream_on[s]) continue;            // masked step: this stream sits it out
         hstageA_stream<DBG, false>(p, s, sPl[wave], sW0, sW[0], sW[1], &sbn[0][0][0], gtab, bad, lane);
     }
@@ -1311,7 +1313,8 @@ struct HeadHxParams {
     HeadHxPost post;
     const uint8_t* stream_on;   // oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
     const int* ids;             // oww_step_masked with few participants: the n_ids participating streams (position k of the launch = stream
-    int n_ids;                  // ids[k]); nullptr = streams 0 .. S-1
+    int n_ids;                  // ids[k]); nullptr = streams s_base .. S-1
+    int s_base;                 // block-pipelined step: first stream of this launch (S = one past its last)
 };
 
 __device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
@@ -1394,7 +1397,7 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int idx = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
-        s[t] = p.ids ? p.ids[min(idx, p.n_ids - 1)] : min(idx, p.S - 1);
+        s[t] = p.ids ? p.ids[min(idx, p.n_ids - 1)] : min(idx + p.s_base, p.S - 1);
         if (p.ext) { frow[t] = p.feat + (size_t)s[t] * p.T * 96; slot0[t] = 0; }
         else { frow[t] = p.feat + (size_t)s[t] * p.TR * 96; slot0[t] = p.nfeat[s[t]] + (uint32_t)(2 * p.TR - p.T + 1); }
     }
@@ -1493,8 +1496,8 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int idx = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
-            if (idx >= (p.ids ? p.n_ids : p.S)) continue;
-            const int st = p.ids ? p.ids[idx] : idx;
+            if (idx >= (p.ids ? p.n_ids : p.S - p.s_base)) continue;
+            const int st = p.ids ? p.ids[idx] : idx + p.s_base;
             if (p.stream_on && !p.stream_on[st]) continue;          // sits this step out: scores, rings and counters stay as they are
             const uint32_t cnt = p.post.enabled ? p.post.npred[st] : 0u;
             const int have = cnt < 30u ? (int)cnt : 30;

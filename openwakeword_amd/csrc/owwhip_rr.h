@@ -499,7 +499,8 @@ struct RStageParams {
     int* range_flag;       // f16-split family: sticky out-of-range flag of the handle (owwhip_hx.h nan_guard); nullptr otherwise
     const uint8_t* stream_on;  // f16-split family, oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
     const int* glist;          // f16-split family, oww_step_masked with few participants: the n_groups groups (of this stage's SPT streams)
-                               // that hold at least one participating stream; nullptr = groups 0 .. n_groups-1
+                               // that hold at least one participating stream; nullptr = groups g_base .. g_base + n_groups-1
+    int g_base;                // f16-split family: first group of the block this launch covers (block-pipelined step; 0 otherwise)
 };
 
 // max-pool PT x PF of the stage output and scatter into the next stage's register-dump layout
@@ -662,6 +663,7 @@ struct RAParams {
     const float* shift[3];
     float* xout;           // stage B xin: [S][4][8][64]
     int n_streams;         // streams to run
+    int s_base;            // f16-split family: first stream of the block this launch covers (block-pipelined step; 0 otherwise)
     int S;
     float* dbg;
     size_t dbg_stride;
