@@ -155,6 +155,10 @@ int  oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const ui
  * stream and returns OWW_OK or OWW_ERANGE; clear != 0 lowers the flag (after e.g. resetting the offending streams).
  * The exact-fp32 family (use_mfma = 1) never raises it. */
 int  oww_range_status(oww_ctx* h, int clear);
+/* Which streams: after OWW_ERANGE, first_stream / n_streams name the contiguous streams of (one of) the wave(s) that saw the
+ * out-of-range value -- the offender is among them -- so that a server can oww_reset just those and clear the flag instead of
+ * restarting every stream; (-1, 0) when the flag is down or the position is not known (a step over a participant list). */
+int  oww_range_where(oww_ctx* h, int32_t* first_stream, int32_t* n_streams);
 
 /* ---- host-fed pipeline: the same step with PCM arriving in host memory every 80 ms (the serving edge of
  *      examples/web/streaming_server.py:32-70 and detect_from_microphone.py: audio is produced on the host) ----------

@@ -40,6 +40,7 @@ SYMBOLS = {
     "oww_step_masked": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
     "oww_sync": (C.c_int, [_P]),
     "oww_range_status": (C.c_int, [_P, C.c_int]),
+    "oww_range_where": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oww_submit": (C.c_int, [_P, _P, C.c_int32]),
     "oww_submit_masked": (C.c_int, [_P, _P, _P]),
     "oww_collect": (C.c_int, [_P, _P]),

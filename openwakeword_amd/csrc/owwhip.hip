@@ -1519,7 +1519,7 @@ int oww_commit(oww_ctx* h) {
     {
         void* dp = nullptr;
         HIPCHK(hipHostMalloc((void**)&h->h_range, 64, hipHostMallocMapped));
-        *h->h_range = 0;
+        h->h_range[0] = 0; h->h_range[1] = -1; h->h_range[2] = 0;
         HIPCHK(hipHostGetDevicePointer(&dp, h->h_range, 0));
         h->d_range = (int*)dp;
     }
@@ -1958,6 +1958,16 @@ int oww_range_status(oww_ctx* h, int clear) {
     const int rc = range_check(h, "oww_range_status");
     if (clear && h->h_range) *(volatile int*)h->h_range = 0;
     return rc;
+}
+
+int oww_range_where(oww_ctx* h, int32_t* first_stream, int32_t* n_streams) {
+    if (!h || !h->committed || !first_stream || !n_streams) return fail(OWW_EINVAL, "oww_range_where: bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const volatile int* f = (const volatile int*)h->h_range;
+    if (f && f[0]) { *first_stream = f[1]; *n_streams = f[2]; if (*first_stream >= h->S) { *first_stream = -1; *n_streams = 0; } else if (*first_stream >= 0) *n_streams = std::min(*n_streams, h->S - *first_stream); }
+    else { *first_stream = -1; *n_streams = 0; }
+    return OWW_OK;
 }
 
 const float* oww_scores_dev(const oww_ctx* h) { return h ? h->d_scores : nullptr; }

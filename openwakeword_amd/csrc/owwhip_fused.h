@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         wave_sync();
         __builtin_amdgcn_sched_barrier(0);       // the mel phase ends here: none of its values stays live into stage A
         owh::hstageA_stream<DBG, true>(q.a, s, sP, sW0, sW1, sW2, sbn, gtab, bad, lane_all);
+        if (bad) { owh::raise_range_flag(bad, q.a.range_flag, s, 1); bad = 0; }
         __builtin_amdgcn_sched_barrier(0);
     }
     owh::raise_range_flag(bad, q.a.range_flag);

@@ -78,8 +78,10 @@ __device__ __forceinline__ void nan_guard(lanemask_t& bad, float x) {
     asm volatile("" : "+s"(bad));
 #endif
 }
-__device__ __forceinline__ void raise_range_flag(lanemask_t bad, int* flag) {
-    if (bad != 0 && flag != nullptr && (threadIdx.x & 63) == 0) *flag = 1;
+// flag[0] = raised; flag[1], flag[2] = first stream and stream count of (one of) the wave(s) that saw it (last writer wins: any
+// offender is enough for a caller that wants to reset the streams concerned instead of the whole handle, oww_range_where)
+__device__ __forceinline__ void raise_range_flag(lanemask_t bad, int* flag, int first_stream = -1, int n_streams = 0) {
+    if (bad != 0 && flag != nullptr && (threadIdx.x & 63) == 0) { flag[1] = first_stream; flag[2] = n_streams; *flag = 1; }
 }
 
 #ifndef OWH_MIXSPLIT
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     }
     }   // pass
     if (!LAST && C::NPASS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the chunk the last pass prefetched
-    raise_range_flag(bad, p.range_flag);
+    raise_range_flag(bad, p.range_flag, s_first, C::SPT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1266,8 +1268,8 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
         const int s = s0 + p.s_base;
         if (p.stream_on && !p.stream_on[s]) continue;            // masked step: this stream sits it out
         hstageA_stream<DBG, false>(p, s, sPl[wave], sW0, sW[0], sW[1], &sbn[0][0][0], gtab, bad, lane);
+        if (bad) { raise_range_flag(bad, p.range_flag, s, 1); bad = 0; }
     }
-    raise_range_flag(bad, p.range_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1553,7 +1555,9 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
             }
         }
     }
-    raise_range_flag(bad, p.range_flag);
+    // (which streams: the wave's 32 positions; with a participant list they are not contiguous -- reported as unknown)
+    if (p.ids) raise_range_flag(bad, p.range_flag);
+    else raise_range_flag(bad, p.range_flag, (blockIdx.x * HX_WG + wave) * 32 + p.s_base, 32);
 }
 
 }  // namespace owh

@@ -372,6 +372,13 @@ class StreamEngine:
         return False
 
     @property
+    def range_where(self):
+        """(first_stream, n_streams) of a wave that saw the out-of-range value behind OwwRangeError -- the offender is among these
+        streams -- or (-1, 0) when the flag is down / the position is unknown (include/owwhip.h: oww_range_where)."""
+        a, b = C.c_int32(-1), C.c_int32(0)
+        _lib.check(self._lib.oww_range_where(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def scores_dev_ptr(self) -> int:
         return int(self._lib.oww_scores_dev(self._h) or 0)
 

@@ -242,8 +242,9 @@ class FanInServer:
 
     async def _recover_range(self, flying) -> None:
         """OWW_ERANGE is sticky per handle: one stream whose activations left the f16 range would stop scoring for everybody.  The
-        flag does not say which stream it was, so every connected stream restarts from Model()'s initial state (their clients keep
-        their connections and simply see a few silent frames), the steps in flight are dropped and the flag is cleared."""
+        streams of the wave that saw it (oww_range_where; every stream when the position is unknown) restart from Model()'s initial
+        state -- their clients keep their connections and simply see a few silent frames -- the steps in flight are dropped and the
+        flag is cleared."""
         self.n_range_recoveries += 1
         def recover():
             eng = self.model.engine
@@ -252,8 +253,10 @@ class FanInServer:
                     eng.collect()
                 except Exception:
                     pass
+            first, n = eng.range_where()
             eng.range_status(clear=True)
-            self.model.reset(None, reset_vad=bool(eng.has_vad))
+            ids = list(range(first, first + n)) if first >= 0 and n > 0 else None      # None: not known -> every stream
+            self.model.reset(ids, reset_vad=bool(eng.has_vad))
             eng.range_status(clear=True)
         await self._gpu.call(recover)
         for ready in flying:

@@ -382,7 +382,10 @@ def test_range_guard_is_sticky_and_loud(emb, heads):
             eng.step(pcm[:, 2560:])
         with pytest.raises(OwwRangeError):
             eng.sync()
+        first, n = eng.range_where()                              # the offender (stream 1) is among the streams named
+        assert first >= 0 and first <= 1 < first + n <= 3
         assert eng.range_status(clear=True) is True
+        assert eng.range_where() == (-1, 0)
         eng.reset()
         assert eng.range_status() is False
         out = eng.step(pcm[:, :1280])
