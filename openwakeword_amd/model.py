@@ -482,8 +482,19 @@ class BatchedModel:
                 name, head = _load_head(m, seed)
                 heads[name] = head
         emb = resolve_embedding(emb, seed)
-        # vad_weights: the on-device voice-activity stand-in network (weights.synthetic_vad layout; Silero's graph is not
-        # available, see openwakeword_amd/vad.py) -- BASELINE configs[4]: network + gate fused into every step
+        # vad_weights: the on-device voice-activity network (weights.synthetic_vad layout) -- BASELINE configs[4]: network + gate
+        # fused into every step.  With a gate asked for and no weights given, a silero_vad.onnx next to the package is ingested
+        # when its graph is the architecture the kernels implement (onnx_ingest.load_vad); a graph it refuses, or no file, leaves
+        # the gate to externally pushed scores (push_vad) -- said loudly, never a silently different network.
+        if vad_weights is None and vad_threshold > 0:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resources", "models", "silero_vad.onnx")
+            if os.path.exists(path):
+                from . import onnx_ingest
+                try:
+                    vad_weights = onnx_ingest.load_vad(path)
+                except ValueError as e:
+                    import warnings
+                    warnings.warn(f"{e} -- the VAD gate of this BatchedModel waits for push_vad() scores", RuntimeWarning)
         self.engine = StreamEngine(n_streams, heads, emb, device=device, max_chunks=max_chunks, hip_stream=hip_stream,
                                    vad=vad_weights, vad_threshold=vad_threshold)
         self.labels: List[str] = []
