@@ -7,8 +7,9 @@
 // is evaluated by three v_mfma_f32_16x16x32_f16 with fp32 accumulation: f16 x f16 products are exact in fp32, so the
 // result differs from the fp32 kernels by ~2^-22 relative per product -- the same class as fp32 round-off itself
 // (oracle emulation: |embedding error| 4.7e-6 vs 4.5e-6 for plain fp32 against float64; tests hold it to the same
-// tolerances as the fp32 paths).  Weights are pre-scaled by 2^8 on the host (keeps their low halves out of the f16
-// subnormal range; undone exactly by the folded BatchNorm scale) and pre-split.
+// tolerances as the fp32 paths).  The embedding CNN's weights are pre-split on the host with the BatchNorm scale and the layers'
+// activation-scale ratio folded in (round 3, see act1 below and calibrate_hx in owwhip.hip); the heads' and the VAD stand-in's
+// weights are pre-scaled by 2^8 (keeps their low halves out of the f16 subnormal range; undone in their bias fma).
 //
 // Operand form.  16x16x32: A lane (i, g) holds A[i][k = 8g..8g+7], B lane (p, g) holds B[k = 8g..8g+7][p] (8 halves =
 // 4 VGPRs each), D as in the fp32 form (lane (p, j), register e <-> D[4j+e][p]).  A k-step carries 32 input channels =
@@ -23,13 +24,13 @@ namespace owh {
 using owr::f32x4;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float WSCALE = 256.0f;            // weights are stored as f16 halves of 2^8 * w
+constexpr float WSCALE = 256.0f;            // heads / VAD: weights are stored as f16 halves of 2^8 * w
 constexpr float WUNSCALE = 1.0f / 256.0f;
 
 // BatchNorm in the f16-split family is FOLDED: the per-channel scale (sign included) goes into the f16-split weights, the shift is
 // the accumulator's start value, and every layer's activations are carried multiplied by a per-layer power of two K = 2^e chosen at
-// oww_commit from a calibration run on the exact-fp32 kernels (owwhip.hip: calibrate_hx) so that they sit in the middle of the f16
-// range whatever the weights' own scale is:
+// oww_commit from a calibration run on the exact-fp32 kernels (owwhip.hip: calibrate_hx) -- a ladder that climbs by 2^2 per layer
+// inside a stage (so the folded weights keep precise low halves) and is brought back at the pooled hand-over:
 //      acc = sum_k W'_k X_k + K h,   W' = s w K_out / K_in,  X = K_in a(y_in)   =>   acc = K_out y
 //      K a(y) = max(max(0.2 acc, acc), -0.4 K)                 (the activation is positively homogeneous up to its clamp constant)
 // Two VALU per value (v_mul, v_max3) instead of three, no silent underflow for small-valued networks, and max-pooling commutes
