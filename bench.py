@@ -48,8 +48,9 @@ PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
 # f16 MFMAs (v_mfma_f32_16x16x32_f16, 16384 flop each) the fp16-split kernels execute per stream-step, channel padding included
 # (round 2: the layers with a 72-channel input run K-merged -- 7 instead of 9 k-steps per output tile -- i.e. layers b, c, d of
 #  stage C: 810 instead of 990, and layer a of stage D: 306 instead of 324; layer a of stage C, 48 channels in, 5 instead of 6: 780)
-#  round 3: stage A's conv0 is one K-folded MFMA per output tile instead of three: 608 instead of 672)
-HX_MFMAS = {"stageA": 608, "stageB": 648, "stageC": 780, "stageD": 306, "stageE": 182}
+#  round 3: stage A's conv0 is one K-folded MFMA per output tile instead of three, and the half tiles of conv1 / conv2 stack a
+#  second tap / output row in their free rows: 512 instead of 672; stage B's remainder k-step in two MFMAs: 648 instead of 756)
+HX_MFMAS = {"stageA": 512, "stageB": 648, "stageC": 780, "stageD": 306, "stageE": 182}
 MEL_FLOPS = 100_000         # FFT form of the log-mel front end per stream-step, executed by the fused launch's VALU
 PEAK_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: peak engine clock; 256 CUs x 4 SIMDs
 N_SIMD = 1024

@@ -239,6 +239,37 @@ void pack_hx_conv0(const float* w /*[9][24]*/, std::vector<float>& out, HxFold* 
     memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
 }
 
+// stage A's two 24 -> 24 layers (owh::hstageA_stream): channel tile 0 as in pack_hx -- blocks [tap][part] -- and the HALF tile (channels
+// 16..23 in rows 4j + e, e < 2) with a second tap stacked into its free rows 4j + e, e >= 2:
+//   conv1 (1x3): blocks (W2 | W0), (W1 | 0), (W0 | W2): the side chain of a parity tile rides in the main chain's registers 2, 3;
+//   conv2 (3x1): blocks (W_i | W_{i-1}) for input row i = 0..3 of [history 0, history 1, row 2q, row 2q+1]: registers 0, 1 accumulate
+//                output row 2q, registers 2, 3 output row 2q+1.
+void pack_hx_stage_a(const float* w /*[3][24][24]*/, int layer, std::vector<float>& out, HxFold* fold) {
+    const int nblk = layer == 1 ? 12 : 14;
+    std::vector<_Float16> hbuf((size_t)nblk * 64 * 8, (_Float16)0.f);
+    auto put = [&](int blk, int lane, int q, int tap, int ci, int co) {
+        if (tap < 0 || tap > 2 || ci < 0 || co < 0) return;
+        _Float16 hi, lo;
+        fold->split(w[((size_t)tap * 24 + ci) * 24 + co], co, hi, lo);
+        hbuf[((size_t)blk * 64 + lane) * 8 + q] = hi;
+        hbuf[((size_t)(blk + 1) * 64 + lane) * 8 + q] = lo;
+    };
+    for (int lane = 0; lane < 64; ++lane)
+        for (int q = 0; q < 8; ++q) {
+            const int i = lane & 15, g = lane >> 4, ci = hx_row_channel(q / 4, 4 * g + q % 4, 24);
+            for (int tap = 0; tap < 3; ++tap) put(tap * 2, lane, q, tap, ci, i);                       // channel tile 0: output channel i
+            const int j = i >> 2, e = i & 3, co = 16 + 2 * j + (e & 1);
+            if (layer == 1) {
+                const int lo_tap[3] = {2, 1, 0}, hi_tap[3] = {0, -1, 2};
+                for (int v = 0; v < 3; ++v) put(6 + v * 2, lane, q, e < 2 ? lo_tap[v] : hi_tap[v], ci, co);
+            } else {
+                for (int r = 0; r < 4; ++r) put(6 + r * 2, lane, q, e < 2 ? r : r - 1, ci, co);
+            }
+        }
+    out.assign(hbuf.size() / 2, 0.f);
+    memcpy(out.data(), hbuf.data(), hbuf.size() * sizeof(_Float16));
+}
+
 struct HostBuf {                      // host image of the device weight buffer (256-byte aligned pieces)
     std::vector<float> data;
     size_t add(const float* p, size_t n) {
@@ -1344,6 +1375,7 @@ int oww_commit(oww_ctx* h) {
                                         (L.cin % 16 == 8 || (OWH_KMERGE_MEL2 && l == 7 && OWH_WPS_C == 2) ||   // (l == 7: stage C layer a, 48 -> 72)
                                          (OWH_KMERGE_MEL2B && l == 5));                                   // (l == 5: stage B layer c, A/B switch)
                 if (l == 0) pack_hx_conv0(q, pk, &fold);
+                else if (l <= 2) pack_hx_stage_a(q, l, pk, &fold);
                 else if (time_merged || mel_merged) pack_hx_tm(q, L.cin, L.cout, pk, &fold);
                 else pack_hx(q, 3, L.cin, L.cout, pk, &fold, OWH_REM2 && !OWH_KMERGE_B && !OWH_KMERGE_MEL2B && l >= 4 && l <= 6);     // (stage B layers b, c, d)
                 if (!(fold.absmax < 65000.0))

@@ -43,8 +43,8 @@ struct MelAParams {
 };
 
 // LDS layout (floats)
-constexpr int FA_W0 = 2 * 256, FA_W12 = 2 * 3 * 2 * 256, FA_BN = 3 * 2 * 32, FA_MT = owh::sa::WAVE_HALVES / 2, FA_Z = 2 * 576, FA_GT = 512;
-constexpr int FA_OFF_W0 = 0, FA_OFF_W1 = FA_OFF_W0 + FA_W0, FA_OFF_W2 = FA_OFF_W1 + FA_W12, FA_OFF_BN = FA_OFF_W2 + FA_W12;
+constexpr int FA_W0 = 2 * 256, FA_W1 = 12 * 256, FA_W2 = 14 * 256, FA_BN = 3 * 2 * 32, FA_MT = owh::sa::WAVE_HALVES / 2, FA_Z = 2 * 576, FA_GT = 512;
+constexpr int FA_OFF_W0 = 0, FA_OFF_W1 = FA_OFF_W0 + FA_W0, FA_OFF_W2 = FA_OFF_W1 + FA_W1, FA_OFF_BN = FA_OFF_W2 + FA_W2;
 constexpr int FA_OFF_HANN = FA_OFF_BN + FA_BN, FA_OFF_TW1 = FA_OFF_HANN + 512, FA_OFF_TW2 = FA_OFF_TW1 + 2 * 8 * 64;
 constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16 * 32, FA_OFF_GT = FA_OFF_MS + 32, FA_OFF_MEL = FA_OFF_GT + FA_GT;
 constexpr int FA_OFF_Z = FA_OFF_MEL + FA_WG * FA_MT + ((4 - (FA_WG * FA_MT) % 4) % 4);
@@ -89,10 +89,8 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
     float* t_taps = fl + FA_OFF_TAPS;
     int* s_ms = reinterpret_cast<int*>(fl + FA_OFF_MS);
     for (int i = tid; i < FA_W0 / 4; i += NT) reinterpret_cast<f32x4*>(sW0)[i] = reinterpret_cast<const f32x4*>(q.a.w0)[i];
-    for (int i = tid; i < FA_W12 / 4; i += NT) {
-        reinterpret_cast<f32x4*>(sW1)[i] = reinterpret_cast<const f32x4*>(q.a.w1)[i];
-        reinterpret_cast<f32x4*>(sW2)[i] = reinterpret_cast<const f32x4*>(q.a.w2)[i];
-    }
+    for (int i = tid; i < FA_W1 / 4; i += NT) reinterpret_cast<f32x4*>(sW1)[i] = reinterpret_cast<const f32x4*>(q.a.w1)[i];
+    for (int i = tid; i < FA_W2 / 4; i += NT) reinterpret_cast<f32x4*>(sW2)[i] = reinterpret_cast<const f32x4*>(q.a.w2)[i];
     if (tid < 96) {
         const int l = tid / 32, c = tid % 32;
         sbn[(l * 2 + 0) * 32 + c] = q.a.scale[l][c];

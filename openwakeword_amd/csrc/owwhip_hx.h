@@ -1111,13 +1111,12 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
         }
         // ---- conv1: 1x3 over the row's two parity tiles (see the header of this section)
         f32x4 Y1[4][2];
-#pragma unroll
-        for (int oct = 0; oct < 2; ++oct) {
-            const f32x4 I = acc_init(bn + 96, oct, j);
+        {   // channel tile 0 (16 channels): per output tile one main chain (start value + two taps) and one side chain (one tap)
+            const f32x4 I = acc_init(bn + 96, 0, j);
             const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 sd[4], mn[4];                   // side chain / main chain of output tile t
+            f32x4 sd[4], mn[4];
             {   // tap 0: W0 X_T1 -> side of T0 (enters shifted right), W0 X_T0 -> main of T1
-                const f16x8 ah = lds_h(w1s, (oct * 3 + 0) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + 0) * 2 + 1, lane);
+                const f16x8 ah = lds_h(w1s, 0, lane), al = lds_h(w1s, 1, lane);
                 sd[0] = OWH_MFMA(ah, Y0o[1][0].h, Z); mn[1] = OWH_MFMA(ah, Y0o[0][0].h, I);
                 sd[2] = OWH_MFMA(ah, Y0o[3][0].h, Z); mn[3] = OWH_MFMA(ah, Y0o[2][0].h, I);
                 sd[0] = OWH_MFMA(ah, Y0o[1][0].l, sd[0]); mn[1] = OWH_MFMA(ah, Y0o[0][0].l, mn[1]);
@@ -1126,7 +1125,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
                 sd[2] = OWH_MFMA(al, Y0o[3][0].h, sd[2]); mn[3] = OWH_MFMA(al, Y0o[2][0].h, mn[3]);
             }
             {   // tap 2: W2 X_T0 -> side of T1 (enters shifted left), W2 X_T1 -> main of T0
-                const f16x8 ah = lds_h(w1s, (oct * 3 + 2) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + 2) * 2 + 1, lane);
+                const f16x8 ah = lds_h(w1s, 4, lane), al = lds_h(w1s, 5, lane);
                 sd[1] = OWH_MFMA(ah, Y0o[0][0].h, Z); mn[0] = OWH_MFMA(ah, Y0o[1][0].h, I);
                 sd[3] = OWH_MFMA(ah, Y0o[2][0].h, Z); mn[2] = OWH_MFMA(ah, Y0o[3][0].h, I);
                 sd[1] = OWH_MFMA(ah, Y0o[0][0].l, sd[1]); mn[0] = OWH_MFMA(ah, Y0o[1][0].l, mn[0]);
@@ -1135,7 +1134,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
                 sd[3] = OWH_MFMA(al, Y0o[2][0].h, sd[3]); mn[2] = OWH_MFMA(al, Y0o[3][0].h, mn[2]);
             }
             {   // tap 1: the centre tap of every tile
-                const f16x8 ah = lds_h(w1s, (oct * 3 + 1) * 2 + 0, lane), al = lds_h(w1s, (oct * 3 + 1) * 2 + 1, lane);
+                const f16x8 ah = lds_h(w1s, 2, lane), al = lds_h(w1s, 3, lane);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) mn[t] = OWH_MFMA(ah, Y0o[t][0].h, mn[t]);
 #pragma unroll
@@ -1147,13 +1146,45 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
             for (int t = 0; t < 4; ++t) {
                 f32x4 r;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (oct == 1 && e >= 2) { r[e] = 0.f; continue; }
-                    r[e] = mn[t][e] + ((t & 1) ? dpp_shl1_zero(sd[t][e]) : dpp_shr1_zero(sd[t][e]));
-                }
-                if (oct == 0) nan_guard(bad, r[0]);
-                if (oct == 1) { Y1[t][oct] = act_t<true, true>(r, p.clampv[1]); pin_t<true>(Y1[t][oct]); }
-                else { Y1[t][oct] = act_t<true, false>(r, p.clampv[1]); pin_t<false>(Y1[t][oct]); }
+                for (int e = 0; e < 4; ++e) r[e] = mn[t][e] + ((t & 1) ? dpp_shl1_zero(sd[t][e]) : dpp_shr1_zero(sd[t][e]));
+                nan_guard(bad, r[0]);
+                Y1[t][0] = act_t<true, false>(r, p.clampv[1]); pin_t<false>(Y1[t][0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {   // channel tile 1 (8 channels in registers 0, 1): the side chain rides in the tile's free registers 2, 3 -- the weight
+            // blocks stack two taps in M (pack_hx_stage_a: (W2 | W0) for T0, (W0 | W2) for T1, (W1 | 0) for the centre tap), so a
+            // tile costs six MFMAs instead of nine
+            const f32x4 I = acc_init(bn + 96, 1, j);
+            const f32x4 I2 = {I[0], I[1], 0.f, 0.f};
+            f32x4 Q[4];
+            {
+                const f16x8 ah = lds_h(w1s, 6, lane), al = lds_h(w1s, 7, lane);          // (W2 | W0) against X_T1 -> T0
+                Q[0] = OWH_MFMA(ah, Y0o[1][0].h, I2); Q[2] = OWH_MFMA(ah, Y0o[3][0].h, I2);
+                Q[0] = OWH_MFMA(ah, Y0o[1][0].l, Q[0]); Q[2] = OWH_MFMA(ah, Y0o[3][0].l, Q[2]);
+                Q[0] = OWH_MFMA(al, Y0o[1][0].h, Q[0]); Q[2] = OWH_MFMA(al, Y0o[3][0].h, Q[2]);
+            }
+            {
+                const f16x8 ah = lds_h(w1s, 10, lane), al = lds_h(w1s, 11, lane);        // (W0 | W2) against X_T0 -> T1
+                Q[1] = OWH_MFMA(ah, Y0o[0][0].h, I2); Q[3] = OWH_MFMA(ah, Y0o[2][0].h, I2);
+                Q[1] = OWH_MFMA(ah, Y0o[0][0].l, Q[1]); Q[3] = OWH_MFMA(ah, Y0o[2][0].l, Q[3]);
+                Q[1] = OWH_MFMA(al, Y0o[0][0].h, Q[1]); Q[3] = OWH_MFMA(al, Y0o[2][0].h, Q[3]);
+            }
+            {
+                const f16x8 ah = lds_h(w1s, 8, lane), al = lds_h(w1s, 9, lane);          // (W1 | 0): the centre tap
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Q[t] = OWH_MFMA(ah, Y0o[t][0].h, Q[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Q[t] = OWH_MFMA(ah, Y0o[t][0].l, Q[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Q[t] = OWH_MFMA(al, Y0o[t][0].h, Q[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) r[e] = Q[t][e] + ((t & 1) ? dpp_shl1_zero(Q[t][e + 2]) : dpp_shr1_zero(Q[t][e + 2]));
+                Y1[t][1] = act_t<true, true>(r, p.clampv[1]); pin_t<true>(Y1[t][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1166,15 +1197,14 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
         for (int t = 0; t < 4; ++t) to_ops<2, true>(Y1[t], Y1o[t]);
         // ---- conv2: 3x1 over [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1], then pool 2x2 (same lane of the four tiles), then the activation
         f32x4 PA[2];
-#pragma unroll
-        for (int oct = 0; oct < 2; ++oct) {
-            const f32x4 I = acc_init(bn + 160, oct, j);
+        {   // channel tile 0
+            const f32x4 I = acc_init(bn + 160, 0, j);
             f32x4 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = I;
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const f16x8 ah = lds_h(w2s, (oct * 3 + tap) * 2 + 0, lane), al = lds_h(w2s, (oct * 3 + tap) * 2 + 1, lane);
+                const f16x8 ah = lds_h(w2s, tap * 2 + 0, lane), al = lds_h(w2s, tap * 2 + 1, lane);
 #pragma unroll
                 for (int part = 0; part < 3; ++part)
 #pragma unroll
@@ -1184,32 +1214,58 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
                         acc[t] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, acc[t]);
                     }
             }
-            if (oct == 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
-            }
+            for (int t = 0; t < 4; ++t) nan_guard(bad, acc[t][0]);
             if (DBG && p.dbg) {
+                const int pos = lane & 15;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    f32x4 y[2] = {};
-                    y[oct] = oct == 1 ? act_t<true, true>(acc[t], p.clampv[2]) : act_t<true, false>(acc[t], p.clampv[2]);
-                    const int pos = lane & 15;
+                    const f32x4 y = act_t<true, false>(acc[t], p.clampv[2]);
 #pragma unroll
-                    for (int e = 0; e < (oct == 1 ? 2 : 4); ++e) {
-                        const int c = oct == 0 ? 4 * j + e : 16 + 2 * j + e;
-                        if (s < p.S) p.dbg[(size_t)s * p.dbg_stride + p.dbg_off[2] + ((2 * q + (t >> 1)) * 32 + 2 * pos + (t & 1)) * 24 + c] = y[oct][e] * p.dbg_mul[2];
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (s < p.S) p.dbg[(size_t)s * p.dbg_stride + p.dbg_off[2] + ((2 * q + (t >> 1)) * 32 + 2 * pos + (t & 1)) * 24 + 4 * j + e] = y[e] * p.dbg_mul[2];
                 }
             }
             f32x4 m;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (oct == 1 && e >= 2) { m[e] = 0.f; continue; }
-                m[e] = fmax_nc(fmax_nc(acc[0][e], acc[1][e]), fmax_nc(acc[2][e], acc[3][e]));
+            for (int e = 0; e < 4; ++e) m[e] = fmax_nc(fmax_nc(acc[0][e], acc[1][e]), fmax_nc(acc[2][e], acc[3][e]));
+            m = act_t<true, false>(m, p.clampv[2]);
+            PA[0] = m * p.xmul;                   // stage B's input scale (calibrate_hx's ladder)
+            pin_t<false>(PA[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {   // channel tile 1 (8 channels): the two output rows of the pair share one accumulator tile per parity -- registers 0, 1 =
+            // row 2q, registers 2, 3 = row 2q+1 -- and the weight blocks stack the two rows' taps in M (pack_hx_stage_a: input row i of
+            // [Yh0, Yh1, Y1 row 2q, Y1 row 2q+1] meets (W_i | W_{i-1})): 12 MFMAs per parity instead of 18
+            const f32x4 I = acc_init(bn + 160, 1, j);
+            f32x4 Q[2] = {f32x4{I[0], I[1], I[0], I[1]}, f32x4{I[0], I[1], I[0], I[1]}};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 ah = lds_h(w2s, 6 + i * 2 + 0, lane), al = lds_h(w2s, 6 + i * 2 + 1, lane);
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const Op& b = i < 2 ? Yh[i][h] : Y1o[(i - 2) * 2 + h][0];
+                        Q[h] = OWH_MFMA(part == 2 ? al : ah, part == 1 ? b.l : b.h, Q[h]);
+                    }
             }
-            m = oct == 1 ? act_t<true, true>(m, p.clampv[2]) : act_t<true, false>(m, p.clampv[2]);
-            PA[oct] = m * p.xmul;                 // stage B's input scale (calibrate_hx's ladder)
-            if (oct == 1) pin_t<true>(PA[oct]); else pin_t<false>(PA[oct]);
+            if (DBG && p.dbg) {
+                const int pos = lane & 15;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 y = act_t<true, false>(Q[h], p.clampv[2]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (s < p.S) p.dbg[(size_t)s * p.dbg_stride + p.dbg_off[2] + ((2 * q + (e >> 1)) * 32 + 2 * pos + h) * 24 + 16 + 2 * j + (e & 1)] = y[e] * p.dbg_mul[2];
+                }
+            }
+            f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) m[e] = fmax_nc(fmax_nc(Q[0][e], Q[0][e + 2]), fmax_nc(Q[1][e], Q[1][e + 2]));
+            m = act_t<true, true>(m, p.clampv[2]);
+            PA[1] = m * p.xmul;
+            pin_t<true>(PA[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1246,15 +1302,13 @@ __global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p
 
     // weights: conv0 [2 oct] K-folded blocks (2 KB), conv1 / conv2 [2 oct][3 taps][part 2] (12 KB each); start values; planes; gather table
     __shared__ __attribute__((aligned(16))) float sW0[2 * 256];
-    __shared__ __attribute__((aligned(16))) float sW[2][2 * 3 * 2 * 256];
+    __shared__ __attribute__((aligned(16))) float sW[2][14 * 256];     // conv1: 12 blocks, conv2: 14 (pack_hx_stage_a)
     __shared__ __attribute__((aligned(16))) float sbn[3][2][32];
     __shared__ __attribute__((aligned(16))) _Float16 sPl[4][sa::WAVE_HALVES];
     __shared__ __attribute__((aligned(16))) int gtab[512];
     for (int i = threadIdx.x; i < 2 * 64; i += 256) reinterpret_cast<f32x4*>(sW0)[i] = reinterpret_cast<const f32x4*>(p.w0)[i];
-    for (int i = threadIdx.x; i < 2 * 3 * 2 * 64; i += 256) {
-        reinterpret_cast<f32x4*>(sW[0])[i] = reinterpret_cast<const f32x4*>(p.w1)[i];
-        reinterpret_cast<f32x4*>(sW[1])[i] = reinterpret_cast<const f32x4*>(p.w2)[i];
-    }
+    for (int i = threadIdx.x; i < 12 * 64; i += 256) reinterpret_cast<f32x4*>(sW[0])[i] = reinterpret_cast<const f32x4*>(p.w1)[i];
+    for (int i = threadIdx.x; i < 14 * 64; i += 256) reinterpret_cast<f32x4*>(sW[1])[i] = reinterpret_cast<const f32x4*>(p.w2)[i];
     if (threadIdx.x < 96) {
         const int l = threadIdx.x / 32, c = threadIdx.x % 32;
         sbn[l][0][c] = p.scale[l][c];

@@ -371,7 +371,6 @@ class StreamEngine:
         _lib.check(rc)
         return False
 
-    @property
     def range_where(self):
         """(first_stream, n_streams) of a wave that saw the out-of-range value behind OwwRangeError -- the offender is among these
         streams -- or (-1, 0) when the flag is down / the position is unknown (include/owwhip.h: oww_range_where)."""
@@ -379,6 +378,7 @@ class StreamEngine:
         _lib.check(self._lib.oww_range_where(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    @property
     def scores_dev_ptr(self) -> int:
         return int(self._lib.oww_scores_dev(self._h) or 0)
 
