@@ -318,7 +318,7 @@ template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ init, float cl, int wave, int lane,
-                                            lanemask_t& bad) {
+                                            lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
     // (interleaved order: the row shift by SH = 16 / F lanes zero-fills exactly the stream-edge lanes and the masks are not used)
@@ -328,8 +328,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
         if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
         f32x4 res[NT], accs[2][NT];
@@ -442,15 +442,15 @@ template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_
 __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], float* wbuf,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
-                                             lanemask_t& bad) {
+                                             lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int SH = 16 / F, KSF = KSI - 1;
     constexpr int NBLK = (3 * KSF + NMK) * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
+        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
         if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
         f32x4 res[NT], accs[2][NT];
@@ -523,7 +523,7 @@ template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = O
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
-                                             lanemask_t& bad) {
+                                             lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = 3 * KSI * 2;
@@ -532,8 +532,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
     for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
         if (oct < NCTO) {
-            const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+            const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
+            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
             if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
             else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);           // folded BatchNorm shift = the chain's start value
@@ -652,7 +652,7 @@ template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, i
 __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1)[KSF], const Op (&in)[NR][KSF], const Op (&M)[NR][NMK],
                                               f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                               const float* __restrict__ init, float cl, int wave, int lane,
-                                              lanemask_t& bad) {
+                                              lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = (3 * KSF + NMK) * 2;
@@ -661,8 +661,8 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
     for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
         if (oct < NCTO) {
-            const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+            const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
+            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
             if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
             else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);
@@ -728,6 +728,32 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
 #ifndef OWH_KMERGE_MEL2B
 #define OWH_KMERGE_MEL2B 0     // layer c of stage B (48 -> 48) in the same form: see DESIGN.md 5.2 for the measurement
 #endif
+#ifndef OWH_HIST_LDS
+#define OWH_HIST_LDS 1
+#endif
+#ifndef OWH_HIST_LDS_C
+#define OWH_HIST_LDS_C 0       // stage C too: measured +1.5 % on C (same box: 1.496 -> 1.520 ms) against -2.5 % on B (1.378 -> 1.345)
+#endif
+// NBLK KB of a wave's own history block, HBM -> LDS (linear image: register-dump rows of 256 B, four rows per DMA instruction)
+template <int NBLK>
+__device__ __forceinline__ void issue_hist(const float* __restrict__ gsrc, float* ldst, int lane) {
+    const float* base = owr::uniform_ptr(gsrc);
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + i * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(ldst + i * 256), 16, 0, 0);
+}
+template <int NCT, bool HALF>
+__device__ __forceinline__ void load_tile_lds(f32x4 (&t)[NCT], const float* base, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (HALF && ct == NCT - 1 && e >= 2) t[ct][e] = 0.f;
+            else t[ct][e] = base[(ct * 4 + e) * 64 + lane];
+        }
+}
+
 template <class C, bool LAST, bool DBG, int WG = OWH_WG>
 __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
@@ -735,7 +761,6 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
     constexpr int KSA = (NCTI + 1) / 2, KS = (NCT + 1) / 2;          // k-steps per tap: first layer / other layers
     constexpr int NBA = 3 * KSA * 2, NB = 3 * KS * 2;                // 1 KB blocks per chunk
-    static_assert(NB * 256 <= WBUF_FLOATS, "chunk fits the LDS buffer");
     using TK = TimeK<NCT, C::HOUT>;
     constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
     constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
@@ -750,11 +775,23 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     constexpr bool MMC = (OWH_KMERGE_MEL && kInterleave && C::HOUT && NCT % 2 == 1 && NCT >= 3) || MMC2;
     constexpr int NPRC = MMC2 ? 2 : 1, NMKC = (3 * NPRC + 3) / 4;
     constexpr int NBAM = MMA ? (3 * (KSA - 1) + NMKA) * 2 : NBA, NBCM = MMC ? (3 * (KS - 1) + NMKC) * 2 : NB;
+    // the largest weight chunk of THIS stage (blocks of 256 floats): the double buffer is sized per stage, so that stages B and C have
+    // LDS left for their conv histories (below)
+    constexpr int NBMAX = (NBAM > NBT ? NBAM : NBT) > (NBCM > (LAST ? NB : 0) ? NBCM : (LAST ? NB : 0)) ? (NBAM > NBT ? NBAM : NBT) : (NBCM > (LAST ? NB : 0) ? NBCM : (LAST ? NB : 0));
+    constexpr int WBS = NBMAX * 256;
+    // HLDS: the two history rows of each 3x1 layer are fetched HBM -> LDS by the DMA path (global_load_lds: no VGPRs, one pass
+    // through the L2 -> CU path) while the preceding 1x3 layer computes, instead of by register loads at the layer boundary where
+    // their latency is exposed with only 2-3 waves per SIMD.  Stage B: 6 KB per wave, -2.5 % (same-box A/B); stage C (10 KB per wave,
+    // OWH_HIST_LDS_C) measured slower; D and E have no LDS left for it at three workgroups per CU.
+    constexpr bool HLDS = OWH_HIST_LDS && !LAST && C::NPASS == 1 && (C::SPT == 1 || (C::SPT == 2 && OWH_HIST_LDS_C));
+    constexpr int HROW = NCT * 4 * 64;                                // floats of one history row of a wave's group
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
-    __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float wbuf[2 * WBS];
     __shared__ __attribute__((aligned(16))) float sbn[4][NCT * 16];      // per layer: K * BatchNorm shift in tile row order = accumulator start values
+    __shared__ __attribute__((aligned(16))) float hlds[HLDS ? WG * 2 * HROW : 4];
+    float* const hl = hlds + (HLDS ? wave * 2 * HROW : 0);
     const bool active = g < p.n_groups;
     if (!active) g = p.n_groups - 1;
     if (p.glist) g = p.glist[g];          // a masked step with few participants runs only the groups that hold one (owwhip.hip: build_active_lists)
@@ -771,6 +808,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const bool lane_on = active && (p.stream_on == nullptr || p.stream_on[min(s_first + tile_stream<F>(lane & 15), p.S - 1)] != 0);
     float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
     float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
+    if (HLDS) issue_hist<2 * NCT>(hb, hl, lane);                      // lands before the first chunk_sync (vmcnt(0)) at the latest
 
 #pragma unroll
     for (int pass = 0; pass < C::NPASS; ++pass) {
@@ -788,9 +826,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMA) {
         Op Mx[R][NMKA];
         merge_mel_rems<KSA, R, F, NPRA>(Xo, Mx);
-        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
+        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, WBS);
     } else
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, WBS);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane, p.dbg_mul[0]);
@@ -802,11 +840,12 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         RemPairs rem[R + 2];
         {
             f32x4 T0[NCT], T1[NCT];
-            load_tile_h<NCT, C::HOUT>(T0, hb, lane);
-            load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane);
+            if (HLDS) { load_tile_lds<NCT, C::HOUT>(T0, hl, lane); load_tile_lds<NCT, C::HOUT>(T1, hl + HROW, lane); }
+            else { load_tile_h<NCT, C::HOUT>(T0, hb, lane); load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane); }
             to_ops_time<NCT, C::HOUT>(T0, H0F, rem[0]);
             to_ops_time<NCT, C::HOUT>(T1, H1F, rem[1]);
         }
+        if (HLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_hist<2 * NCT>(hd, hl, lane); }   // the slot is free again: conv d's history flies during conv b and c
         if (lane_on) {
             store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
             store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
@@ -815,15 +854,16 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, WBS);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
-        load_tile_h<NCT, C::HOUT>(T0, hb, lane);
-        load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane);
+        if (HLDS) { load_tile_lds<NCT, C::HOUT>(T0, hl, lane); load_tile_lds<NCT, C::HOUT>(T1, hl + HROW, lane); }
+        else { load_tile_h<NCT, C::HOUT>(T0, hb, lane); load_tile_h<NCT, C::HOUT>(T1, hb + NCT * 4 * 64, lane); }
         to_ops<NCT, C::HOUT, REM2>(T0, H0);
         to_ops<NCT, C::HOUT, REM2>(T1, H1);
     }
+    if (HLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_hist<2 * NCT>(hd, hl, lane); }
     if (lane_on) {
         store_tile_h<NCT, C::HOUT>(Y[R - 2], hb, lane);
         store_tile_h<NCT, C::HOUT>(Y[R - 1], hb + NCT * 4 * 64, lane);
@@ -832,7 +872,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, WBS);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -845,9 +885,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMC) {
         Op Mc[R][NMKC];
         merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
-        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
+        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, WBS);
     } else
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, WBS);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
@@ -858,8 +898,8 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         RemPairs rem[R + 2];
         {
             f32x4 T0[NCT], T1[NCT];
-            load_tile_h<NCT, C::HOUT>(T0, hd, lane);
-            load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane);
+            if (HLDS) { load_tile_lds<NCT, C::HOUT>(T0, hl, lane); load_tile_lds<NCT, C::HOUT>(T1, hl + HROW, lane); }
+            else { load_tile_h<NCT, C::HOUT>(T0, hd, lane); load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane); }
             to_ops_time<NCT, C::HOUT>(T0, H0F, rem[0]);
             to_ops_time<NCT, C::HOUT>(T1, H1F, rem[1]);
         }
@@ -871,12 +911,12 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad, WBS);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
-        load_tile_h<NCT, C::HOUT>(T0, hd, lane);
-        load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane);
+        if (HLDS) { load_tile_lds<NCT, C::HOUT>(T0, hl, lane); load_tile_lds<NCT, C::HOUT>(T1, hl + HROW, lane); }
+        else { load_tile_h<NCT, C::HOUT>(T0, hd, lane); load_tile_h<NCT, C::HOUT>(T1, hd + NCT * 4 * 64, lane); }
         to_ops<NCT, C::HOUT, REM2>(T0, H0);
         to_ops<NCT, C::HOUT, REM2>(T1, H1);
     }
@@ -888,7 +928,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad, WBS);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -952,7 +992,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         to_ops<NCT>(Pl, Po[0]);
         f32x4 E[1][NCT];
         // (no guard here: an out-of-range input of conv19 yields a NaN embedding, which the heads kernel's guard reports)
-        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, 0.f, wave, lane, bad);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, 0.f, wave, lane, bad, WBS);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
         const bool on19 = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (pos & 7), p.S - 1)] != 0);   // lanes 8..15 mirror 0..7
         if (on19) {
             store_tile<NCT>(T1, h19, lane);
