@@ -519,6 +519,9 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #ifndef OWH_PIPE_VALU
 #define OWH_PIPE_VALU 2
 #endif
+#ifndef OWH_PIPE_M
+#define OWH_PIPE_M 0       // the same interleave hint in the K-merged time layers (stage C): same-box A/B 1.555 -> 1.525 ms WITHOUT it
+#endif
 template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0, bool REM2 = false>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
@@ -705,7 +708,7 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
                 else { out[r][oct - 1] = act_t<BN, false>(prev[r], cl); pin_t<false>(out[r][oct - 1]); }
             }
         }
-#if OWH_PIPE
+#if OWH_PIPE_M
         if (oct > 0 && oct < NCTO) {
 #pragma unroll
             for (int i = 0; i < 3 * (3 * KSF + NMK) * NR; ++i) {
