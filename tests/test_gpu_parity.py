@@ -294,6 +294,30 @@ def test_large_batch_properties(emb, heads):
         small.close()
 
 
+def test_block_pipelined_step_is_bit_identical(emb, heads, monkeypatch):
+    """OWW_BLOCKS=3: the fused one-chunk step launched as three stream blocks on internal HIP streams (off by default: measured no
+    faster) must give exactly the scores of the single-launch step, also through a dense masked step."""
+    S = 16384 + 96                                                  # (block borders at multiples of 128, a ragged last block)
+    pcm = W.synthetic_pcm(S, 1280 * 7, seed=72)
+    on = (np.random.default_rng(3).random(S) < 0.8).astype(np.uint8)
+    monkeypatch.delenv("OWW_BLOCKS", raising=False)
+    one = StreamEngine(S, heads, emb)
+    monkeypatch.setenv("OWW_BLOCKS", "3")
+    three = StreamEngine(S, heads, emb)
+    try:
+        for t in range(7):
+            x = np.ascontiguousarray(pcm[:, 1280 * t: 1280 * (t + 1)])
+            if t == 5:
+                a, b = one.step_masked(x, on), three.step_masked(x, on)
+            else:
+                a, b = one.step(x), three.step(x)
+            np.testing.assert_array_equal(a, b)
+        assert a.max() > 0
+    finally:
+        one.close()
+        three.close()
+
+
 def test_host_fed_pipeline_matches_blocking_steps(emb, heads):
     """oww_submit / oww_collect (upload of step t+1 overlapping the kernels of step t, two steps in flight) deliver
     exactly the scores of the blocking oww_step sequence, post-processing included; order errors are reported."""
