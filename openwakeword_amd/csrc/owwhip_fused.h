@@ -10,7 +10,8 @@
 //   4 passes x (fetch 672 int16 samples of [480-sample tail ; 1280 new] -> Hann(400) -> one complex 512-point FFT of two frames,
 //   radix-8 x 3 through the wave's own LDS planes -> |.|^2 of bins 2..121 -> sparse mel -> 10 log10) -> per-call maximum over the
 //   8 x 32 values (wave reduction) -> clamp at max - 80 dB, x/10 + 2, first-call masking (utils.py:180-208, 387-401; the same
-//   arithmetic and operation order as owk::mel_kernel) -> rows 2..9 of the wave's mel tile -> owh::hstageA_stream.
+//   arithmetic and operation order as owk::mel_kernel) -> rows 2..9 of the wave's two f16 planes (hi / lo halves of every mel value,
+//   split once here: conv0 gathers its operands from them as halves) -> owh::hstageA_stream.
 // Twiddles, window and the sparse filter bank live in LDS (shared by the 12 waves of the workgroup) instead of 48 registers per
 // lane, so that the register budget of stage A (3 waves per SIMD) is untouched.  Streaming steps of one chunk only; multi-chunk
 // calls, clip embedding and the other kernel families keep the separate mel kernel.
@@ -151,8 +152,12 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         const int16_t* tail_row = q.tail + (size_t)s * 480;
         const int16_t* pcm_row = q.pcm + (size_t)s * 1280;
         fetch_pass(tail_row, pcm_row, 0, lane, raw);
+#ifdef OWF_EXP_NOMEL              // (timing experiment only: one FFT pass instead of four -> what the mel phase costs)
+        for (int f2 = 0; f2 < 1; ++f2) {
+#else
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
+#endif
             wave_sync();                         // the previous pass's readers of the planes / power rows are done (same wave)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
