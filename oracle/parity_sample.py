@@ -87,12 +87,33 @@ def _worker(args) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     return out, feats0, last
 
 
+def effective_cpus() -> int:
+    """CPUs this process can actually use: the affinity mask, capped by a cgroup CPU quota when one is set (a container may see 256
+    CPUs and own eight of them -- forking 64 workers there is what makes a run crawl)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def _run_pool(pcm: np.ndarray, head_names: List[str], workers: int) -> Dict[str, np.ndarray]:
     n = pcm.shape[0]
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = effective_cpus()
     workers = max(1, min(workers or cores, n, 64))
     parts = [list(range(w, n, workers)) for w in range(workers)]
     jobs = [([pcm[i] for i in idx], head_names) for idx in parts]
@@ -126,8 +147,10 @@ def oracle_reference(n_probe: int = N_PROBE, n_frames: int = N_FRAMES, head_name
     if not os.path.exists(path):
         root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         tmp = path + f".{os.getpid()}.tmp.npz"
+        # one BLAS thread per forked worker: the workers already cover the cores (an unbounded pool per worker oversubscribes the host)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         subprocess.run([sys.executable, "-m", "oracle.parity_sample", tmp, str(n_probe), str(n_frames), str(workers)] + head_names,
-                       cwd=root, check=True, timeout=timeout_s)
+                       cwd=root, check=True, timeout=timeout_s, env=env)
         os.replace(tmp, path)
     z = np.load(path)
     return {k: z[k] for k in z.files}

@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_blas_threads():
+    """The oracle is numpy / torch-CPU code.  On a 256-CPU GPU box an unbounded BLAS pool per process (and per forked oracle worker)
+    oversubscribes the host badly when the box is shared; eight threads are plenty for the small matrices involved."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        yield
+        return
+    with threadpool_limits(limits=8):
+        yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
