@@ -73,7 +73,12 @@ def physical_cores():
 def run(head_names, budget_s: float = 12.0, max_workers: int | None = None, batch: int = 4) -> dict:
     head_names = list(head_names)
     firsts, logical = physical_cores()
-    workers = max(1, min(len(firsts), max_workers or len(firsts)))
+    # a container may SEE every CPU of the host and own a fraction of them (cgroup quota: the GPU boxes of this pool show 256 CPUs
+    # and a quota of 16): more workers than that only share the quota -- round 2's "80 frames/s per core on 128 cores" was exactly
+    # that, 16 CPUs' worth of work spread over 128 processes
+    from .parity_sample import effective_cpus
+    quota = effective_cpus()
+    workers = max(1, min(len(firsts), quota, max_workers or len(firsts)))
     ctx = mp.get_context("fork")
     t_single = max(2.0, budget_s * 0.3)
     t_all = max(2.0, budget_s - t_single)
@@ -87,10 +92,11 @@ def run(head_names, budget_s: float = 12.0, max_workers: int | None = None, batc
             "per_core": round(frames / wall / workers, 1),
             "single_process": {"value": round(n1 / w1, 1), "unit": "frames/s", "cores": 1,
                                "sample": f"{n1} frames in {w1:.1f} s, one single-threaded process alone on the host"},
-            "host": {"logical_cpus": logical, "physical_cores": len(firsts), "workers": workers,
-                     "pinning": "one worker per physical core (first SMT sibling), SMT siblings idle"},
+            "host": {"logical_cpus": logical, "physical_cores": len(firsts), "cpu_quota": quota, "workers": workers,
+                     "pinning": "one worker per physical core (first SMT sibling), SMT siblings idle; never more workers than the "
+                                "container's CPU quota"},
             "survey_probe_per_core": SURVEY_PER_CORE_PROBE,
-            "sample": f"{frames} frames in {wall:.1f} s: {workers} single-threaded processes (one per physical core of "
-                      f"{logical} logical CPUs) x {batch} streams each, the reference's algorithm (257-bin DFT mel, FULL 76x32 window "
+            "sample": f"{frames} frames in {wall:.1f} s: {workers} single-threaded processes (one per usable core: {len(firsts)} physical cores "
+                      f"visible, CPU quota {quota}) x {batch} streams each, the reference's algorithm (257-bin DFT mel, FULL 76x32 window "
                       f"through the 20-layer CNN every frame, {len(head_names)} heads) as a torch-CPU/oneDNN port "
                       "(oracle/oww_oracle_torch.py); onnxruntime and the .onnx model files are not available offline"}

@@ -39,7 +39,8 @@ def _cpu_worker(args):
 
 
 def cpu_baseline(n, budget_s):
-    cores = len(os.sched_getaffinity(0))
+    from oracle.parity_sample import effective_cpus
+    cores = effective_cpus()               # (the affinity mask capped by the container's CPU quota)
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(50 + i, budget_s, n) for i in range(cores)])
     clips, wall = sum(r[0] for r in res), max(r[1] for r in res)
