@@ -78,7 +78,15 @@ int  oww_destroy(oww_ctx* h);
 int  oww_load_mel(oww_ctx* h, const void* blob, size_t nbytes);
 int  oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes);
 int  oww_add_head(oww_ctx* h, const void* blob, size_t nbytes);     /* returns head index >= 0 */
-int  oww_commit(oww_ctx* h);          /* pack + upload, allocate state, derive reset state; then reset all */
+/* oww_commit: pack + upload, allocate state, derive reset state, then reset all.  For the default kernel family (use_mfma = 3) it also
+ * (1) calibrates: a scratch handle of the exact-fp32 family runs the all-ones mel history and 32 probe streams x 16 frames (silence,
+ *     noise RMS 30..32767, full-scale square waves) on the same weights; from every layer's largest |activation| each layer gets a
+ *     power-of-two scale under which its f16-split operands keep full precision, and BatchNorm is folded into the packed weights;
+ * (2) self-tests: the probes are replayed on the f16-split kernels and embeddings / raw head outputs compared with the fp32 run.
+ * Weights the split cannot carry within the north-star tolerance (1e-3) -- the reference's fp32 graphs have no such limit,
+ * utils.py:84-93 -- are REFUSED here with OWW_ERANGE (message names the deviation; use use_mfma = 1 for them) instead of scoring
+ * differently later.  Adds ~0.05-0.3 s to the call.  (OWW_NO_COMMIT_SELFTEST=1 in the environment skips step (2): development only.) */
+int  oww_commit(oww_ctx* h);
 int  oww_n_labels(const oww_ctx* h);  /* total score columns = sum of n_out over heads */
 
 /* ---- per-stream state (AudioFeatures.reset utils.py:172-178 + Model.reset model.py:226-230) -----
