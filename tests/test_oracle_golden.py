@@ -166,3 +166,35 @@ def test_torch_cpu_port_matches_numpy_oracle(golden):
     for name, h in heads.items():
         f = feats[:, -h["T"]:]
         np.testing.assert_allclose(port.head(name, torch.from_numpy(f)).numpy(), O.head_stage(f, h), rtol=0, atol=2e-5)
+
+
+def test_mel_stage_matches_an_independent_stft(golden):
+    """The oracle's log-mel (two dense DFT matmuls) against an independent formulation of the same recipe:
+    torch.stft (n_fft 512, hop 160, periodic Hann(400) centred in the frame, center=False) -> |X|^2 -> the Slaney filterbank built
+    here from the closed-form triangle definition -> 10 log10 -> top_db clamp over the call.  Pins framing, window placement and
+    the bin <-> frequency mapping of the restatement to a library STFT (torchlibrosa's Spectrogram is a Conv1d form of the same)."""
+    torch = pytest.importorskip("torch")
+    clip = golden["pcm/hey_mycroft_test"].astype(np.float32)
+    x = clip[len(clip) // 3: len(clip) // 3 + 1280 * 3 + 480]
+    win = torch.hann_window(400, periodic=True, dtype=torch.float64)
+    X = torch.stft(torch.from_numpy(x.astype(np.float64)), n_fft=512, hop_length=160, win_length=400, window=win, center=False,
+                   return_complex=True)                                     # [257, F]; win_length < n_fft: the window is centre-padded
+    power = (X.real ** 2 + X.imag ** 2).T.numpy()                           # [F, 257]
+    # Slaney mel scale, slaney norm, 32 bands 60..3800 Hz, written from the definition (not the oracle's code path)
+    def hz2mel(f):
+        return np.where(f < 1000.0, f / (200.0 / 3.0), 15.0 + np.log(np.maximum(f, 1e-9) / 1000.0) / (np.log(6.4) / 27.0))
+    def mel2hz(m):
+        return np.where(m < 15.0, m * (200.0 / 3.0), 1000.0 * np.exp((m - 15.0) * (np.log(6.4) / 27.0)))
+    edges = mel2hz(np.linspace(hz2mel(np.array(60.0)), hz2mel(np.array(3800.0)), 34))
+    freqs = np.arange(257) * (16000.0 / 512.0)
+    fb = np.zeros((257, 32))
+    for i in range(32):
+        lo, ce, hi = edges[i], edges[i + 1], edges[i + 2]
+        tri = np.maximum(0.0, np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)))
+        fb[:, i] = tri * (2.0 / (hi - lo))
+    db = 10.0 * np.log10(np.maximum(power @ fb, 1e-10))
+    db = np.maximum(db, db.max() - 80.0)
+    got = O.mel_stage(x[None], np.float64)[0, 0]
+    assert got.shape == db.shape == ((len(x) - 512) // 160 + 1, 32)
+    np.testing.assert_allclose(got, db, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(O.mel_stage(x[None], np.float32)[0, 0], db, rtol=0, atol=2e-3)     # fp32 DFT of int16-scale audio
