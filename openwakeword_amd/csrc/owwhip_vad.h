@@ -234,8 +234,10 @@ __global__ __launch_bounds__(64 * V_WG, (V_WG + 3) / 4) void vad_front_kernel(Va
                 const int idx = it * 64 + lane, f = idx >> 7, kb = idx & 127, k = kb + 1;
                 const float zr_ = xr[f * 256 + k], zi_ = xi[f * 256 + k], yr_ = xr[f * 256 + 256 - k], yi_ = xi[f * 256 + 256 - k];
                 const float ar = zr_ + yr_, ai = zi_ - yi_, br = zi_ + yi_, bi = zr_ - yr_;
-                fa[it] = __logf(1.0f + p.mag_gain * 0.5f * sqrtf(ar * ar + ai * ai));
-                fb[it] = __logf(1.0f + p.mag_gain * 0.5f * sqrtf(br * br + bi * bi));
+                // (hardware v_sqrt_f32 / v_log_f32, 1 ulp each: the IEEE-exact sqrtf and the full logf expand to ~10 VALU instructions
+                //  apiece here -- a third of this kernel's instruction count -- for digits the 1e-4 score tolerance never sees)
+                fa[it] = __builtin_amdgcn_logf(1.0f + p.mag_gain * 0.5f * __builtin_amdgcn_sqrtf(ar * ar + ai * ai)) * 0.69314718055994531f;
+                fb[it] = __builtin_amdgcn_logf(1.0f + p.mag_gain * 0.5f * __builtin_amdgcn_sqrtf(br * br + bi * bi)) * 0.69314718055994531f;
             }
             wave_sync();                             // every spectrum value has been read: the re plane becomes the staging rows
 #pragma unroll
