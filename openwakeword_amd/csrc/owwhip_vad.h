@@ -298,8 +298,9 @@ constexpr int L_WG = 4;                       // waves per workgroup: they share
 constexpr int L_CHUNK_BLOCKS = 2 * 4 * 2;     // two gate tiles x 4 k-steps x hi/lo
 constexpr int L_CHUNK = L_CHUNK_BLOCKS * 256; // floats
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
+// (v_rcp_f32, 1 ulp: a true fp32 division is ~10 VALU instructions here -- 58 % of this kernel's instruction count before)
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 
 __global__ __launch_bounds__(64 * L_WG, 2) void vad_lstm_kernel(VadLstmParams p) {
     using namespace owr;
