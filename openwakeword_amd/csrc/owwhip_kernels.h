@@ -631,9 +631,10 @@ struct MelParams {
 };
 
 // dB value and host transform of the mel front end (ipynb cell 15: 10 log10(max(p, 1e-10)); utils.py:180,206: x / 10 + 2) with the two
-// divisions by constants written as multiplications (a true fp32 division is ~10 VALU instructions here; the result moves by <= 1 ulp,
-// i.e. < 1e-5 dB / 1e-6 mel units -- tests hold the rows to 5e-4)
-__device__ __forceinline__ float db10(float p) { return logf(fmaxf(p, 1e-10f)) * 4.3429448190325183f; }
+// divisions by constants written as multiplications and the hardware log2 (a true fp32 division / the full logf are ~10 VALU
+// instructions each here; the result moves by a few ulp, i.e. < 2e-5 dB / 2e-6 mel units -- tests hold the rows to 5e-4)
+// (v_log_f32 -- log2, 1 ulp -- times 10 log10(2): the full-precision logf costs ~10 VALU more per value for digits below 1e-5 dB)
+__device__ __forceinline__ float db10(float p) { return __builtin_amdgcn_logf(fmaxf(p, 1e-10f)) * 3.0102999566398120f; }
 __device__ __forceinline__ float mel_units(float db, float floor_db) { return fmaf(fmaxf(db, floor_db), 0.1f, 2.0f); }
 
 __device__ __forceinline__ void dft8(float* re, float* im) {
