@@ -862,8 +862,8 @@ int launch_vad(oww_ctx* h, const int16_t* d_pcm, int n_samples) {
 }
 
 // Lists for a masked step with few participants: [stream ids | C groups | D groups | E groups | VAD groups] into one pinned staging
-// buffer, copied to the device on the compute stream (ordered before the step's kernels).  Returns the number of participants, or -1
-// when the dense launches should be used (more than half of the streams take part).
+// buffer, copied to the device on the compute stream (ordered before the step's kernels).  Returns the number of participants, -1
+// when the dense launches should be used (more than half of the streams take part), or an OWW_E* code - 100 on failure.
 int build_active_lists(oww_ctx* h, const uint8_t* on) {
     const int S = h->S;
     int n_act = 0;
@@ -878,10 +878,10 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
             if (h->h_lists[i]) { (void)hipHostFree(h->h_lists[i]); h->h_lists[i] = nullptr; }
         }
         h->lists_cap = 0;
-        if (hipMalloc(&h->d_lists, need * sizeof(int)) != hipSuccess) { fail(OWW_ENOMEM, "oww_step_masked: out of device memory"); return -2; }
+        if (hipMalloc(&h->d_lists, need * sizeof(int)) != hipSuccess) return fail(OWW_ENOMEM, "oww_step_masked: out of device memory") - 100;
         for (int i = 0; i < 2; ++i) {
-            if (hipHostMalloc((void**)&h->h_lists[i], need * sizeof(int), hipHostMallocDefault) != hipSuccess) { fail(OWW_ENOMEM, "oww_step_masked: out of page-locked memory"); return -2; }
-            if (!h->lists_ev[i] && hipEventCreateWithFlags(&h->lists_ev[i], hipEventDisableTiming) != hipSuccess) { fail(OWW_EHIP, "hipEventCreate failed"); return -2; }
+            if (hipHostMalloc((void**)&h->h_lists[i], need * sizeof(int), hipHostMallocDefault) != hipSuccess) return fail(OWW_ENOMEM, "oww_step_masked: out of page-locked memory") - 100;
+            if (!h->lists_ev[i] && hipEventCreateWithFlags(&h->lists_ev[i], hipEventDisableTiming) != hipSuccess) return fail(OWW_EHIP, "hipEventCreate failed") - 100;
         }
         h->lists_cap = need;
     }
@@ -925,7 +925,7 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
         off += (size_t)n[k];
     }
     if (off) {
-        if (hipMemcpyAsync(h->d_lists, out, off * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) { fail(OWW_EHIP, "oww_step_masked: list upload failed"); return -2; }
+        if (hipMemcpyAsync(h->d_lists, out, off * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(OWW_EHIP, "oww_step_masked: list upload failed") - 100;
         (void)hipEventRecord(h->lists_ev[turn], h->stream);
     }
     return n_act;
@@ -1771,7 +1771,7 @@ int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uin
     int n_act = -1;
     if (!stream_on_on_device) {                                 // few participants: only their groups are launched (build_active_lists)
         n_act = build_active_lists(h, stream_on);
-        if (n_act == -2) { h->on_now = nullptr; return OWW_ENOMEM; }
+        if (n_act < -1) { h->on_now = nullptr; return n_act + 100; }
     }
     h->lists_now = n_act >= 0;
     const int rc = n_act == 0 ? 0 : launch_step(h, d_pcm, 1);     // nobody takes part: nothing moves
@@ -1842,7 +1842,7 @@ static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const u
     int n_act = -1;
     if (stream_on) {
         n_act = build_active_lists(h, stream_on);
-        if (n_act == -2) { h->on_now = nullptr; return OWW_ENOMEM; }
+        if (n_act < -1) { h->on_now = nullptr; return n_act + 100; }
     }
     h->lists_now = n_act >= 0;
     const int rc_step = n_act == 0 ? 0 : launch_step(h, sl.d_pcm, n_chunks);
