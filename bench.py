@@ -165,9 +165,11 @@ def timed_run(torch, dist, eng, pool, scores, steps, warmup, dev, world, gathere
     return float(t.item()), kt
 
 
-def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank):
+def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank, vad=False):
     """The oracle-sampled parity check on the engine that is about to be timed: the 64 probe streams replace random rows
-    of the synthetic batch for 16 frames (oracle/parity_sample.py); max |score - oracle| over the 1,024 (stream, step) pairs."""
+    of the synthetic batch for 16 frames (oracle/parity_sample.py); max |score - oracle| over the 1,024 (stream, step) pairs.
+    With `vad` (BASELINE configs[4]) the reference side is OracleModel behind the voice-activity gate of model.py:366-381 and a gate
+    decision whose compared value lies within 1e-3 of the threshold is skipped (and counted)."""
     from oracle import parity_sample as PS
     S = eng.n_streams
     ids = PS.probe_stream_ids(S, seed=7 + rank)
@@ -175,9 +177,16 @@ def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank):
     pcm = torch.from_numpy(PS.probe_pcm()).to(dev)
     cols = [list(PS.HEADS3).index(h) for h in head_names]
     want = torch.from_numpy(ref["scores"][:, :, cols]).to(dev)
+    keep = torch.ones(PS.N_PROBE, PS.N_FRAMES, dtype=torch.bool, device=dev)
+    if vad:
+        g = ref["vad_window_max"]
+        keep = torch.from_numpy(~(np.abs(g - PS.VAD_THRESHOLD) < 1e-3)).to(dev)
     eng.reset(None, ref["init_features"][-eng.feature_ring:])
+    if vad:
+        eng.reset_vad()
     worst = 0.0
     finite = True
+    n_open = 0
     for t in range(PS.N_FRAMES):
         buf = pool[t % len(pool)].clone()
         buf[ids_t] = pcm[:, t * 1280:(t + 1) * 1280]
@@ -185,14 +194,26 @@ def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank):
         torch.cuda.synchronize(dev)
         got = scores[ids_t].double()
         finite = finite and bool(torch.isfinite(scores).all().item())
-        worst = max(worst, float((got - want[:, t]).abs().max().item()))
+        k = keep[:, t]
+        if bool(k.any().item()):
+            worst = max(worst, float((got[k] - want[:, t][k]).abs().max().item()))
+            n_open += int((want[:, t][k] != 0).any(dim=1).sum().item())
     eng.reset()
-    return {"n_pairs": int(PS.N_PROBE * PS.N_FRAMES), "max_abs_err": worst, "tolerance": 1e-4, "ok": bool(worst <= 1e-4 and finite),
-            "streams_in_batch": S, "checker": "oracle/parity_sample.py: 64 probe streams (fixture WAVs, silence, LSB / full-scale noise, "
-            "square waves, Gaussian RMS 30..12000) at random stream ids of this engine x 16 frames vs OracleModel (numpy fp32)"}
+    if vad:
+        eng.reset_vad()
+    n_pairs = int(keep.sum().item())
+    out = {"n_pairs": n_pairs, "max_abs_err": worst, "tolerance": 1e-4, "ok": bool(worst <= 1e-4 and finite),
+           "streams_in_batch": S, "checker": "oracle/parity_sample.py: 64 probe streams (fixture WAVs, silence, LSB / full-scale noise, "
+           "square waves, Gaussian RMS 30..12000) at random stream ids of this engine x 16 frames vs OracleModel (numpy fp32)"}
+    if vad:
+        out.update({"vad_gate": f"OracleModel(vad_threshold={PS.VAD_THRESHOLD}, vad_session=StandinVadSession): model.py:366-381 around the stand-in network",
+                    "skipped_near_threshold": int(PS.N_PROBE * PS.N_FRAMES - n_pairs), "pairs_gate_open": n_open,
+                    "pairs_gated_to_zero": n_pairs - n_open})
+        out["ok"] = bool(out["ok"] and n_open > 0 and n_pairs - n_open > 0)
+    return out
 
 
-def quick_config(torch, dev, stream, S, head_names, steps, warmup, vad=False, host=False):
+def quick_config(torch, dev, stream, S, head_names, steps, warmup, vad=False, host=False, parity_ref=None):
     """One more configuration timed inside the default run (driver-timed): HBM-resident PCM unless `host` (pinned host buffers through
     the pipelined oww_submit / oww_collect path); returns ms per step and frames/s."""
     from openwakeword_amd import weights as W
@@ -206,6 +227,12 @@ def quick_config(torch, dev, stream, S, head_names, steps, warmup, vad=False, ho
         gen.manual_seed(0xA11CE + 17)
         pool = make_pcm_pool(torch, dev, S, 2, "noise", gen, 0)
         scores = torch.empty(S, eng.n_labels, device=dev, dtype=torch.float32)
+        parity = None
+        if parity_ref is not None:
+            try:
+                parity = parity_check(torch, eng, pool, scores, dev, head_names, parity_ref, 0, vad=vad)
+            except Exception as e:
+                parity = {"error": repr(e)[:300], "ok": False}
         if not host:
             dt, _ = timed_run(torch, None, eng, pool, scores, steps, warmup, dev, 1, timing=False)
         else:
@@ -228,17 +255,24 @@ def quick_config(torch, dev, stream, S, head_names, steps, warmup, vad=False, ho
             dt = time.perf_counter() - t0
             scores = torch.from_numpy(host_scores).to(dev)
         ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item()) and not eng.range_status()
-        return {"streams": S, "heads": list(head_names), "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 4),
-                "value": round(S * steps / dt, 1), "unit": "frames/s", "scores_valid": ok}
+        rec = {"streams": S, "heads": list(head_names), "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 4),
+               "value": round(S * steps / dt, 1), "unit": "frames/s", "scores_valid": ok}
+        if parity_ref is not None:
+            rec["parity"] = parity
+        return rec
     finally:
         eng.close()
 
 
 def masked_leg(torch, dev, stream, S, head_names):
-    """oww_step_masked at 10 % / 50 % / 100 % participation (random streams, mask on the host, PCM resident in HBM): the serving
-    edge's step for the connections that have a full chunk (examples/web/streaming_server.py:49-66)."""
+    """oww_step_masked at 10 / 25 / 50 / 100 % participation (mask on the host, PCM resident in HBM): the serving edge's step for the
+    connections that have a full chunk (examples/web/streaming_server.py:49-66).  Two placements of the same number of participants:
+    `random` = connections sit at arbitrary stream slots (every 8-stream group holds somebody at 50 %), `packed` = slots handed out by
+    serve.SlotAllocator from each connection's cohort key (80 ms messages, random arrival times), the participants of a step being
+    the connections whose phase bins fall due in that pump round -- what FanInServer's placement produces for real-time clients."""
     from openwakeword_amd import weights as W
     from openwakeword_amd.engine import StreamEngine
+    from openwakeword_amd import serve
     heads = {n: W.synthetic_head(n, 1234) for n in head_names}
     eng = StreamEngine(S, heads, W.synthetic_embedding(1234), device=dev.index, use_mfma=3, hip_stream=stream.cuda_stream)
     try:
@@ -248,9 +282,24 @@ def masked_leg(torch, dev, stream, S, head_names):
         pool = make_pcm_pool(torch, dev, S, 2, "noise", gen, 0)
         scores = torch.zeros(S, eng.n_labels, device=dev, dtype=torch.float32)
         rng = np.random.default_rng(17)
-        out = {}
-        for frac in (0.1, 0.5, 1.0):
-            masks = [(rng.random(S) < frac).astype(np.uint8) for _ in range(4)]
+        # packed placement: S connections arriving at random times, one 80 ms message each
+        al = serve.SlotAllocator(S, group=32, distance=serve.cohort_distance)
+        keys = [serve.cohort_key(0.080, t) for t in rng.random(S) * 600.0]
+        slot = np.fromiter((al.alloc(k) for k in keys), dtype=np.int64, count=S)
+        phase = np.fromiter((k[1] for k in keys), dtype=np.int64, count=S)
+        NB = serve.N_PHASE_BINS
+
+        def packed_masks(frac):
+            width = max(1, int(round(frac * NB)))                      # phase bins due per pump round
+            out = []
+            for r in range(4):
+                m = np.zeros(S, np.uint8)
+                bins = [(r * width + j) % NB for j in range(width)]
+                m[slot[np.isin(phase, bins)]] = 1
+                out.append(m)
+            return out
+
+        def run(masks):
             for i in range(5):
                 eng.step_masked_device(pool[i % 2].data_ptr(), masks[i % 4], scores.data_ptr())
             torch.cuda.synchronize(dev)
@@ -260,10 +309,21 @@ def masked_leg(torch, dev, stream, S, head_names):
                 eng.step_masked_device(pool[i % 2].data_ptr(), masks[i % 4], scores.data_ptr())
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
-            out[f"participation_{int(frac * 100)}pct"] = {"ms_per_step": round(1e3 * dt / n, 4), "stream_steps_per_s": round(sum(int(m.sum()) for m in masks) / 4 * n / dt, 1)}
+            part = sum(int(m.sum()) for m in masks) / 4
+            g8 = float(np.mean([m[: S // 8 * 8].reshape(-1, 8).any(axis=1).mean() for m in masks]))
+            return {"ms_per_step": round(1e3 * dt / n, 4), "stream_steps_per_s": round(part * n / dt, 1),
+                    "participation": round(part / S, 4), "groups_of_8_touched": round(g8, 4)}
+
+        out = {}
+        for frac in (0.1, 0.25, 0.5, 1.0):
+            out[f"participation_{int(frac * 100)}pct"] = run([(rng.random(S) < frac).astype(np.uint8) for _ in range(4)])
+        out["packed"] = {f"participation_{int(frac * 100)}pct": run(packed_masks(frac)) for frac in (0.125, 0.25, 0.5)}
+        out["packed"]["placement"] = ("serve.SlotAllocator: 32-stream blocks per cohort key (message period, arrival phase in 8 bins); a round's "
+                                      "participants = the connections of the phase bins due")
         out["streams"] = S
         out["scores_valid"] = bool(torch.isfinite(scores).all().item()) and not eng.range_status()
-        out["note"] = "host-side list building included; <= 50 % participation launches only the stage groups that hold a participating stream"
+        out["note"] = ("host-side list building included; below 7/8 participation only the stage groups that hold a participating stream are "
+                       "launched, so the cost follows the groups touched: 'random' placement touches nearly all of them at 50 %")
         return out
     finally:
         eng.close()
@@ -308,6 +368,94 @@ def leg_resident_1m(args):
                       "scores_valid": ok, "parity": parity}))
 
 
+def self_launch(n: int) -> None:
+    """A bare `python bench.py --gpus N` (N > 1, no torchrun environment): re-execute this command line under
+    torch.distributed.run -- one rank per GPU, rendezvous on 127.0.0.1 at a free port -- and pass the ranks' output through
+    (rank 0 prints the one JSON line).  The driver's explicit `python -m torch.distributed.run ... bench.py --gpus N` form
+    never gets here: it sets RANK / WORLD_SIZE."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env, cwd=os.getcwd()).returncode)
+
+
+class CAbiGather:
+    """Delivery of the scores through the C ABI's own exchange (include/owwhip.h: oww_comm_init / oww_gather_scores -- one grouped
+    ncclSend (every rank) / ncclRecv x world (rank 0) on the handle's stream per step) instead of torch.distributed.  The
+    communicator id travels over the process group here; any side channel will do.  Same interface as shard.ScoreGather."""
+
+    def __init__(self, torch, dist, eng, S, NL, dev, world, rank):
+        from openwakeword_amd.engine import StreamEngine
+        box = [StreamEngine.comm_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0], rank, world)
+        self.eng, self.rank, self.world = eng, rank, world
+        self.ranks = eng.comm_count()                      # ncclCommCount
+        self.out = torch.full((S * world, NL), -1.0, device=dev, dtype=torch.float32) if rank == 0 else None
+        self.counts = [S] * world
+        self.collectives = 0
+
+    def gather(self, scores):
+        self.eng.gather_scores(self.out.data_ptr() if self.rank == 0 else 0, self.counts)
+        self.collectives += 1
+        return self.out
+
+    def flush(self):
+        self.eng.sync()
+
+    def close(self):
+        self.eng.comm_destroy()
+
+
+def c_abi_gather_pass(torch, dist, eng, pool, scores, dev, world, rank, steps, warmup):
+    """The headline steps once more with the scores delivered by CAbiGather; rank 0 then checks what arrived against a
+    torch.distributed gather of the same scores.  Returns the record for the JSON line."""
+    S, NL = scores.shape
+    g = CAbiGather(torch, dist, eng, S, NL, dev, world, rank)
+    try:
+        dt, _ = timed_run(torch, dist, eng, pool, scores, steps, warmup, dev, world, g, False)
+        if world > 1:
+            blocks = [torch.empty_like(scores) for _ in range(world)] if rank == 0 else None
+            dist.gather(scores, blocks, dst=0)
+            equal = bool(torch.equal(g.out, torch.cat(blocks))) if rank == 0 else None
+        else:
+            equal = bool(torch.equal(g.out, scores))
+        return {"exchange": "oww_gather_scores: grouped ncclSend (every rank) / ncclRecv x world (rank 0) on the handle's stream, every step",
+                "rccl_ranks": g.ranks, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 4),
+                "value": round(S * world * steps / dt, 1), "unit": "frames/s", "bytes_per_rank_and_step": int(S * NL * 4),
+                "gathered_equals_scores": equal}
+    finally:
+        g.close()
+
+
+def with_watchdog(seconds, on_timeout, fn):
+    """Run fn(); if it has not returned after `seconds` (a collective that never completes cannot be cancelled from the host),
+    call on_timeout() and end the process with exit code 0 -- the headline record must not be lost to an extra one."""
+    import threading
+    done = threading.Event()
+
+    def guard():
+        if not done.wait(seconds):
+            try:
+                on_timeout()
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+    threading.Thread(target=guard, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +477,10 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=250)
     ap.add_argument("--sustained-warmup", type=int, default=100)
     ap.add_argument("--gather-every", type=int, default=1, help="N > 1: gather scores to rank 0 every K steps (one K-times larger collective)")
+    ap.add_argument("--gather", choices=("dist", "c_abi"), default="dist",
+                    help="delivery of the scores to rank 0 inside the timed region: dist = torch.distributed gather (backend nccl = RCCL); "
+                         "c_abi = the library's own grouped ncclSend / ncclRecv exchange (oww_comm_init / oww_gather_scores; also runs "
+                         "with one rank, as a send-to-self through RCCL)")
     ap.add_argument("--vad", action="store_true", help="BASELINE configs[4]: the voice-activity stand-in network + gate fused into the step")
     ap.add_argument("--leg", default="", help="(internal) run one extra record in this process and print its JSON: resident_1m")
     ap.add_argument("--pcm-pool", type=int, default=4, help="distinct PCM buffers cycled through")
@@ -345,6 +497,9 @@ def main():
     if args.leg == "resident_1m":
         return leg_resident_1m(args)
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -358,10 +513,13 @@ def main():
     parity_ref = None
     family_ok = not (args.valu or args.lds_mfma)
     want_parity = (not args.no_parity and family_ok and set(head_names) <= {"alexa", "hey_mycroft", "hey_jarvis"}
-                   and not (args.host_pcm or args.host_pcm_blocking) and not args.vad)     # (the probe reference is computed without a VAD gate)
+                   and not (args.host_pcm or args.host_pcm_blocking))
+    vad_parity_ref = None
     if want_parity and rank0:
         from oracle import parity_sample as PS
-        parity_ref = PS.oracle_reference()              # computed once by a child interpreter, cached under $TMPDIR
+        parity_ref = PS.oracle_reference(vad=args.vad)  # computed once by a child interpreter, cached under $TMPDIR
+        if world == 1 and not args.no_extras and not args.vad and set(head_names) == set(PS.HEADS3):
+            vad_parity_ref = PS.oracle_reference(vad=True)     # for the vad_fused record (BASELINE configs[4])
 
     import torch
     import torch.distributed as dist
@@ -387,7 +545,7 @@ def main():
             dist.barrier()                               # rank 0 wrote the cache file before it joined
             if not rank0:
                 from oracle import parity_sample as PS
-                parity_ref = PS.oracle_reference()
+                parity_ref = PS.oracle_reference(vad=args.vad)
 
     S = args.streams
     emb = W.synthetic_embedding(1234)
@@ -409,17 +567,29 @@ def main():
     pool = make_pcm_pool(torch, dev, S, max(1, args.pcm_pool), args.pcm, gen, rank)
     scores = torch.empty(S, NL, device=dev, dtype=torch.float32)
     from openwakeword_amd.shard import ScoreGather
-    gatherer = ScoreGather(S * world, NL, dev, every=args.gather_every) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
+    if args.gather == "c_abi":
+        if one_gpu and world > 1:
+            raise SystemExit("--gather c_abi needs one GPU per rank (RCCL refuses two ranks on one device); OWW_BENCH_ONE_GPU runs use --gather dist")
+        if args.gather_every != 1:
+            raise SystemExit("--gather c_abi delivers every step (--gather-every applies to --gather dist)")
+        gatherer = CAbiGather(torch, dist, eng, S, NL, dev, world, rank)
+    else:
+        gatherer = ScoreGather(S * world, NL, dev, every=args.gather_every) if world > 1 else None      # rank r owns global streams [r*S, (r+1)*S)
+    backend = dist.get_backend() if world > 1 else None
+    rccl_ranks = gatherer.ranks if args.gather == "c_abi" else (dist.get_world_size() if backend == "nccl" else 0)
 
     parity = None
     if parity_ref is not None:
-        parity = parity_check(torch, eng, pool, scores, dev, head_names, parity_ref, rank)
+        parity = parity_check(torch, eng, pool, scores, dev, head_names, parity_ref, rank, vad=args.vad)
         if world > 1:
             t = torch.tensor([parity["max_abs_err"]], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             parity["max_abs_err"] = float(t.item())
-            parity["n_pairs"] *= world
-            parity["ok"] = bool(parity["max_abs_err"] <= parity["tolerance"])
+            n = torch.tensor([parity["n_pairs"], int(parity["ok"])], device=dev, dtype=torch.int64)
+            dist.all_reduce(n[:1], op=dist.ReduceOp.SUM)
+            dist.all_reduce(n[1:], op=dist.ReduceOp.MIN)
+            parity["n_pairs"] = int(n[0].item())
+            parity["ok"] = bool(n[1].item()) and bool(parity["max_abs_err"] <= parity["tolerance"])
 
     host = args.host_pcm or args.host_pcm_blocking
     timing = not args.no_kernel_timing and not args.graph
@@ -466,13 +636,19 @@ def main():
         if timing:
             n_k = max(4, min(args.steps, 10))
             dt_k, ktimes = timed_run(torch, dist, eng, pool, scores, n_k, 2, dev, world, gatherer, True)
-            kpass = {"steps": n_k, "ms_per_step": round(1e3 * dt_k / n_k, 4),
+            kpass = {"steps": n_k, "launches": int(sum(v["launches"] for v in ktimes.values())), "ms_per_step": round(1e3 * dt_k / n_k, 4),
                      "note": "separate pass after the timed steps: per-kernel hipEvents on, block pipelining off (kernels run one after the other)"}
     ok = bool(torch.isfinite(scores).all().item()) and bool(((scores >= 0) & (scores <= 1)).all().item())
     range_flag = eng.range_status() if family == 3 else False
 
     extras = {}
     if rank0 and world == 1 and not args.no_extras and not host:
+        # ---- c_abi_gather with ONE rank: the C ABI's RCCL exchange as a send-to-self on the handle's stream (what a 1-GPU box can show)
+        if args.gather == "dist" and family == 3:
+            try:
+                extras["c_abi_gather"] = c_abi_gather_pass(torch, dist, eng, pool, scores, dev, 1, 0, 20, 5)
+            except Exception as e:
+                extras["c_abi_gather"] = {"error": repr(e)[:400]}
         # ---- sustained: the same configuration for 100 warm-up + 250 timed steps (the part is power-limited: a 20-step burst reads low)
         dt_s, _ = timed_run(torch, dist, eng, pool, scores, args.sustained_steps, args.sustained_warmup, dev, 1, None, timing=False)
         extras["sustained"] = {"steps": args.sustained_steps, "warmup": args.sustained_warmup,
@@ -513,7 +689,7 @@ def main():
                     "c1_4096x1": quick_config(torch, dev, stream, 4096, ["hey_jarvis"], 50, 10),
                     "c2_65536x3": quick_config(torch, dev, stream, 65536, head_names, 50, 10),
                 }
-                extras["vad_fused"] = quick_config(torch, dev, stream, S, head_names, 20, 5, vad=True)
+                extras["vad_fused"] = quick_config(torch, dev, stream, S, head_names, 20, 5, vad=True, parity_ref=vad_parity_ref)
                 extras["masked_step"] = masked_leg(torch, dev, stream, S, head_names)
                 extras["host_pcm"] = dict(quick_config(torch, dev, stream, S, head_names, 20, 5, host=True),
                                           note="PCIe-inclusive (pinned host PCM in, scores out, two steps in flight): never the headline value")
@@ -542,8 +718,11 @@ def main():
                                    "80 ms frames, BASELINE configs[3] per-GPU shard" if S == 131072 else
                                    f"{S} concurrent 16 kHz streams per GPU x {len(heads)} heads ({','.join(heads)}), 80 ms frames",
                        "streams_per_gpu": S, "heads": list(heads), "frame_samples": 1280, "sharding": f"stream-range x{world}",
-                       "collective": (f"RCCL gather of scores every {args.gather_every} step(s)" if not one_gpu else
-                                      f"gloo gather every {args.gather_every} step(s) (OWW_BENCH_ONE_GPU testing aid: all ranks on device 0)") if world > 1 else "none",
+                       "collective": ("oww_gather_scores (C ABI: grouped ncclSend / ncclRecv over RCCL) every step" if args.gather == "c_abi" else
+                                      (f"RCCL gather of scores every {args.gather_every} step(s)" if not one_gpu else
+                                       f"gloo gather every {args.gather_every} step(s) (OWW_BENCH_ONE_GPU testing aid: all ranks on device 0)") if world > 1 else "none"),
+                       "gather": args.gather if (world > 1 or args.gather == "c_abi") else "none",
+                       "rccl_ranks": int(rccl_ranks),
                        "pcm_distribution": {"noise": "Gaussian, RMS 3000", "uniform": "randint(-1000, 1000)", "wav": "fixture WAVs tiled, phase 997*s"}[args.pcm],
                        "pcm": ("pinned host buffers, PCIe-inclusive, " + ("blocking oww_step" if args.host_pcm_blocking else "pipelined oww_submit/oww_collect") +
                                " (not the headline configuration)") if host else "resident in HBM",
@@ -560,7 +739,8 @@ def main():
             per = {k: (v["ms"] / max(v["launches"], 1)) for k, v in ktimes.items()}
             out["kernel_ms"] = {k: round(v, 4) for k, v in per.items()}
             out["kernel_timing_pass"] = kpass
-            out["launches_per_step"] = int(round(sum(v["launches"] for v in ktimes.values()) / max(args.steps, 1)))
+            # launches of the pass the events were recorded in, per step of THAT pass (the host-PCM form records during the timed steps)
+            out["launches_per_step"] = round(sum(v["launches"] for v in ktimes.values()) / max(kpass["steps"] if kpass else args.steps, 1), 2)
             # Roofline kernel = the LONGEST launch of the step (not the longest "matrix-bound" one).  With the mel front end
             # fused into stage A (default: the mel class has no launches) that launch also carries the FFT / log-mel work; its
             # algorithmic flops are stage A's + the FFT form of the front end, priced against the matrix peak like every stage, and
@@ -619,7 +799,30 @@ def main():
             out["roofline"] = None
         out.update(extras)
         out["cpu_baseline"] = cpu_base
+    else:
+        out = None
+    if world > 1 and args.gather == "dist" and backend == "nccl" and not one_gpu and not args.no_extras and not host and eng is not None:
+        # ---- c_abi_gather: the same steps delivered through the library's own RCCL exchange (the binder-without-torch path), every rank.
+        #      Under a watchdog: a collective that never completes cannot be cancelled, and the headline line must survive it.
+        def lost():
+            if rank == 0:
+                print(json.dumps(dict(out, c_abi_gather={"error": "did not complete within 120 s; the process was ended by the watchdog"})))
+        try:
+            rec = with_watchdog(120.0, lost, lambda: c_abi_gather_pass(torch, dist, eng, pool, scores, dev, world, rank,
+                                                                      min(args.steps, 20), min(args.warmup, 5)))
+        except Exception as e:
+            rec = {"error": repr(e)[:400]}
+        if rank == 0:
+            out["c_abi_gather"] = rec
+        if "error" in rec:                                  # a rank that failed alone leaves its peers in a collective: do not join them
+            if rank == 0:
+                print(json.dumps(out))
+            sys.stdout.flush()
+            os._exit(0)
+    if rank == 0:
         print(json.dumps(out))
+    if args.gather == "c_abi":
+        gatherer.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OWW_ABI_VERSION 4
+#define OWW_ABI_VERSION 5
 
 #define OWW_OK            0
 #define OWW_EINVAL       -1   /* bad argument */
@@ -207,6 +207,7 @@ int  oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in,
  *   oww_gather_scores enqueued on the handle's stream after a step: every rank sends its fp32 [S_r][n_labels] scores to rank 0,
  *                     which receives them at out + sum(counts[0..r)) * n_labels (device pointer; counts[r] = streams of rank r, the
  *                     same array on every rank).  One grouped ncclSend / ncclRecv exchange; asynchronous (oww_sync to wait).
+ *   oww_comm_count    *ranks = what the communicator itself reports (ncclCommCount): the number of RCCL ranks actually joined
  *   oww_comm_destroy  leaves the communicator (oww_destroy does it too)
  * librccl.so is bound at run time by the first of these calls; a process that already holds a copy (e.g. torch's) shares it.
  * Python: openwakeword_amd.shard.ScoreGather is the torch.distributed form of the same exchange. */
@@ -214,6 +215,7 @@ int  oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in,
 int  oww_comm_id(void* id);
 int  oww_comm_init(oww_ctx* h, const void* id, int32_t rank, int32_t world);
 int  oww_gather_scores(oww_ctx* h, float* out, const int32_t* counts);
+int  oww_comm_count(oww_ctx* h, int32_t* ranks);
 int  oww_comm_destroy(oww_ctx* h);
 
 /* ---- stage-level entry points (the reference's per-stage closures; used for parity tests and for

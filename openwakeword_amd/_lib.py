@@ -8,7 +8,7 @@ import os
 from . import _build
 
 _lib = None
-ABI_VERSION = 4          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
+ABI_VERSION = 5          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
 ERANGE = -5
 
 
@@ -70,6 +70,7 @@ SYMBOLS = {
     "oww_comm_id": (C.c_int, [_P]),
     "oww_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "oww_gather_scores": (C.c_int, [_P, _P, _P]),
+    "oww_comm_count": (C.c_int, [_P, _P]),
     "oww_comm_destroy": (C.c_int, [_P]),
 }
 

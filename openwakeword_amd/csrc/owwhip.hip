@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <dlfcn.h>
 #include <string>
 #include <vector>
@@ -32,9 +34,17 @@ int fail(int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    try { g_err = buf; } catch (...) {}                // (the message is best effort; the code is what callers branch on)
     return code;
 }
+
+// Nothing throws across the C ABI: every extern "C" body that can allocate (std::vector / std::string packing buffers, new) runs
+// between these two, which turn a C++ exception into an error code + message like any other failure.
+#define OWW_GUARD_BEGIN try {
+#define OWW_GUARD_END                                                                                              \
+    } catch (const std::bad_alloc&) { return fail(OWW_ENOMEM, "%s: out of host memory", __func__);                 \
+    } catch (const std::exception& e__) { return fail(OWW_ESTATE, "%s: unexpected C++ exception: %s", __func__, e__.what()); \
+    } catch (...) { return fail(OWW_ESTATE, "%s: unexpected C++ exception", __func__); }
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -744,6 +754,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -764,6 +775,7 @@ int rccl_load() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
@@ -863,12 +875,14 @@ int launch_vad(oww_ctx* h, const int16_t* d_pcm, int n_samples) {
 
 // Lists for a masked step with few participants: [stream ids | C groups | D groups | E groups | VAD groups] into one pinned staging
 // buffer, copied to the device on the compute stream (ordered before the step's kernels).  Returns the number of participants, -1
-// when the dense launches should be used (more than half of the streams take part), or an OWW_E* code - 100 on failure.
+// when the dense launches should be used (more than 7/8 of the streams take part: the lists then save nothing; below that they do even
+// for a mask that touches most groups, and a serving edge that places connections by cohort -- serve.py::SlotAllocator -- makes
+// participation per group all-or-nothing, so the launches shrink with the mask), or an OWW_E* code - 100 on failure.
 int build_active_lists(oww_ctx* h, const uint8_t* on) {
     const int S = h->S;
     int n_act = 0;
     for (int s = 0; s < S; ++s) n_act += on[s] != 0;          // (vectorised by the compiler)
-    if (n_act * 2 > S) return -1;
+    if ((long long)n_act * 8 > (long long)S * 7) return -1;
     const size_t need = (size_t)S + S / 2 + S / 4 + S / 8 + S / 16 + 64;       // (regions of the five lists, see below)
     if (need > h->lists_cap) {
         if (h->d_lists) (void)hipFree(h->d_lists);
@@ -1199,6 +1213,7 @@ int oww_abi_version(void) { return OWW_ABI_VERSION; }
 const char* oww_last_error(void) { return g_err.c_str(); }
 
 int oww_create(const oww_config* cfg, oww_ctx** out) {
+    OWW_GUARD_BEGIN
     if (!cfg || !out) return fail(OWW_EINVAL, "oww_create: null argument");
     if (cfg->n_streams < 1) return fail(OWW_EINVAL, "oww_create: n_streams must be >= 1");
     int ndev = 0;
@@ -1223,9 +1238,11 @@ int oww_create(const oww_config* cfg, oww_ctx** out) {
     }
     *out = h;
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_destroy(oww_ctx* h) {
+    OWW_GUARD_BEGIN
     if (!h) return OWW_OK;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
@@ -1235,18 +1252,22 @@ int oww_destroy(oww_ctx* h) {
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_load_mel(oww_ctx* h, const void* blob, size_t nbytes) {
+    OWW_GUARD_BEGIN
     if (!h || !blob) return fail(OWW_EINVAL, "oww_load_mel: null argument");
     if (h->committed) return fail(OWW_ESTATE, "weights already committed");
     const size_t want = (400 + 32 + 32 * 16) * 4;
     if (nbytes != want) return fail(OWW_EINVAL, "oww_load_mel: blob is %zu bytes, expected %zu", nbytes, want);
     h->mel_blob.assign((const float*)blob, (const float*)blob + want / 4);
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes) {
+    OWW_GUARD_BEGIN
     if (!h || !blob) return fail(OWW_EINVAL, "oww_load_embedding: null argument");
     if (h->committed) return fail(OWW_ESTATE, "weights already committed");
     size_t want = 0;
@@ -1257,9 +1278,11 @@ int oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes) {
     if (nbytes != want * 4) return fail(OWW_EINVAL, "oww_load_embedding: blob is %zu bytes, expected %zu", nbytes, want * 4);
     h->emb_blob.assign((const float*)blob, (const float*)blob + want);
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
+    OWW_GUARD_BEGIN
     if (!h || !blob || nbytes < 32) return fail(OWW_EINVAL, "oww_add_head: bad argument");
     if (h->committed) return fail(OWW_ESTATE, "weights already committed");
     if ((int)h->heads.size() >= OWW_MAX_HEADS) return fail(OWW_EINVAL, "too many heads");
@@ -1276,6 +1299,7 @@ int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
     hh.blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
     h->heads.push_back(std::move(hh));
     return (int)h->heads.size() - 1;
+    OWW_GUARD_END
 }
 
 namespace {
@@ -1290,6 +1314,7 @@ size_t vad_blob_floats() {
 }  // namespace
 
 int oww_load_vad(oww_ctx* h, const void* blob, size_t nbytes) {
+    OWW_GUARD_BEGIN
     if (!h || !blob) return fail(OWW_EINVAL, "oww_load_vad: null argument");
     if (h->committed) return fail(OWW_ESTATE, "weights already committed");
     const size_t want = 32 + vad_blob_floats() * 4;
@@ -1299,11 +1324,13 @@ int oww_load_vad(oww_ctx* h, const void* blob, size_t nbytes) {
         return fail(OWW_EINVAL, "oww_load_vad: unsupported geometry (version %d, n_fft %d, hop %d, bins %d, hidden %d)", hdr[0], hdr[1], hdr[2], hdr[3], hdr[4]);
     h->vad_blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_n_labels(const oww_ctx* h) { return h ? h->NL : 0; }
 
 int oww_commit(oww_ctx* h) {
+    OWW_GUARD_BEGIN
     if (!h) return fail(OWW_EINVAL, "null handle");
     if (h->committed) return fail(OWW_ESTATE, "already committed");
     if (h->mel_blob.empty() || h->emb_blob.empty()) return fail(OWW_ESTATE, "mel and embedding weights must be loaded before commit");
@@ -1551,7 +1578,7 @@ int oww_commit(oww_ctx* h) {
     {
         void* dp = nullptr;
         HIPCHK(hipHostMalloc((void**)&h->h_range, 64, hipHostMallocMapped));
-        h->h_range[0] = 0; h->h_range[1] = -1; h->h_range[2] = 0;
+        h->h_range[0] = 0; h->h_range[1] = -1;
         HIPCHK(hipHostGetDevicePointer(&dp, h->h_range, 0));
         h->d_range = (int*)dp;
     }
@@ -1660,9 +1687,11 @@ int oww_commit(oww_ctx* h) {
     }
     h->committed = true;
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* init_features) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_reset: handle not committed");
     HIPCHK(hipSetDevice(h->cfg.device));
     const float* d_init = nullptr;
@@ -1687,9 +1716,11 @@ int oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* ini
     }
     HIPCHK(hipStreamSynchronize(h->stream));     // host buffers may be reused by the caller
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold, int32_t debounce_frames) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_set_postproc: handle not committed");
     HIPCHK(hipSetDevice(h->cfg.device));
     std::vector<int> pat(std::max(h->NL, 1), 0);
@@ -1702,9 +1733,11 @@ int oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold
     h->debounce_frames = debounce_frames;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // baked-in scalar changed
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks, float* scores, int scores_on_device) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step: handle not committed");
     if (!pcm) return fail(OWW_EINVAL, "oww_step: pcm is null");
     if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_step: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
@@ -1743,10 +1776,12 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
         }
     }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uint8_t* stream_on, int stream_on_on_device,
                     float* scores, int scores_on_device) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step_masked: handle not committed");
     if (!pcm || !stream_on) return fail(OWW_EINVAL, "oww_step_masked: null argument");
     if (!h->hx || !h->fuse || !h->generic_nets.empty())
@@ -1786,6 +1821,7 @@ int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uin
         }
     }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 static int ensure_ingest(oww_ctx* h) {
@@ -1807,13 +1843,15 @@ static int ensure_ingest(oww_ctx* h) {
 
 static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const uint8_t* stream_on);
 
-int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) { return submit_impl(h, pcm, n_chunks, nullptr); }
+int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) { OWW_GUARD_BEGIN return submit_impl(h, pcm, n_chunks, nullptr); OWW_GUARD_END }
 
 int oww_submit_masked(oww_ctx* h, const int16_t* pcm, const uint8_t* stream_on) {
+    OWW_GUARD_BEGIN
     if (!stream_on) return fail(OWW_EINVAL, "oww_submit_masked: stream_on is null");
     if (h && h->committed && (!h->hx || !h->fuse || !h->generic_nets.empty()))
         return fail(OWW_EINVAL, "oww_submit_masked: needs the fp16-split kernels with the fused front end (see oww_step_masked)");
     return submit_impl(h, pcm, 1, stream_on);
+    OWW_GUARD_END
 }
 
 static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const uint8_t* stream_on) {
@@ -1860,6 +1898,7 @@ static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const u
 }
 
 int oww_collect(oww_ctx* h, float* scores) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_collect: handle not committed");
     auto& sl = h->slot[h->n_collect & 1];
     if (h->n_collect == h->n_submit || !sl.busy) return fail(OWW_ESTATE, "oww_collect: no step in flight");
@@ -1870,20 +1909,26 @@ int oww_collect(oww_ctx* h, float* scores) {
     ++h->n_collect;
     if (int rc = range_check(h, "oww_collect")) return rc;      // the step is consumed; its scores are suspect
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_host_alloc(void** out, size_t nbytes) {
+    OWW_GUARD_BEGIN
     if (!out || !nbytes) return fail(OWW_EINVAL, "oww_host_alloc: bad argument");
     if (hipHostMalloc(out, nbytes, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(OWW_ENOMEM, "oww_host_alloc: %zu bytes of page-locked memory not available", nbytes); }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_host_free(void* p) {
+    OWW_GUARD_BEGIN
     if (p) HIPCHK(hipHostFree(p));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, float bias, float threshold) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_set_verifier: handle not committed");
     if (label < 0 || label >= h->NL) return fail(OWW_EINVAL, "oww_set_verifier: label %d outside [0,%d)", label, h->NL);
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1912,17 +1957,21 @@ int oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, flo
     for (int t : h->ver_T) h->n_verifiers += t > 0;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }       // the launch list changed
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_set_vad_threshold(oww_ctx* h, float threshold) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_set_vad_threshold: handle not committed");
     if (!(threshold == threshold)) return fail(OWW_EINVAL, "oww_set_vad_threshold: NaN");
     h->vad_threshold = threshold;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }     // the threshold is a kernel argument
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_push_vad: handle not committed");
     if (!vad_scores) return fail(OWW_EINVAL, "oww_push_vad: null argument");
     if (h->vad) return fail(OWW_ESTATE, "oww_push_vad: this handle computes its own voice-activity scores (oww_load_vad)");
@@ -1936,9 +1985,11 @@ int oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device) {
     HIPCHK(hipGetLastError());
     if (!on_device) HIPCHK(hipStreamSynchronize(h->stream));          // the caller's buffer may be reused at once
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_get_vad(oww_ctx* h, float* out) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_vad: handle not committed");
     if (!h->vad) return fail(OWW_ESTATE, "oww_get_vad: no voice-activity network loaded (oww_load_vad)");
     if (!out) return fail(OWW_EINVAL, "oww_get_vad: null argument");
@@ -1946,9 +1997,11 @@ int oww_get_vad(oww_ctx* h, float* out) {
     HIPCHK(hipMemcpyAsync(out, h->d_vadlast, (size_t)h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_reset_vad: handle not committed");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int* d_ids = nullptr;
@@ -1974,38 +2027,52 @@ int oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_sync(oww_ctx* h) {
+    OWW_GUARD_BEGIN
     if (!h) return fail(OWW_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     return range_check(h, "oww_sync");
+    OWW_GUARD_END
 }
 
 int oww_range_status(oww_ctx* h, int clear) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_range_status: handle not committed");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int rc = range_check(h, "oww_range_status");
-    if (clear && h->h_range) *(volatile int*)h->h_range = 0;
+    if (clear && h->h_range) { volatile int* f = (volatile int*)h->h_range; f[1] = -1; f[0] = 0; }     // the position goes with the flag
     return rc;
+    OWW_GUARD_END
 }
 
 int oww_range_where(oww_ctx* h, int32_t* first_stream, int32_t* n_streams) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed || !first_stream || !n_streams) return fail(OWW_EINVAL, "oww_range_where: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const volatile int* f = (const volatile int*)h->h_range;
-    if (f && f[0]) { *first_stream = f[1]; *n_streams = f[2]; if (*first_stream >= h->S) { *first_stream = -1; *n_streams = 0; } else if (*first_stream >= 0) *n_streams = std::min(*n_streams, h->S - *first_stream); }
-    else { *first_stream = -1; *n_streams = 0; }
+    *first_stream = -1; *n_streams = 0;
+    if (f && f[0]) {
+        const int packed = f[1];                            // first << 6 | count, written by one wave in one store (owwhip_hx.h)
+        if (packed >= 0) {
+            const int first = (int)((unsigned)packed >> 6), cnt = packed & 63;
+            if (first < h->S && cnt > 0) { *first_stream = first; *n_streams = std::min(cnt, h->S - first); }
+        }
+    }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 const float* oww_scores_dev(const oww_ctx* h) { return h ? h->d_scores : nullptr; }
 
 int oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, int32_t p, int32_t q, const float* taps, int32_t n_taps,
                  int16_t* out, int out_on_device, int32_t n_out) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_resample: handle not committed");
     if (!in || !out || !taps) return fail(OWW_EINVAL, "oww_resample: null argument");
     if (n_in < 1 || p < 1 || q < 1 || n_taps < 2 || (n_taps & 1) || n_taps > 4096 || q > 65536)
@@ -2057,9 +2124,11 @@ int oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, 
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_get_raw(oww_ctx* h, float* out) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_raw: handle not committed");
     if (!out) return fail(OWW_EINVAL, "oww_get_raw: null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -2067,6 +2136,7 @@ int oww_get_raw(oww_ctx* h, float* out) {
     if (nb) HIPCHK(hipMemcpyAsync(out, h->d_raw, nb, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 static int mel_impl(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db, bool per_clip) {
@@ -2099,10 +2169,11 @@ static int mel_impl(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float*
     return rc;
 }
 
-int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) { return mel_impl(h, pcm, B, n, out_db, false); }
-int oww_mel_clips(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) { return mel_impl(h, pcm, B, n, out_db, true); }
+int oww_mel(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) { OWW_GUARD_BEGIN return mel_impl(h, pcm, B, n, out_db, false); OWW_GUARD_END }
+int oww_mel_clips(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float* out_db) { OWW_GUARD_BEGIN return mel_impl(h, pcm, B, n, out_db, true); OWW_GUARD_END }
 
 int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float* out) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_embed: handle not committed");
     if (!mel_rows || !out || B < 1 || B > h->Spad || rows < 76 || (rows - 76) % 8) return fail(OWW_EINVAL, "oww_embed: bad argument (B=%d rows=%d, need B<=%d)", B, rows, h->Spad);
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -2132,9 +2203,11 @@ int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float*
     if (rc_all) return rc_all;
     if (rc_restore) return rc_restore;
     return range_check(h, "oww_embed");
+    OWW_GUARD_END
 }
 
 int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32_t B, int32_t n, float* out, int32_t out_on_device) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_embed_clips: handle not committed");
     if (!pcm || !out || B < 1 || B > h->Spad || n < 512) return fail(OWW_EINVAL, "oww_embed_clips: bad argument (B=%d n=%d, need B<=%d)", B, n, h->Spad);
     const int F = (n - 512) / 160 + 1;
@@ -2183,9 +2256,11 @@ int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32
     if (!rc) rc = rc_restore;
     if (!rc) rc = range_check(h, "oww_embed_clips");
     return rc;
+    OWW_GUARD_END
 }
 
 int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* out) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_head: handle not committed");
     if (head < 0 || head >= (int)h->heads.size() || !features || !out || B < 1) return fail(OWW_EINVAL, "oww_head: bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -2209,9 +2284,11 @@ int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* 
     } while (0);
     (void)hipFree(d_f); (void)hipFree(d_raw);
     return rc;
+    OWW_GUARD_END
 }
 
 int oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_features: handle not committed");
     if (sid < 0 || sid >= h->S || T < 1 || T > h->TR || !out) return fail(OWW_EINVAL, "oww_get_features: bad argument (sid=%d T=%d ring=%d)", sid, T, h->TR);
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -2226,9 +2303,11 @@ int oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out) {
         memcpy(out + (size_t)t * 96, &ring[(size_t)slot * 96], 96 * sizeof(float));
     }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_get_mel: handle not committed");
     if (h->fuse && h->k_last == 1 && !h->cfg.debug_layers)
         return fail(OWW_ESTATE, "oww_get_mel: with the mel front end fused into stage A the rows of a one-chunk step never reach HBM; "
@@ -2240,9 +2319,11 @@ int oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows) {
     HIPCHK(hipMemcpyAsync(out, h->d_mel + ((size_t)sid * rows_last + (rows_last - n_rows)) * 32, (size_t)n_rows * 32 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t cap) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed || !h->d_dbg) return fail(OWW_ESTATE, "oww_debug_read: needs a committed handle created with debug_layers=1");
     if (sid < 0 || sid >= h->S || layer < 0 || layer > 19 || !out) return fail(OWW_EINVAL, "oww_debug_read: bad argument");
     int off = 0;
@@ -2253,48 +2334,60 @@ int oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t c
     HIPCHK(hipMemcpyAsync(out, h->d_dbg + (size_t)sid * DBG_FLOATS + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return n;
+    OWW_GUARD_END
 }
 
 int oww_debug_profile(oww_ctx* h, int64_t* out, int32_t cap) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed || !h->d_prof) return fail(OWW_ESTATE, "oww_debug_profile: set OWW_PROF_BLOCK before creating the handle");
     if (!out || cap < 4 * 256) return fail(OWW_EINVAL, "oww_debug_profile: need room for 1024 values");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->d_prof, (size_t)4 * 256 * sizeof(long long), hipMemcpyDeviceToHost));
     return 4 * 256;
+    OWW_GUARD_END
 }
 
 int oww_enable_timing(oww_ctx* h, int on) {
+    OWW_GUARD_BEGIN
     if (!h) return fail(OWW_EINVAL, "null handle");
     if (!on && h->timing) { if (int rc = flush_events(h)) return rc; }
     h->timing = on != 0;
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_kernel_times(oww_ctx* h, double ms[OWW_N_KERNEL_CLASSES], int64_t n[OWW_N_KERNEL_CLASSES]) {
+    OWW_GUARD_BEGIN
     if (!h || !ms || !n) return fail(OWW_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (int rc = flush_events(h)) return rc;
     for (int i = 0; i < OWW_N_KERNEL_CLASSES; ++i) { ms[i] = h->t_ms[i]; n[i] = h->t_n[i]; h->t_ms[i] = 0; h->t_n[i] = 0; }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_use_graph(oww_ctx* h, int on) {
+    OWW_GUARD_BEGIN
     if (!h) return fail(OWW_EINVAL, "null handle");
     h->want_graph = on != 0;
     if (!on && h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 // ---- multi-GPU delivery of results over RCCL, without torch.distributed -----------------------------------------------------------
 int oww_comm_id(void* id) {
+    OWW_GUARD_BEGIN
     if (!id) return fail(OWW_EINVAL, "oww_comm_id: null argument");
     if (int rc = rccl_load()) return rc;
     RCCLCHK(g_rccl.GetUniqueId(id));
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_comm_init(oww_ctx* h, const void* id, int32_t rank, int32_t world) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_comm_init: handle not committed");
     if (!id || world < 1 || rank < 0 || rank >= world) return fail(OWW_EINVAL, "oww_comm_init: bad argument (rank %d of %d)", rank, world);
     if (h->comm) return fail(OWW_ESTATE, "oww_comm_init: the handle already has a communicator");
@@ -2306,9 +2399,11 @@ int oww_comm_init(oww_ctx* h, const void* id, int32_t rank, int32_t world) {
     RCCLCHK(g_rccl.CommInitRank(&comm, world, uid, rank));
     h->comm = comm; h->comm_rank = rank; h->comm_world = world;
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_gather_scores(oww_ctx* h, float* out, const int32_t* counts) {
+    OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_gather_scores: handle not committed");
     if (!h->comm) return fail(OWW_ESTATE, "oww_gather_scores: call oww_comm_init first");
     if (!counts) return fail(OWW_EINVAL, "oww_gather_scores: counts is null");
@@ -2336,13 +2431,27 @@ int oww_gather_scores(oww_ctx* h, float* out, const int32_t* counts) {
     if (rc_recv) RCCLCHK(rc_recv);
     RCCLCHK(rc_end);
     return OWW_OK;
+    OWW_GUARD_END
+}
+
+int oww_comm_count(oww_ctx* h, int32_t* ranks) {
+    OWW_GUARD_BEGIN
+    if (!h || !ranks) return fail(OWW_EINVAL, "oww_comm_count: null argument");
+    if (!h->comm) return fail(OWW_ESTATE, "oww_comm_count: call oww_comm_init first");
+    int n = 0;
+    RCCLCHK(g_rccl.CommCount(h->comm, &n));
+    *ranks = n;
+    return OWW_OK;
+    OWW_GUARD_END
 }
 
 int oww_comm_destroy(oww_ctx* h) {
+    OWW_GUARD_BEGIN
     if (!h) return OWW_OK;
     if (h->comm) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->stream); }
     comm_release(h);
     return OWW_OK;
+    OWW_GUARD_END
 }
 
 }  // extern "C"

@@ -79,10 +79,15 @@ __device__ __forceinline__ void nan_guard(lanemask_t& bad, float x) {
     asm volatile("" : "+s"(bad));
 #endif
 }
-// flag[0] = raised; flag[1], flag[2] = first stream and stream count of (one of) the wave(s) that saw it (last writer wins: any
-// offender is enough for a caller that wants to reset the streams concerned instead of the whole handle, oww_range_where)
+// flag[0] = raised; flag[1] = ONE packed word (first stream << 6 | stream count, count <= 32; -1 = position unknown) of one of the
+// waves that saw it.  Several waves -- of different kernels, reporting 1, 2, 4, 8 or 32 streams -- may write concurrently; a single
+// aligned 32-bit store is indivisible, so whichever write lands last, first and count always belong to the same wave (any offender is
+// enough for a caller that resets the streams concerned instead of the whole handle: oww_range_where).
 __device__ __forceinline__ void raise_range_flag(lanemask_t bad, int* flag, int first_stream = -1, int n_streams = 0) {
-    if (bad != 0 && flag != nullptr && (threadIdx.x & 63) == 0) { flag[1] = first_stream; flag[2] = n_streams; *flag = 1; }
+    if (bad != 0 && flag != nullptr && (threadIdx.x & 63) == 0) {
+        flag[1] = first_stream < 0 ? -1 : (int)(((unsigned)first_stream << 6) | (unsigned)(n_streams & 63));
+        *flag = 1;
+    }
 }
 
 #ifndef OWH_MIXSPLIT

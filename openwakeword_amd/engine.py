@@ -501,6 +501,12 @@ class StreamEngine:
         c = np.ascontiguousarray(counts, dtype=np.int32)
         _lib.check(self._lib.oww_gather_scores(self._h, C.c_void_p(int(out_dev_ptr)), _ptr(c)))
 
+    def comm_count(self) -> int:
+        """Ranks the handle's RCCL communicator itself reports (ncclCommCount)."""
+        n = C.c_int32(0)
+        _lib.check(self._lib.oww_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
     def comm_destroy(self) -> None:
         _lib.check(self._lib.oww_comm_destroy(self._h))
 

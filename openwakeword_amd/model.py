@@ -240,6 +240,23 @@ class AudioFeatures:
         return buf[int(-1 * n_feature_frames):, :][None, ].astype(np.float32)
 
 
+def make_engine(n_streams: int, heads: dict, embedding: dict, use_mfma: Optional[int] = None, **kw) -> StreamEngine:
+    """The engine behind Model / BatchedModel.  `use_mfma` None = the default fp16-split family (3), and -- when oww_commit refuses
+    these weights for it (OWW_ERANGE: the commit-time comparison with the exact-fp32 kernels failed, i.e. the weights' range cannot be
+    carried by f16 hi/lo pairs) -- the exact-fp32 family (1) instead, under a loud RuntimeWarning: a custom-trained model must never
+    be unloadable.  An explicit value is taken as given (and an explicit 3 raises on such weights)."""
+    from ._lib import OwwRangeError
+    if use_mfma is not None:
+        return StreamEngine(n_streams, heads, embedding, use_mfma=int(use_mfma), **kw)
+    try:
+        return StreamEngine(n_streams, heads, embedding, use_mfma=3, **kw)
+    except OwwRangeError as e:
+        import warnings
+        warnings.warn(f"{e} -- falling back to the exact-fp32 kernel family (use_mfma=1): same results, about 2.5x slower; masked "
+                      "steps (predict_active / the fan-in server) need the fp16-split family", RuntimeWarning)
+        return StreamEngine(n_streams, heads, embedding, use_mfma=1, **kw)
+
+
 class Model:
     """openwakeword.Model on the HIP library (one stream per object)."""
 
@@ -259,14 +276,15 @@ class Model:
         except Exception as e:                       # ImportError of the package itself or of onnxruntime / tflite inside it
             raise ValueError(f"inference_framework='{framework}' is served by the reference package, which cannot be imported "
                              f"here ({type(e).__name__}: {e}); use inference_framework='hip'") from e
-        passthrough = {k: v for k, v in kwargs.items() if k not in ("weights", "device", "max_chunks", "vad_session")}
+        passthrough = {k: v for k, v in kwargs.items() if k not in ("weights", "device", "max_chunks", "vad_session", "use_mfma")}
         return reference_package.Model(*args, **passthrough)
 
     def __init__(self, wakeword_models: List[str] = [], class_mapping_dicts: List[dict] = [],
                  enable_speex_noise_suppression: bool = False, vad_threshold: float = 0,
                  custom_verifier_models: dict = {}, custom_verifier_threshold: float = 0.1,
                  inference_framework: str = "hip", weights: Union[str, dict, None] = None, device: int = 0,
-                 max_chunks: int = 32, wakeword_model_paths: Optional[List[str]] = None, vad_session=None, **kwargs):
+                 max_chunks: int = 32, wakeword_model_paths: Optional[List[str]] = None, vad_session=None,
+                 use_mfma: Optional[int] = None, **kwargs):
         if wakeword_model_paths is not None:            # deprecated alias (model.py:37)
             wakeword_models = wakeword_model_paths
         seed, embedding, given_heads = resolve_weights(weights)
@@ -319,8 +337,8 @@ class Model:
             from .vad import VAD
             self.vad = VAD(session=vad_session)         # raises ValueError without a network (silero_vad.onnx is not in the checkout)
 
-        self._engine = StreamEngine(1, heads, embedding, device=device, max_chunks=max_chunks,
-                                    feature_ring=AudioFeatures.feature_buffer_max_len)
+        self._engine = make_engine(1, heads, embedding, use_mfma, device=device, max_chunks=max_chunks,
+                                   feature_ring=AudioFeatures.feature_buffer_max_len)
         self._cols = self._engine.head_cols
         self.preprocessor = AudioFeatures(self._engine, 0)
 
@@ -470,7 +488,7 @@ class BatchedModel:
 
     def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict, None] = None,
                  device: int = 0, max_chunks: int = 1, hip_stream: int = 0, vad_weights: Optional[dict] = None,
-                 vad_threshold: float = 0.0):
+                 vad_threshold: float = 0.0, use_mfma: Optional[int] = None):
         # same weight resolution as Model: real .onnx files (heads AND the shared embedding network) unless synthetic
         # weights are asked for explicitly -- never a random-init embedding under real heads
         seed, emb, given = resolve_weights(weights)
@@ -492,11 +510,11 @@ class BatchedModel:
                 from . import onnx_ingest
                 try:
                     vad_weights = onnx_ingest.load_vad(path)
-                except ValueError as e:
+                except Exception as e:               # refused by name (ValueError) or unreadable in a way the reader did not foresee
                     import warnings
                     warnings.warn(f"{e} -- the VAD gate of this BatchedModel waits for push_vad() scores", RuntimeWarning)
-        self.engine = StreamEngine(n_streams, heads, emb, device=device, max_chunks=max_chunks, hip_stream=hip_stream,
-                                   vad=vad_weights, vad_threshold=vad_threshold)
+        self.engine = make_engine(n_streams, heads, emb, use_mfma, device=device, max_chunks=max_chunks, hip_stream=hip_stream,
+                                  vad=vad_weights, vad_threshold=vad_threshold)
         self.labels: List[str] = []
         self._keep: List[int] = []
         col = 0

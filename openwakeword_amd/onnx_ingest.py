@@ -325,7 +325,20 @@ def load_vad(path: str) -> dict:
     described anywhere in the reference and no copy of the file exists offline, so what this function does with
     the real release asset is unknown until one is seen: anything that is not exactly the structure above is REFUSED with a
     ValueError that lists what was found -- the caller then keeps the host path (`VAD(session=onnxruntime session)`,
-    `oww_push_vad`) instead of a silently different network."""
+    `oww_push_vad`) instead of a silently different network.  Any other failure while reading or recognising the file (a truncated
+    protobuf, an LSTM node without its optional inputs, `If` subgraphs, attributes of an unexpected type ...) is a refusal too: it
+    surfaces as the same ValueError, never as an IndexError / KeyError / struct.error from the middle of the reader."""
+    try:
+        return _load_vad(path)
+    except ValueError:
+        raise
+    except Exception as e:
+        raise ValueError(f"{path}: not the voice-activity architecture the HIP kernels implement (the graph could not be read as one: "
+                         f"{type(e).__name__}: {e}).  Drive this network on the host instead (openwakeword_amd.VAD(session=...) / "
+                         "oww_push_vad): the gate, the score ring and the state handling of vad.py stay the same") from e
+
+
+def _load_vad(path: str) -> dict:
     g = load_graph(path)
     inits, nodes = g["initializers"], g["nodes"]
     ops = [n["op"] for n in nodes]

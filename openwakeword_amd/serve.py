@@ -16,6 +16,11 @@ all of them, two steps in flight (upload of step t+1 while the kernels of step t
 A connection without a full chunk sits the step out bit-exactly (no zero padding, no skipped audio), so each client gets exactly the
 scores a private `openwakeword.Model` would have produced on its own audio in 1280-sample calls.
 
+Slot placement (`SlotAllocator`): a masked step launches only the 2 / 4 / 8 / 16 / 32-stream groups that hold a participant, so its
+cost follows the number of GROUPS touched, not the number of streams.  Connections are therefore placed by cohort -- message period
+(first message's duration) and arrival phase within that period -- so that clients whose chunks fall due in the same pump round
+share groups: participation per group becomes all-or-nothing instead of "every group holds somebody".
+
 Sample-rate conversion follows the example (per message, stateless: `resampy.resample(data, sample_rate, 16000)`,
 streaming_server.py:57-58) with scipy's polyphase resampler; resampy is not a dependency here.
 
@@ -59,16 +64,99 @@ def to_16k(pcm: np.ndarray, sample_rate: int) -> np.ndarray:
     return resample.apply_numpy(pcm[None, :], int(sample_rate))[0]
 
 
-class _Client:
-    __slots__ = ("slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed", "in_flight")
+class SlotAllocator:
+    """Stream slots handed out in blocks of `group` consecutive streams per cohort key.
 
-    def __init__(self, slot: int, ws):
-        self.slot, self.ws, self.rate = slot, ws, 16000
+    `alloc(key)` prefers a block already tagged with `key` that has a free slot, then an untouched block (which it tags), then the
+    block of the nearest key (`distance(key_a, key_b)`, smaller = closer; default: equal or not), then anything free.  `release`
+    returns a slot; a block whose slots are all free loses its tag.  Pure bookkeeping: O(1) amortised per call, no device work."""
+
+    def __init__(self, n_slots: int, group: int = 32, distance=None):
+        self.n_slots, self.group = int(n_slots), int(group)
+        self.n_blocks = (self.n_slots + self.group - 1) // self.group
+        self._fresh: List[int] = list(range(self.n_blocks - 1, -1, -1))          # untouched blocks, lowest index on top
+        self._free: Dict[int, List[int]] = {}                                    # block -> free slots (descending: pop() = lowest)
+        self._tag: Dict[int, object] = {}                                        # block -> cohort key
+        self._open: Dict[object, List[int]] = {}                                 # key -> blocks of that key with a free slot
+        self._distance = distance or (lambda a, b: 0 if a == b else 1)
+        self.n_used = 0
+
+    def _block_slots(self, b: int) -> List[int]:
+        return list(range(min(self.n_slots, (b + 1) * self.group) - 1, b * self.group - 1, -1))
+
+    def _take(self, b: int) -> int:
+        slot = self._free[b].pop()
+        if not self._free[b]:
+            self._open[self._tag[b]].remove(b)
+        self.n_used += 1
+        return slot
+
+    def alloc(self, key=None) -> int:
+        if self.n_used >= self.n_slots:
+            raise IndexError("no free stream slot")
+        blocks = self._open.get(key)
+        if blocks:
+            return self._take(blocks[-1])
+        if self._fresh:
+            b = self._fresh.pop()
+            self._free[b] = self._block_slots(b)
+            self._tag[b] = key
+            self._open.setdefault(key, []).append(b)
+            return self._take(b)
+        near = min((k for k, bl in self._open.items() if bl), key=lambda k: self._distance(key, k))
+        return self._take(self._open[near][-1])
+
+    def release(self, slot: int) -> None:
+        b = slot // self.group
+        free = self._free[b]
+        if slot in free:
+            raise ValueError(f"slot {slot} is not in use")
+        if not free:
+            self._open.setdefault(self._tag[b], []).append(b)
+        free.append(slot)
+        free.sort(reverse=True)
+        self.n_used -= 1
+        if len(free) == len(self._block_slots(b)):           # the block is empty again: any cohort may claim it
+            self._open[self._tag[b]].remove(b)
+            del self._free[b], self._tag[b]
+            self._fresh.append(b)
+            self._fresh.sort(reverse=True)
+
+    def key_of(self, slot: int):
+        return self._tag.get(slot // self.group)
+
+
+N_PHASE_BINS = 8
+
+
+def cohort_key(period_s: float, arrival_s: float, n_bins: int = N_PHASE_BINS):
+    """(message period in ms, phase bin of the arrival within that period): clients with equal keys have their chunks fall due in
+    the same pump rounds for as long as they keep their pace."""
+    period_ms = max(1, int(round(period_s * 1e3)))
+    phase = (arrival_s % (period_ms * 1e-3)) / (period_ms * 1e-3)
+    return period_ms, min(n_bins - 1, int(phase * n_bins))
+
+
+def cohort_distance(a, b) -> float:
+    """Same period first, then the cyclic distance between phase bins."""
+    if a is None or b is None:
+        return 1e6
+    d = abs(a[1] - b[1])
+    return (0 if a[0] == b[0] else 1e3) + min(d, N_PHASE_BINS - d)
+
+
+class _Client:
+    __slots__ = ("cid", "slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed", "in_flight", "outbox", "sender")
+
+    def __init__(self, slot: Optional[int], ws, cid: int = -1):
+        self.cid, self.slot, self.ws, self.rate = cid, slot, ws, 16000
         self.pending: List[np.ndarray] = []
         self.n_pending = 0
         self.n_steps = 0
         self.closed = False
         self.in_flight = 0            # submitted steps whose scores for this client have not been dispatched yet
+        self.outbox: "collections.deque" = collections.deque()     # activation messages not yet written to the socket, in step order
+        self.sender: Optional[asyncio.Task] = None                  # the one task that drains `outbox`
 
     def push(self, x: np.ndarray) -> None:
         if x.size:
@@ -134,8 +222,11 @@ class FanInServer:
     """`model`: a BatchedModel; its n_streams is the number of clients that can be connected at once (further connections are
     refused with close code 1013).  `window_s`: how long the pump waits after the first chunk of a round becomes available for other
     connections' chunks to arrive before it steps (0 = step at once; real-time clients deliver one chunk per 80 ms, so a few ms
-    gathers nearly everyone into the same step).  `on_scores(slot, step_index, scores_row)`: optional tap, called for every
-    stream-step (used by the tests).
+    gathers nearly everyone into the same step).  `on_scores(connection_id, step_index, scores_row)`: optional tap, called for every
+    stream-step (used by the tests; connection ids count accepted connections from 0).
+
+    A connection gets its stream slot with its first audio message -- until then it has no device state to keep -- from a
+    `SlotAllocator` keyed by the message's duration and arrival phase (`cohort_key`), see the module docstring.
 
     Steps go through the host-fed pipeline (`oww_submit_masked` / `oww_collect`): while the kernels of step t run, the pump already
     gathers and uploads step t+1 from page-locked buffers; at most two steps are in flight, scores are dispatched in step order."""
@@ -145,8 +236,11 @@ class FanInServer:
         self.threshold = float(threshold)
         self.window_s = float(window_s)
         self.on_scores = on_scores
-        self.free: List[int] = list(range(model.n_streams - 1, -1, -1))
-        self.clients: Dict[int, _Client] = {}
+        self.slots = SlotAllocator(model.n_streams, group=32, distance=cohort_distance)
+        self.clients: Dict[int, _Client] = {}          # by stream slot: the connections that have sent audio
+        self.conns: Dict[int, _Client] = {}            # by connection id: every accepted connection
+        self._next_cid = 0
+        self._tasks: set = set()                       # sender tasks (asyncio keeps only weak references to tasks)
         self._have_chunk: Optional[asyncio.Event] = None
         self._pump_task: Optional[asyncio.Task] = None
         self._gpu: Optional[_GpuWorker] = None
@@ -156,6 +250,7 @@ class FanInServer:
         self.n_steps = 0              # batched steps taken
         self.n_stream_steps = 0       # sum over steps of the streams that took part
         self.n_range_recoveries = 0   # OWW_ERANGE events the pump recovered from (see _recover_range)
+        self._last_recovery_step = -10**9
         self.send_timeout_s = 2.0     # deadline of one activation message / close handshake
         self.failed: Optional[BaseException] = None      # set when the pump died of anything it cannot recover from
 
@@ -190,15 +285,12 @@ class FanInServer:
         if self.failed is not None:
             await ws.close(code=1011, message=b"scoring backend failed")
             return ws
-        if not self.free:
+        if len(self.conns) >= self.model.n_streams:
             await ws.close(code=1013, message=b"all stream slots are taken")
             return ws
-        slot = self.free.pop()
-        # a slot handed to a new caller starts from Model()'s initial state, VAD history included; the job queue orders the reset
-        # after every step already submitted
-        await self._gpu.call(self.model.reset, [slot], reset_vad=bool(self.model.engine.has_vad))
-        c = _Client(slot, ws)
-        self.clients[slot] = c
+        c = _Client(None, ws, cid=self._next_cid)
+        self._next_cid += 1
+        self.conns[c.cid] = c
         try:
             await ws.send_str(json.dumps({"loaded_models": list(self.model.labels)}))
             async for msg in ws:
@@ -208,12 +300,21 @@ class FanInServer:
                     except ValueError:
                         rate = 0
                     if rate not in RATES:                   # (the example trusts the client here; see RATES)
-                        await ws.close(code=1003, message=b"the first text message must be the sample rate in Hz, one of " +
-                                       ",".join(str(r) for r in RATES).encode())
+                        # the accepted rates go out as a message: a close reason is limited to 123 bytes (RFC 6455, 5.5)
+                        await ws.send_str(json.dumps({"error": "unsupported sample rate", "accepted_rates": list(RATES)}))
+                        await ws.close(code=1003, message=b"unsupported sample rate")
                         break
                     c.rate = rate
                 elif msg.type == WSMsgType.BINARY:
                     n = len(msg.data) // 2
+                    if c.slot is None and n:
+                        # the first audio: place the connection next to the ones whose chunks fall due in the same rounds.  A slot
+                        # handed to a new caller starts from Model()'s initial state, VAD history included; the job queue orders
+                        # the reset after every step already submitted
+                        loop = asyncio.get_running_loop()
+                        c.slot = self.slots.alloc(cohort_key(n / c.rate, loop.time()))
+                        self.clients[c.slot] = c
+                        await self._gpu.call(self.model.reset, [c.slot], reset_vad=bool(self.model.engine.has_vad))
                     x = np.frombuffer(msg.data, dtype="<i2", count=n)
                     if c.rate != 16000:                     # filtering runs on the default executor, not on the event loop
                         x = await asyncio.get_running_loop().run_in_executor(None, to_16k, x, c.rate)
@@ -228,24 +329,44 @@ class FanInServer:
         return ws
 
     def _reap(self) -> None:
-        for slot in [s for s, c in self.clients.items() if c.closed and c.n_pending < CHUNK and c.in_flight == 0]:
-            del self.clients[slot]
-            self.free.append(slot)
+        for c in [c for c in self.conns.values() if c.closed and c.n_pending < CHUNK and c.in_flight == 0]:
+            del self.conns[c.cid]
+            if c.slot is not None:
+                del self.clients[c.slot]
+                self.slots.release(c.slot)
 
     # ---- the one place steps are put together
-    async def _send(self, c: "_Client", text: str) -> None:
-        """One client's activation message, on its own task and with a deadline: a stalled socket never holds up the pump."""
-        try:
-            await asyncio.wait_for(c.ws.send_str(text), timeout=self.send_timeout_s)
-        except (ConnectionError, RuntimeError, asyncio.TimeoutError):
-            c.closed = True
+    def _post(self, c: "_Client", text: str) -> None:
+        """Queue one activation message for a client.  Each client has ONE sender task that writes its queue in order (messages of
+        consecutive steps cannot overtake each other) with a deadline per message, so a stalled socket never holds up the pump and
+        never accumulates more than its own bounded queue; the task set keeps the tasks alive until they finish."""
+        if c.closed or len(c.outbox) >= 64:
+            return
+        c.outbox.append(text)
+        if c.sender is None or c.sender.done():
+            c.sender = asyncio.get_running_loop().create_task(self._drain(c))
+            self._tasks.add(c.sender)
+            c.sender.add_done_callback(self._tasks.discard)
+
+    async def _drain(self, c: "_Client") -> None:
+        while c.outbox and not c.closed:
+            text = c.outbox.popleft()
+            try:
+                await asyncio.wait_for(c.ws.send_str(text), timeout=self.send_timeout_s)
+            except (ConnectionError, RuntimeError, asyncio.TimeoutError):
+                c.closed = True
+                c.outbox.clear()
 
     async def _recover_range(self, flying) -> None:
         """OWW_ERANGE is sticky per handle: one stream whose activations left the f16 range would stop scoring for everybody.  The
         streams of the wave that saw it (oww_range_where; every stream when the position is unknown) restart from Model()'s initial
         state -- their clients keep their connections and simply see a few silent frames -- the steps in flight are dropped and the
-        flag is cleared."""
+        flag is cleared.  The reported position names ONE offending wave; if the flag comes back within a few steps of a partial
+        recovery another stream was (also) out of range, and every stream is restarted instead of dropping the clients' steps again
+        and again."""
         self.n_range_recoveries += 1
+        again = self.n_steps - self._last_recovery_step <= 8
+        self._last_recovery_step = self.n_steps
         def recover():
             eng = self.model.engine
             for _ in range(len(flying)):
@@ -255,7 +376,7 @@ class FanInServer:
                     pass
             first, n = eng.range_where()
             eng.range_status(clear=True)
-            ids = list(range(first, first + n)) if first >= 0 and n > 0 else None      # None: not known -> every stream
+            ids = list(range(first, first + n)) if (first >= 0 and n > 0 and not again) else None      # None: every stream
             self.model.reset(ids, reset_vad=bool(eng.has_vad))
             eng.range_status(clear=True)
         await self._gpu.call(recover)
@@ -295,11 +416,11 @@ class FanInServer:
                             c.in_flight -= 1
                             row = scores[c.slot]
                             if self.on_scores is not None:
-                                self.on_scores(c.slot, c.n_steps, row)
+                                self.on_scores(c.cid, c.n_steps, row)
                             c.n_steps += 1
                             hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
                             if hits and not c.closed:
-                                asyncio.get_running_loop().create_task(self._send(c, json.dumps({"activations": hits})))
+                                self._post(c, json.dumps({"activations": hits}))
                         self._reap()
                 except OwwRangeError:
                     await self._recover_range(flying)
@@ -312,8 +433,8 @@ class FanInServer:
             # accepting audio that is silently dropped
             self.failed = e
             import logging
-            logging.getLogger("openwakeword_amd.serve").exception("the GPU pump failed; closing %d connections", len(self.clients))
-            for c in list(self.clients.values()):
+            logging.getLogger("openwakeword_amd.serve").exception("the GPU pump failed; closing %d connections", len(self.conns))
+            for c in list(self.conns.values()):
                 c.closed = True
                 try:
                     await asyncio.wait_for(c.ws.close(code=1011, message=b"scoring backend failed"), timeout=self.send_timeout_s)
@@ -331,9 +452,12 @@ def main(argv=None) -> None:
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--port", type=int, default=9000)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--use-mfma", type=int, default=3, choices=(3,),
+                    help="kernel family; the fan-in server steps through oww_submit_masked, which the fp16-split family (3) provides -- "
+                         "weights that family refuses at commit (OWW_ERANGE) cannot be served batched-and-masked")
     a = ap.parse_args(argv)
     from .model import BatchedModel
-    model = BatchedModel(a.streams, a.models, weights=a.weights, device=a.device)
+    model = BatchedModel(a.streams, a.models, weights=a.weights, device=a.device, use_mfma=a.use_mfma)
     web.run_app(FanInServer(model, threshold=a.threshold).app(), host=a.host, port=a.port)
 
 

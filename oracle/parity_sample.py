@@ -25,7 +25,7 @@ N_PROBE = 64
 N_FRAMES = 16
 SEED_WEIGHTS = 1234
 SEED_INIT_NOISE = 3
-PROBE_VERSION = 2           # bump when probe_pcm changes (part of the cache file name)
+PROBE_VERSION = 3           # bump when probe_pcm changes (part of the cache file name)
 HEADS3 = ("alexa", "hey_mycroft", "hey_jarvis")
 _GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_streaming.npz")
 
@@ -70,21 +70,39 @@ def init_noise() -> np.ndarray:
     return W.synthetic_pcm(1, 64000, seed=SEED_INIT_NOISE, rms=600.0)[0]
 
 
-def _worker(args) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    rows, head_names = args
+VAD_THRESHOLD = 0.5        # the gate of BASELINE configs[4] (model.py:366-381) as bench.py / the tests configure it
+
+
+def _model(heads, emb, vad: bool):
     from oracle import oww_oracle as O
+    if not vad:
+        return O.OracleModel(heads, emb, init_noise=init_noise())
+    from oracle import vad_standin as V
+    from openwakeword_amd import weights as W
+    return O.OracleModel(heads, emb, init_noise=init_noise(), vad_threshold=VAD_THRESHOLD,
+                         vad_session=V.StandinVadSession(W.synthetic_vad(SEED_WEIGHTS)))
+
+
+def _worker(args) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    rows, head_names, vad = args
     emb, heads = _weights(head_names)
-    proto = O.OracleModel(heads, emb, init_noise=init_noise())
+    proto = _model(heads, emb, vad)
     feats0 = np.array(proto.preprocessor.features, dtype=np.float32)
-    out = np.zeros((len(rows), rows[0].shape[0] // CHUNK, len(head_names)), np.float64)
+    n_frames = rows[0].shape[0] // CHUNK
+    out = np.zeros((len(rows), n_frames, len(head_names)), np.float64)
     last = np.zeros((len(rows), 16, 96), np.float32)
+    gate = np.full((len(rows), n_frames), np.nan)                # max of the VAD ring's [-7:-4] window the gate compared (NaN: empty)
     for i, pcm in enumerate(rows):
-        m = proto if i == 0 else O.OracleModel(heads, emb, init_noise=init_noise())
-        for t in range(pcm.shape[0] // CHUNK):
+        m = proto if i == 0 else _model(heads, emb, vad)
+        for t in range(n_frames):
             p = m.predict(pcm[t * CHUNK:(t + 1) * CHUNK])
             out[i, t] = [p[k] for k in head_names]
+            if vad:
+                window = list(m.vad.ring)[-7:-4]
+                if window:
+                    gate[i, t] = float(np.max(window))
         last[i] = np.asarray(m.preprocessor.features[-16:], dtype=np.float32)
-    return out, feats0, last
+    return out, feats0, last, gate
 
 
 def effective_cpus() -> int:
@@ -111,12 +129,12 @@ def effective_cpus() -> int:
     return n
 
 
-def _run_pool(pcm: np.ndarray, head_names: List[str], workers: int) -> Dict[str, np.ndarray]:
+def _run_pool(pcm: np.ndarray, head_names: List[str], workers: int, vad: bool = False) -> Dict[str, np.ndarray]:
     n = pcm.shape[0]
     cores = effective_cpus()
     workers = max(1, min(workers or cores, n, 64))
     parts = [list(range(w, n, workers)) for w in range(workers)]
-    jobs = [([pcm[i] for i in idx], head_names) for idx in parts]
+    jobs = [([pcm[i] for i in idx], head_names, vad) for idx in parts]
     if workers == 1:
         res = [_worker(jobs[0])]
     else:
@@ -124,16 +142,21 @@ def _run_pool(pcm: np.ndarray, head_names: List[str], workers: int) -> Dict[str,
             res = pool.map(_worker, jobs)
     scores = np.zeros((n, pcm.shape[1] // CHUNK, len(head_names)), np.float64)
     feats = np.zeros((n, 16, 96), np.float32)
-    for idx, (out, _, last) in zip(parts, res):
+    gate = np.full((n, pcm.shape[1] // CHUNK), np.nan)
+    for idx, (out, _, last, g) in zip(parts, res):
         scores[idx] = out
         feats[idx] = last
-    return {"scores": scores, "init_features": res[0][1], "features": feats, "heads": np.array(head_names)}
+        gate[idx] = g
+    return {"scores": scores, "init_features": res[0][1], "features": feats, "heads": np.array(head_names), "vad_window_max": gate}
 
 
 def oracle_reference(n_probe: int = N_PROBE, n_frames: int = N_FRAMES, head_names: Sequence[str] = HEADS3,
-                     workers: int = 0, timeout_s: float = 1500.0) -> Dict[str, np.ndarray]:
+                     workers: int = 0, timeout_s: float = 1500.0, vad: bool = False) -> Dict[str, np.ndarray]:
     """Oracle results for `probe_pcm(n_probe, n_frames)`: scores [n_probe, n_frames, n_heads] (float64), the feature-ring
-    seed every stream starts from ([41, 96], oldest first) and each probe's last 16 feature rows.
+    seed every stream starts from ([41, 96], oldest first) and each probe's last 16 feature rows.  With `vad` every model carries
+    the voice-activity gate of BASELINE configs[4] (model.py:366-381; threshold VAD_THRESHOLD, the stand-in network with the seed-1234
+    weights behind the reference's VAD wrapper) and `vad_window_max` [n_probe, n_frames] holds the value each gate decision compared
+    with the threshold (NaN while the window is empty), so that a caller can skip decisions within rounding of it.
 
     Computed by a FRESH interpreter (`python -m oracle.parity_sample`) that fans the streams out over forked workers:
     the caller may already hold a HIP context / BLAS thread pools, neither of which survives a fork reliably, and a
@@ -142,14 +165,14 @@ def oracle_reference(n_probe: int = N_PROBE, n_frames: int = N_FRAMES, head_name
     import sys
     import tempfile
     head_names = list(head_names)
-    tag = f"oww_parity_{n_probe}x{n_frames}_{'-'.join(head_names)}_{SEED_WEIGHTS}_{SEED_INIT_NOISE}_v{PROBE_VERSION}.npz"
+    tag = f"oww_parity_{n_probe}x{n_frames}_{'-'.join(head_names)}_{SEED_WEIGHTS}_{SEED_INIT_NOISE}_v{PROBE_VERSION}{'_vad' if vad else ''}.npz"
     path = os.path.join(tempfile.gettempdir(), tag)
     if not os.path.exists(path):
         root = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         tmp = path + f".{os.getpid()}.tmp.npz"
         # one BLAS thread per forked worker: the workers already cover the cores (an unbounded pool per worker oversubscribes the host)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        subprocess.run([sys.executable, "-m", "oracle.parity_sample", tmp, str(n_probe), str(n_frames), str(workers)] + head_names,
+        subprocess.run([sys.executable, "-m", "oracle.parity_sample", tmp, str(n_probe), str(n_frames), str(workers), str(int(vad))] + head_names,
                        cwd=root, check=True, timeout=timeout_s, env=env)
         os.replace(tmp, path)
     z = np.load(path)
@@ -173,5 +196,5 @@ def probe_stream_ids(n_streams: int, n_probe: int = N_PROBE, seed: int = 7) -> n
 
 if __name__ == "__main__":
     import sys
-    out_path, n_probe_, n_frames_, workers_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    np.savez(out_path, **_run_pool(probe_pcm(n_probe_, n_frames_), list(sys.argv[5:]), workers_))
+    out_path, n_probe_, n_frames_, workers_, vad_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), bool(int(sys.argv[5]))
+    np.savez(out_path, **_run_pool(probe_pcm(n_probe_, n_frames_), list(sys.argv[6:]), workers_, vad_))

@@ -26,7 +26,7 @@ def test_library_is_built_and_exports_the_header():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/owwhip.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.oww_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.oww_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_blob_layouts():

@@ -126,7 +126,7 @@ def test_fan_in_server_gives_each_client_private_scores():
     model = BatchedModel(8, HEADS, weights=wts)
     tap = {}
     srv = FanInServer(model, threshold=0.02, window_s=0.002,
-                      on_scores=lambda slot, k, row: tap.setdefault(slot, []).append(row.copy()))
+                      on_scores=lambda cid, k, row: tap.setdefault(cid, []).append(row.copy()))
     plans = [(16000, 1280, 30), (16000, 700, 41), (8000, 640, 36), (48000, 4096, 25), (16000, 5000, 9)]   # rate, samples/message, messages
     audio = [(rng.standard_normal(n * m) * 5000).astype(np.int16) for _r, n, m in plans]
     got = [dict(loaded=None, hits=[]) for _ in plans]
@@ -157,10 +157,10 @@ def test_fan_in_server_gives_each_client_private_scores():
     async def run():
         async with TestClient(TestServer(srv.app())) as tc:
             wss = []
-            for i in range(len(plans)):          # one after the other: client i owns slot i
+            for i in range(len(plans)):          # one after the other: client i is connection i (its slot comes with its first audio)
                 ws = await tc.ws_connect("/ws")
                 got[i]["loaded"] = json.loads((await ws.receive()).data)["loaded_models"]
-                assert srv.clients[i].slot == i
+                assert srv.conns[i].cid == i and srv.conns[i].slot is None
                 wss.append(ws)
             return await asyncio.gather(*[client(ws, i) for i, ws in enumerate(wss)])
 
@@ -226,7 +226,7 @@ def test_fan_in_server_slot_reuse_and_refusal():
     heads = {n: W.synthetic_head(n, seed=11 + i) for i, n in enumerate(HEADS)}
     model = BatchedModel(2, HEADS, weights={"heads": heads, "embedding": W.synthetic_embedding(seed=3)})
     tap = {}
-    srv = FanInServer(model, threshold=2.0, window_s=0.0, on_scores=lambda slot, k, row: tap.setdefault(slot, []).append(row.copy()))
+    srv = FanInServer(model, threshold=2.0, window_s=0.0, on_scores=lambda cid, k, row: tap.setdefault(cid, []).append(row.copy()))
     first = (rng.standard_normal(1280 * 12) * 6000).astype(np.int16)
     second = (rng.standard_normal(1280 * 9) * 2000).astype(np.int16)
 
@@ -241,26 +241,28 @@ def test_fan_in_server_slot_reuse_and_refusal():
             await a.send_bytes(first.tobytes())                       # one message, twelve chunks
             while len(tap.get(0, [])) < 12:
                 await asyncio.sleep(0.01)
+            assert srv.conns[0].slot == 0 and srv.conns[1].slot is None   # (b has not sent audio: no device state, no slot yet)
             await a.close()
-            while 0 in srv.clients:
+            while 0 in srv.conns:
                 await asyncio.sleep(0.01)
             n_before = len(tap[0])
-            d = await tc.ws_connect("/ws"); await d.receive()        # takes over slot 0
-            assert sorted(srv.clients) == [0, 1]
+            d = await tc.ws_connect("/ws"); await d.receive()        # connection 2 ...
             await d.send_bytes(second.tobytes())
-            while len(tap[0]) < n_before + 9:
+            while len(tap.get(2, [])) < 9:
                 await asyncio.sleep(0.01)
+            assert srv.conns[2].slot == 0 and sorted(srv.clients) == [0]      # ... takes over slot 0
             await d.close(); await b.close()
             return n_before
 
     n_before = asyncio.run(asyncio.wait_for(run(), 60))
     model.close()
-    for audio, got in ((first, tap[0][:n_before]), (second, tap[0][n_before:])):
+    assert n_before == 12
+    for audio, got in ((first, tap[0]), (second, tap[2])):
         e = _engine(1)
         want = np.stack([e.step(audio[None, k * 1280:(k + 1) * 1280])[0] for k in range(audio.size // 1280)])
         e.close()
         np.testing.assert_array_equal(np.stack(got), want)
-    assert (np.stack(tap[0][n_before:n_before + 5]) == 0).all()        # model.py:331-333 for the new owner of the slot
+    assert (np.stack(tap[2][:5]) == 0).all()                           # model.py:331-333 for the new owner of the slot
 
 
 def test_masked_submit_pipeline_equals_masked_steps():

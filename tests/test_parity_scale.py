@@ -79,3 +79,43 @@ def test_probe_streams_match_oracle_inside_a_full_size_batch(probe, n_streams, h
     finally:
         eng.close()
     print(f"\n{n_streams} streams x {len(head_names)} heads, family {family}: 1024 (stream, step) pairs, max |score - oracle| = {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_c4_131072x3_vad_probe_streams_match_gated_oracle():
+    """BASELINE configs[4] at its per-GPU size: 131,072 streams x 3 heads with the voice-activity network and gate fused into every
+    step.  The 64 probe streams x 16 frames are compared with OracleModel(vad_threshold=0.5, vad_session=StandinVadSession)
+    -- the reference's gate (model.py:366-381) and VAD wrapper (vad.py:98-130) around the stand-in network; a gate decision whose
+    compared value lies within 1e-3 of the threshold is skipped (as in test_fused_vad_gate_matches_oracle_model) and counted."""
+    n_streams = 131072
+    pcm = PS.probe_pcm()
+    ref = PS.oracle_reference(vad=True)
+    emb, heads = PS._weights(PS.HEADS3)
+    ids = PS.probe_stream_ids(n_streams)
+    r = np.random.default_rng(n_streams + 4)
+    background = np.clip(np.round(r.normal(0.0, 3000.0, (n_streams, 1280))), -32768, 32767).astype(np.int16)
+    eng = StreamEngine(n_streams, heads, emb, vad=W.synthetic_vad(PS.SEED_WEIGHTS), vad_threshold=PS.VAD_THRESHOLD)
+    worst, skipped, n_gated, n_open = 0.0, 0, 0, 0
+    try:
+        eng.reset(None, ref["init_features"][-eng.feature_ring:])
+        buf = np.empty_like(background)
+        for t in range(PS.N_FRAMES):
+            np.copyto(buf, np.roll(background, 37 * t + 1, axis=1))
+            buf[ids] = pcm[:, t * 1280:(t + 1) * 1280]
+            got = eng.step(buf)
+            assert np.isfinite(got).all() and got.min() >= 0.0 and got.max() <= 1.0
+            want = ref["scores"][:, t]
+            g = ref["vad_window_max"][:, t]
+            keep = ~(np.abs(g - PS.VAD_THRESHOLD) < 1e-3)            # NaN (empty window: gated by definition) compares False -> kept
+            skipped += int((~keep).sum())
+            worst = max(worst, float(np.abs(got[ids][keep] - want[keep]).max()))
+            np.testing.assert_allclose(got[ids][keep], want[keep], rtol=0, atol=TOL_SCORE, err_msg=f"frame {t}")
+            if t >= 6:
+                n_gated += int((want[keep] == 0).all(axis=1).sum())
+                n_open += int((want[keep] != 0).any(axis=1).sum())
+        assert n_gated > 50 and n_open > 50 and skipped < 32         # both branches of the gate, and the skip rule is an exception
+        assert eng.range_status() is False
+    finally:
+        eng.close()
+    print(f"\nc4: {n_streams} streams x 3 heads + VAD gate: {1024 - skipped} (stream, step) pairs, max |score - oracle| = {worst:.2e}, "
+          f"{skipped} decisions within 1e-3 of the threshold skipped, {n_gated} gated / {n_open} open after frame 6")

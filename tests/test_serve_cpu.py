@@ -47,3 +47,49 @@ def test_client_queue_rechunks_any_message_sizes():
     np.testing.assert_array_equal(np.concatenate(got), data[:1280 * 7])
     c.push(data[:0])                                                        # empty messages are ignored
     assert c.n_pending == 333
+
+
+def test_slot_allocator_packs_cohorts_into_blocks():
+    """Connections with the same cohort key share 32-stream blocks; a mask of "everybody whose chunk is due in this half of the
+    period" then touches about half of the stream groups instead of nearly all of them (VERDICT r03 next 7)."""
+    rng = np.random.default_rng(5)
+    S = 4096
+    al = serve.SlotAllocator(S, group=32, distance=serve.cohort_distance)
+    arrivals = rng.random(S) * 10.0                                         # connection times over 10 s, 80 ms messages
+    keys = [serve.cohort_key(0.080, t) for t in arrivals]
+    slots = np.array([al.alloc(k) for k in keys])
+    assert sorted(slots.tolist()) == list(range(S)) and al.n_used == S
+    with pytest.raises(IndexError):
+        al.alloc(keys[0])
+    phase = np.array([k[1] for k in keys])
+    on = np.zeros(S, bool)
+    on[slots[phase < serve.N_PHASE_BINS // 2]] = True                       # one pump round: the first half of the period is due
+    groups8 = on.reshape(-1, 8).any(axis=1).mean()
+    rnd = np.zeros(S, bool)
+    rnd[rng.permutation(S)[: int(on.sum())]] = True
+    assert 0.45 < on.mean() < 0.55
+    assert groups8 < 0.60 and rnd.reshape(-1, 8).any(axis=1).mean() > 0.95   # packed: ~half the groups; random: nearly all
+    # release / reuse: a freed slot goes back to its cohort's block, an emptied block can be claimed by any cohort
+    k0 = al.key_of(int(slots[0]))
+    al.release(int(slots[0]))
+    assert al.alloc(k0) == slots[0]
+    with pytest.raises(ValueError):
+        al.release(int(slots[0])); al.release(int(slots[0]))
+    al2 = serve.SlotAllocator(64, group=32)
+    a = [al2.alloc("x") for _ in range(32)]
+    b = al2.alloc("y")
+    assert a == list(range(32)) and b == 32
+    for s_ in a:
+        al2.release(s_)
+    assert al2.alloc("z") == 0 and al2.key_of(0) == "z"
+    # every block taken by other cohorts: the nearest phase of the same period wins
+    al3 = serve.SlotAllocator(64, group=32, distance=serve.cohort_distance)
+    assert al3.alloc((80, 0)) == 0 and al3.alloc((80, 4)) == 32
+    assert al3.alloc((80, 3)) == 33 and al3.alloc((80, 7)) == 1 and al3.alloc((93, 4)) in (2, 34)
+
+
+def test_cohort_key_bins_by_period_and_phase():
+    assert serve.cohort_key(0.080, 0.0) == (80, 0)
+    assert serve.cohort_key(0.080, 0.079) == (80, 7)
+    assert serve.cohort_key(0.080, 8.0 + 0.045) == (80, 4)                  # the same phase ten periods later
+    assert serve.cohort_key(4096 / 48000.0, 0.0)[0] == 85                   # the reference client's 4096-sample buffers at 48 kHz
