@@ -12,9 +12,12 @@ Three graph families are recognised by structure, not by node names:
   19 BatchNormalization nodes -- or biases on the Conv nodes where an exporter folded the BatchNorm.
 * melspectrogram: analytic in this package; `check_melspectrogram` compares the file's filterbank with ours.
 
-No real model file exists in this environment, so the structural assumptions are pinned only by the
-round-trip test in tests/test_onnx_ingest.py (files written by a minimal protobuf writer); anything unrecognised raises
-ValueError instead of guessing.
+No real model file exists in this environment, so the structural assumptions are pinned by tests/test_onnx_ingest.py:
+two independent writers -- one in the plain idiom, one emitting the idioms tf2onnx (embedding model: NHWC <-> NCHW Transposes, Pad
+nodes, BatchNorm folded into Conv bias or written as Mul / Add, the activation as Max(Mul(x, 0.2), x) -> Max(., -0.4) or as
+LeakyRelu + Clip) and torch.onnx.export (heads: Gemm transB, opset-17 LayerNormalization or its decomposition, the hey_jarvis gate
+as Greater + Where or as an If with subgraphs) produce -- must load to the same weights.  The loaders walk the DATAFLOW and check
+every operator they pass against what the kernels compute; anything else raises ValueError naming the operator.
 """
 from __future__ import annotations
 
@@ -111,6 +114,8 @@ def _attribute(buf: bytes):
             val = v.decode(errors="replace")
         elif fno == 5:
             val = _tensor(v)[1]
+        elif fno == 6:
+            val = _graph(v)                                     # a subgraph (If then_branch / else_branch)
         elif fno == 7:
             val = (val or []) + (list(struct.unpack(f"<{len(v) // 4}f", v)) if wt == 2 else [struct.unpack("<f", v)[0]])
         elif fno == 8:
@@ -118,22 +123,19 @@ def _attribute(buf: bytes):
     return name, val
 
 
-def load_graph(path: str) -> dict:
-    """{'initializers': {name: ndarray}, 'nodes': [{'op', 'name', 'inputs', 'outputs', 'attrs'}]} of an ONNX file."""
-    data = open(path, "rb").read()
-    graph = None
-    for fno, wt, v in _fields(data):
-        if fno == 7 and wt == 2:
-            graph = v
-    if graph is None:
-        raise ValueError(f"{path}: no GraphProto found (not an ONNX ModelProto?)")
+def _graph(buf: bytes) -> dict:
+    """One GraphProto (the model's, or an If branch): initializers (Constant nodes included), nodes, input / output names."""
     inits: Dict[str, np.ndarray] = {}
-    nodes = []
-    for fno, wt, v in _fields(graph):
+    nodes, inputs, outputs = [], [], []
+    for fno, wt, v in _fields(buf):
         if fno == 5:
             name, arr = _tensor(v)
             if arr is not None:
                 inits[name] = arr
+        elif fno in (11, 12):                                   # ValueInfoProto: name = field 1
+            for f2, _w2, v2 in _fields(v):
+                if f2 == 1:
+                    (inputs if fno == 11 else outputs).append(v2.decode())
         elif fno == 1:
             node = {"op": "", "name": "", "inputs": [], "outputs": [], "attrs": {}}
             for f2, w2, v2 in _fields(v):
@@ -148,156 +150,572 @@ def load_graph(path: str) -> dict:
                 elif f2 == 5:
                     k, a = _attribute(v2)
                     node["attrs"][k] = a
-            if node["op"] == "Constant" and "value" in node["attrs"] and node["outputs"]:
+            if node["op"] == "Constant" and node["outputs"] and isinstance(node["attrs"].get("value"), np.ndarray):
                 inits[node["outputs"][0]] = node["attrs"]["value"]
+                continue
             nodes.append(node)
-    return {"initializers": inits, "nodes": nodes}
+    return {"initializers": inits, "nodes": nodes, "inputs": [i for i in inputs if i not in inits], "outputs": outputs}
+
+
+def load_graph(path: str) -> dict:
+    """{'initializers': {name: ndarray}, 'nodes': [{'op', 'name', 'inputs', 'outputs', 'attrs'}], 'inputs', 'outputs'} of an ONNX
+    file.  Constant nodes become initializers; shape-only operators on constants (Transpose / Reshape / Identity / Cast / Squeeze /
+    Unsqueeze of an initializer -- a weight stored HWIO behind a Transpose, a scalar behind a Cast) are folded away; subgraph
+    attributes (If branches) are graphs of the same form under attrs[...]."""
+    data = open(path, "rb").read()
+    graph = None
+    try:
+        for fno, wt, v in _fields(data):
+            if fno == 7 and wt == 2:
+                graph = v
+        g = _graph(graph) if graph is not None else None
+    except (IndexError, struct.error, UnicodeDecodeError) as e:
+        raise ValueError(f"{path}: not a readable ONNX ModelProto ({type(e).__name__}: {e})") from e
+    if g is None:
+        raise ValueError(f"{path}: no GraphProto found (not an ONNX ModelProto?)")
+    _fold_constants(g)
+    return g
+
+
+def _fold_constants(g: dict) -> None:
+    inits = g["initializers"]
+    keep = []
+    for n in g["nodes"]:
+        for a in n["attrs"].values():
+            if isinstance(a, dict) and "nodes" in a:
+                a["initializers"] = dict(inits, **a["initializers"])     # a branch sees the outer scope's constants
+                _fold_constants(a)
+        x = inits.get(n["inputs"][0]) if n["inputs"] else None
+        out = None
+        if x is not None and all(i in inits or i == "" for i in n["inputs"]):
+            if n["op"] == "Transpose":
+                out = np.transpose(x, n["attrs"].get("perm") or list(range(x.ndim))[::-1])
+            elif n["op"] in ("Identity", "Cast"):
+                out = x if n["op"] == "Identity" else x.astype(_DTYPES.get(n["attrs"].get("to", 1), np.float32))
+            elif n["op"] == "Reshape" and len(n["inputs"]) > 1:
+                out = x.reshape([int(d) if d != 0 else x.shape[i] for i, d in enumerate(inits[n["inputs"][1]].tolist())])
+            elif n["op"] in ("Squeeze", "Unsqueeze"):
+                axes = n["attrs"].get("axes")
+                if axes is None and len(n["inputs"]) > 1:
+                    axes = inits[n["inputs"][1]].tolist()
+                if n["op"] == "Squeeze":
+                    out = np.squeeze(x, axis=tuple(axes) if axes else None)
+                elif axes:
+                    out = x
+                    for ax in sorted(axes):
+                        out = np.expand_dims(out, ax)
+        if out is not None and n["outputs"]:
+            inits[n["outputs"][0]] = np.ascontiguousarray(out)
+        else:
+            keep.append(n)
+    g["nodes"] = keep
+
+
+class _Flow:
+    """Dataflow view of a graph: who consumes a tensor, who produced it.  The loaders walk the DATAFLOW (never node order or node
+    names), interpret every operator they pass and refuse -- naming the operator and where it sits -- what they cannot interpret."""
+
+    def __init__(self, g: dict, path: str):
+        self.g, self.path, self.inits = g, path, g["initializers"]
+        self.consumers: Dict[str, List[dict]] = {}
+        self.producer: Dict[str, dict] = {}
+        for n in g["nodes"]:
+            for i in n["inputs"]:
+                if i and i not in self.inits:
+                    self.consumers.setdefault(i, []).append(n)
+            for o in n["outputs"]:
+                self.producer[o] = n
+
+    def refuse(self, why: str):
+        from collections import Counter
+        raise ValueError(f"{self.path}: {why}; operators in the file: {dict(Counter(n['op'] for n in self.g['nodes']))}")
+
+    def const(self, n: dict, skip: str = None):
+        """The constant operand of a binary node (the input that is an initializer), or None."""
+        c = [self.inits[i] for i in n["inputs"] if i in self.inits and i != skip]
+        return c[0] if len(c) == 1 else None
+
+    def data_input(self, n: dict) -> str:
+        d = [i for i in n["inputs"] if i and i not in self.inits]
+        return d[0] if d else ""
+
+    def start(self) -> str:
+        ins = [i for i in self.g["inputs"] if i in self.consumers]
+        if not ins:                                              # files without ValueInfo: the tensor nobody produces
+            ins = [t for t in self.consumers if t not in self.producer]
+        if len(ins) != 1:
+            self.refuse(f"expected one data input, found {ins}")
+        return ins[0]
+
+
+def _scalar(c) -> float:
+    return float(np.asarray(c).reshape(-1)[0]) if c is not None and np.asarray(c).size == 1 else float("nan")
 
 
 # ------------------------------------------------------------------------------------------- wake-word heads
-def _linear_layers(g: dict):
-    """(weight [in, out], bias [out]) of every Gemm / MatMul(+Add) in graph order."""
-    inits, out = g["initializers"], []
-    nodes = g["nodes"]
-    for i, n in enumerate(nodes):
-        if n["op"] == "Gemm":
-            w = inits.get(n["inputs"][1])
-            if w is None or w.ndim != 2:
-                continue
-            w = w.T if n["attrs"].get("transB", 0) else w
-            b = inits.get(n["inputs"][2]) if len(n["inputs"]) > 2 else None
-            out.append((np.ascontiguousarray(w, np.float32), (np.zeros(w.shape[1], np.float32) if b is None else b.astype(np.float32)), i))
-        elif n["op"] == "MatMul":
-            w = inits.get(n["inputs"][1])
-            if w is None or w.ndim != 2:
-                continue
-            b = None
-            for m in nodes[i + 1:i + 3]:
-                if m["op"] == "Add" and n["outputs"][0] in m["inputs"]:
-                    other = [x for x in m["inputs"] if x != n["outputs"][0]]
-                    b = inits.get(other[0]) if other else None
-            out.append((np.ascontiguousarray(w, np.float32), (np.zeros(w.shape[1], np.float32) if b is None else b.astype(np.float32)), i))
-    return out
+LN_EPS = 1e-5        # torch.nn.LayerNorm's default (train.py:63-64): the constant the head kernels apply
 
 
-def _layernorms(g: dict, hidden: int):
-    """(gamma, beta) pairs in graph order: LayerNormalization nodes, or Mul / Add by [hidden] initializers after a Sqrt/Div."""
-    inits, out = g["initializers"], []
-    for n in g["nodes"]:
-        if n["op"] == "LayerNormalization":
-            gm = inits.get(n["inputs"][1])
-            bt = inits.get(n["inputs"][2]) if len(n["inputs"]) > 2 else None
-            if gm is not None:
-                out.append((gm.astype(np.float32), np.zeros_like(gm, np.float32) if bt is None else bt.astype(np.float32)))
-    if out:
-        return out
-    # decomposed form: ... -> Mul(x, gamma[hidden]) -> Add(., beta[hidden])
-    nodes = g["nodes"]
-    for i, n in enumerate(nodes):
-        if n["op"] != "Mul":
-            continue
-        gm = [inits[x] for x in n["inputs"] if x in inits and inits[x].shape == (hidden,)]
-        if not gm:
-            continue
-        bt = None
-        for m in nodes[i + 1:i + 3]:
-            if m["op"] == "Add" and n["outputs"][0] in m["inputs"]:
-                cand = [inits[x] for x in m["inputs"] if x in inits and inits[x].shape == (hidden,)]
-                bt = cand[0] if cand else None
-        out.append((gm[0].astype(np.float32), np.zeros(hidden, np.float32) if bt is None else bt.astype(np.float32)))
-    return out
+def _walk_layernorm(fl: _Flow, cur: str, hidden: int, where: str):
+    """LayerNormalization over the last axis starting at tensor `cur`: the opset-17 operator, or its decomposition
+    (ReduceMean, Sub, Pow | Mul, ReduceMean, Add eps, Sqrt, Div, Mul gamma, Add beta).  Returns ((gamma, beta), output tensor),
+    or (None, cur) when `cur` is not normalised."""
+    cons = fl.consumers.get(cur, [])
+    if len(cons) == 1 and cons[0]["op"] == "LayerNormalization":
+        n = cons[0]
+        eps = float(n["attrs"].get("epsilon", 1e-5))
+        if abs(eps - LN_EPS) > 1e-9:
+            fl.refuse(f"{where}: LayerNormalization epsilon {eps:g}, the head kernels apply {LN_EPS:g}")
+        if int(n["attrs"].get("axis", -1)) not in (-1, 1):
+            fl.refuse(f"{where}: LayerNormalization over axis {n['attrs'].get('axis')}")
+        gm = fl.inits.get(n["inputs"][1]) if len(n["inputs"]) > 1 else None
+        bt = fl.inits.get(n["inputs"][2]) if len(n["inputs"]) > 2 else None
+        if gm is None or gm.shape != (hidden,):
+            fl.refuse(f"{where}: LayerNormalization without a constant scale of {hidden} values")
+        return (gm.astype(np.float32), np.zeros(hidden, np.float32) if bt is None else bt.astype(np.float32)), n["outputs"][0]
+    if not any(c["op"] == "ReduceMean" for c in cons):
+        return None, cur
+    # decomposed form: collect the sub-graph between `cur` and the tensor the activation consumes
+    seen, frontier, ops, gamma, beta, eps, out = set(), [cur], [], None, None, None, None
+    while frontier:
+        t = frontier.pop()
+        for n in fl.consumers.get(t, []):
+            if id(n) in seen:
+                continue
+            if n["op"] in ("Relu", "Gemm", "MatMul", "Sigmoid", "Softmax"):
+                out = t
+                continue
+            seen.add(id(n))
+            ops.append(n["op"])
+            c = fl.const(n)
+            if n["op"] == "Mul" and c is not None and c.shape == (hidden,):
+                gamma = c
+            elif n["op"] == "Add" and c is not None and c.shape == (hidden,):
+                beta = c
+            elif n["op"] == "Add" and c is not None and c.size == 1:
+                eps = _scalar(c)
+            elif n["op"] == "ReduceMean":
+                axes = n["attrs"].get("axes") or ([] if len(n["inputs"]) < 2 else fl.inits[n["inputs"][1]].tolist())
+                if [int(a) for a in axes] not in ([-1], [1]):
+                    fl.refuse(f"{where}: ReduceMean over axes {axes} inside a LayerNorm")
+            elif n["op"] == "Pow" and abs(_scalar(c) - 2.0) > 0:
+                fl.refuse(f"{where}: Pow exponent {_scalar(c)} inside a LayerNorm")
+            frontier += n["outputs"]
+    want = {"ReduceMean": 2, "Sub": 1, "Sqrt": 1, "Div": 1}
+    from collections import Counter
+    cnt = Counter(ops)
+    ok = all(cnt[k] == v for k, v in want.items()) and cnt["Pow"] + cnt["Mul"] in (1, 2) and cnt["Add"] in (1, 2) and \
+        set(cnt) <= {"ReduceMean", "Sub", "Sqrt", "Div", "Pow", "Mul", "Add"}
+    if not ok or eps is None or out is None:
+        fl.refuse(f"{where}: operators {dict(cnt)} after a linear layer are not a LayerNorm over the last axis")
+    if abs(eps - LN_EPS) > 1e-9:
+        fl.refuse(f"{where}: LayerNorm epsilon {eps:g}, the head kernels apply {LN_EPS:g}")
+    gm = np.ones(hidden, np.float32) if gamma is None else gamma.astype(np.float32)
+    bt = np.zeros(hidden, np.float32) if beta is None else beta.astype(np.float32)
+    return (gm, bt), out
+
+
+def _walk_linear(fl: _Flow, n: dict, where: str):
+    """(weight [in, out], bias [out], output tensor) of a Gemm, or of a MatMul and the Add that follows it."""
+    if n["op"] == "Gemm":
+        w = fl.inits.get(n["inputs"][1])
+        if w is None or w.ndim != 2:
+            fl.refuse(f"{where}: Gemm without a constant 2-D weight")
+        at = n["attrs"]
+        if float(at.get("alpha", 1.0)) != 1.0 or float(at.get("beta", 1.0)) != 1.0 or int(at.get("transA", 0)) != 0:
+            fl.refuse(f"{where}: Gemm with alpha / beta / transA = {at.get('alpha', 1.0)} / {at.get('beta', 1.0)} / {at.get('transA', 0)}")
+        w = w.T if int(at.get("transB", 0)) else w
+        b = fl.inits.get(n["inputs"][2]) if len(n["inputs"]) > 2 and n["inputs"][2] else None
+        if len(n["inputs"]) > 2 and n["inputs"][2] and b is None:
+            fl.refuse(f"{where}: Gemm bias is not a constant")
+        out = n["outputs"][0]
+    else:
+        w = fl.inits.get(n["inputs"][1])
+        if w is None or w.ndim != 2:
+            fl.refuse(f"{where}: MatMul without a constant 2-D right operand")
+        b, out = None, n["outputs"][0]
+        cons = fl.consumers.get(out, [])
+        if len(cons) == 1 and cons[0]["op"] == "Add" and fl.const(cons[0]) is not None and fl.const(cons[0]).shape == (w.shape[1],):
+            b, out = fl.const(cons[0]), cons[0]["outputs"][0]
+    bias = np.zeros(w.shape[1], np.float32) if b is None else np.asarray(b, np.float32).reshape(-1)
+    if bias.shape != (w.shape[1],):
+        fl.refuse(f"{where}: bias of {bias.shape[0]} values on a layer with {w.shape[1]} outputs")
+    return np.ascontiguousarray(w, np.float32), bias, out
+
+
+def _walk_net(fl: _Flow, first: dict, where: str):
+    """One MLP of train.py:56-83 from its first linear node: Linear -> [LN] -> Relu -> Linear -> [LN] -> Relu -> Linear, then the
+    output activation(s).  Returns (net dict, tail operator names, last tensor)."""
+    net, node = {}, first
+    for li in (1, 2, 3):
+        w, b, cur = _walk_linear(fl, node, f"{where} layer {li}")
+        net[f"w{li}"], net[f"b{li}"] = w, b
+        if li == 3:
+            break
+        ln, cur = _walk_layernorm(fl, cur, w.shape[1], f"{where} layer {li}")
+        net[f"ln{li}"] = ln
+        cons = fl.consumers.get(cur, [])
+        if len(cons) != 1 or cons[0]["op"] != "Relu":
+            fl.refuse(f"{where}: expected exactly one Relu after linear layer {li}, found {[c['op'] for c in cons]}")
+        cons = fl.consumers.get(cons[0]["outputs"][0], [])
+        if len(cons) != 1 or cons[0]["op"] not in ("Gemm", "MatMul"):
+            fl.refuse(f"{where}: expected a linear layer after the Relu of layer {li}, found {[c['op'] for c in cons]}")
+        node = cons[0]
+    if (net["ln1"] is None) != (net["ln2"] is None):
+        fl.refuse(f"{where}: LayerNorm after one hidden layer but not the other")
+    tail = []
+    while True:
+        cons = fl.consumers.get(cur, [])
+        if len(cons) == 1 and cons[0]["op"] in ("Relu", "Sigmoid", "Softmax", "Tanh", "LeakyRelu", "Elu", "Selu", "Gelu", "HardSigmoid", "PRelu", "Clip"):
+            if cons[0]["op"] == "Softmax" and int(cons[0]["attrs"].get("axis", -1)) not in (-1, 1):
+                fl.refuse(f"{where}: Softmax over axis {cons[0]['attrs'].get('axis')}")
+            tail.append(cons[0]["op"])
+            cur = cons[0]["outputs"][0]
+        else:
+            return net, tail, cur
+
+
+GATE_THRESHOLD = 0.5   # docs/models/hey_jarvis.md:38: the verifier network replaces the score where the first network is > 0.5
+
+
+def _shape_only(fl: _Flow, t: str) -> str:
+    """Follow Squeeze / Unsqueeze / Reshape / Identity / Flatten / Cast-free plumbing from tensor t to the tensor that is next USED."""
+    while True:
+        cons = fl.consumers.get(t, [])
+        if len(cons) == 1 and cons[0]["op"] in ("Squeeze", "Unsqueeze", "Reshape", "Identity", "Flatten"):
+            t = cons[0]["outputs"][0]
+        else:
+            return t
 
 
 def load_head(path: str) -> dict:
+    """A wake-word model file -> {'kind', 'T', 'hidden', 'n_out', 'net'[, 'net2']} (the layout of weights.synthetic_head).
+
+    Walked by dataflow from the graph input: [Flatten | Reshape] -> network(s) -> output.  Two networks fed by the same features are
+    the gated form of hey_jarvis; its routing must be the one the kernels implement -- `where(first > 0.5, second, first)`, written
+    as Greater + Where or as Greater + If (second network inside the then-branch, the first score passed through by the
+    else-branch) -- with that threshold and that branch order, or the file is refused."""
     g = load_graph(path)
-    lin = _linear_layers(g)
-    if len(lin) not in (3, 6):
-        raise ValueError(f"{path}: expected 3 (or 6 for a gated model) linear layers, found {len(lin)}")
-    n_nets = len(lin) // 3
-    w1 = lin[0][0]
-    if w1.shape[0] % W.EMB_DIM:
-        raise ValueError(f"{path}: first layer input {w1.shape[0]} is not a multiple of {W.EMB_DIM}")
-    T, hidden, n_out = w1.shape[0] // W.EMB_DIM, w1.shape[1], lin[2][0].shape[1]
-    lns = _layernorms(g, hidden)
-    if len(lns) not in (0, 2 * n_nets):
-        raise ValueError(f"{path}: found {len(lns)} LayerNorm parameter pairs for {n_nets} network(s)")
-    nets = []
-    for k in range(n_nets):
-        (a, ab, _), (b, bb, _), (c, cb, _) = lin[3 * k:3 * k + 3]
-        if a.shape != (T * W.EMB_DIM, hidden) or b.shape != (hidden, hidden) or c.shape != (hidden, n_out):
-            raise ValueError(f"{path}: network {k} has layer shapes {a.shape}, {b.shape}, {c.shape}")
-        nets.append({"w1": a, "b1": ab, "ln1": lns[2 * k] if lns else None, "w2": b, "b2": bb,
-                     "ln2": lns[2 * k + 1] if lns else None, "w3": c, "b3": cb})
-    # the activations the kernels will apply are fixed (Linear -> [LN] -> ReLU twice, then Sigmoid, or ReLU + Softmax for a
-    # multiclass model): check that the file really has them instead of inferring the kind from one op name
-    acts = {"Relu", "Sigmoid", "Softmax", "Tanh", "LeakyRelu", "Elu", "Selu", "Gelu", "HardSigmoid", "PRelu", "Clip"}
-    tails = []
-    for k in range(n_nets):
-        idx = [lin[3 * k + i][2] for i in range(3)]
-        stop = lin[3 * k + 3][2] if k + 1 < n_nets else len(g["nodes"])
-        for a, b in ((idx[0], idx[1]), (idx[1], idx[2])):
-            between = [n["op"] for n in g["nodes"][a + 1:b] if n["op"] in acts]
-            if between != ["Relu"]:
-                raise ValueError(f"{path}: expected exactly one Relu between the linear layers of network {k}, found {between}")
-        tails.append([n["op"] for n in g["nodes"][idx[2] + 1:stop] if n["op"] in acts])
-    if any(t != tails[0] for t in tails):
-        raise ValueError(f"{path}: the networks of a gated model end differently: {tails}")
-    if tails[0] == ["Sigmoid"]:
-        kind = "gated" if n_nets == 2 else "binary"
-    elif tails[0] == ["Relu", "Softmax"] and n_nets == 1:
+    fl = _Flow(g, path)
+    x = fl.start()
+    feats = _shape_only(fl, x)
+    cons = fl.consumers.get(feats, [])
+    lin = [c for c in cons if c["op"] in ("Gemm", "MatMul")]
+    ifs = [n for n in g["nodes"] if n["op"] == "If"]
+    if not lin:
+        fl.refuse(f"no linear layer consumes the (flattened) input; found {[c['op'] for c in cons]}")
+    if len(lin) > 2 or len(lin) + len(ifs) > 2:
+        fl.refuse(f"{len(lin)} networks and {len(ifs)} If nodes read the input; one network, or two with a 0.5 gate, are supported")
+    net, tail, s1 = _walk_net(fl, lin[0], "network 0")
+    T, rem = divmod(net["w1"].shape[0], W.EMB_DIM)
+    if rem:
+        fl.refuse(f"first layer input {net['w1'].shape[0]} is not a multiple of {W.EMB_DIM}")
+    hidden, n_out = net["w1"].shape[1], net["w3"].shape[1]
+    if net["w2"].shape != (hidden, hidden) or net["w3"].shape[0] != hidden:
+        fl.refuse(f"layer shapes {net['w1'].shape}, {net['w2'].shape}, {net['w3'].shape}")
+    net2 = None
+    if len(lin) == 2 or ifs:
+        if ifs:
+            net2, s1, s_out = _gate_if(fl, ifs[0], feats, s1)
+        else:
+            net2, tail2, s2 = _walk_net(fl, lin[1], "network 1")
+            if tail2 != tail:
+                fl.refuse(f"the two networks of a gated model end differently: {tail} / {tail2}")
+            s_out = _gate_where(fl, s1, s2)
+        for k in ("w1", "w2", "w3"):
+            if net2[k].shape != net[k].shape:
+                fl.refuse(f"the two networks of a gated model differ in shape: {net[k].shape} / {net2[k].shape}")
+        if (net2["ln1"] is None) != (net["ln1"] is None):
+            fl.refuse("LayerNorm in one network of a gated model but not the other")
+    # the activations the kernels apply are fixed (Linear -> [LN] -> ReLU twice, then Sigmoid, or ReLU + Softmax for a multiclass
+    # model): the file must have exactly them
+    if tail == ["Sigmoid"]:
+        kind = "gated" if net2 is not None else "binary"
+    elif tail == ["Relu", "Softmax"] and net2 is None:
         kind = "multiclass"
     else:
         # e.g. train.py's multiclass branch ends in a bare ReLU (train.py:81-83): no kernel applies that, so refuse
-        raise ValueError(f"{path}: unsupported output activation {tails[0]} (supported: Sigmoid, or Relu -> Softmax)")
-    head = {"kind": kind, "T": int(T), "hidden": int(hidden), "n_out": int(n_out), "net": nets[0]}
-    if n_nets == 2:
-        head["net2"] = nets[1]
+        fl.refuse(f"unsupported output activation {tail} (supported: Sigmoid, or Relu -> Softmax)")
+    head = {"kind": kind, "T": int(T), "hidden": int(hidden), "n_out": int(n_out), "net": net}
+    if net2 is not None:
+        head["net2"] = net2
     return head
 
 
+def _gate_condition(fl: _Flow, s1: str, where: str) -> dict:
+    """The comparison node that tests the first network's score against the gate threshold."""
+    t = _shape_only(fl, s1)
+    cmps = [c for c in fl.consumers.get(t, []) + fl.consumers.get(s1, []) if c["op"] in ("Greater", "Less", "GreaterOrEqual", "LessOrEqual")]
+    if not cmps:
+        fl.refuse(f"{where}: two networks but no comparison of the first score with a threshold")
+    n = cmps[0]
+    thr = _scalar(fl.const(n))
+    if n["op"] != "Greater" or n["inputs"][1] not in fl.inits:
+        fl.refuse(f"{where}: the gate compares with {n['op']} (operands {n['inputs']}); the kernels implement `first > {GATE_THRESHOLD}`")
+    if abs(thr - GATE_THRESHOLD) > 1e-7:
+        fl.refuse(f"{where}: gate threshold {thr:g}; the kernels implement {GATE_THRESHOLD}")
+    return n
+
+
+def _gate_where(fl: _Flow, s1: str, s2: str) -> str:
+    cmp_node = _gate_condition(fl, s1, "gate")
+    cond = _shape_only(fl, cmp_node["outputs"][0])
+    wh = [c for c in fl.consumers.get(cond, []) if c["op"] == "Where"]
+    if len(wh) != 1:
+        fl.refuse(f"gate: the comparison feeds {[c['op'] for c in fl.consumers.get(cond, [])]}, expected one Where")
+    a, b = wh[0]["inputs"][1], wh[0]["inputs"][2]
+    reach = lambda src, dst: dst == src or dst == _shape_only(fl, src)
+    if not (reach(s2, a) and reach(s1, b)):
+        fl.refuse("gate: Where(first > 0.5, X, Y) must select the SECOND network's score where the condition holds and the first "
+                  "network's score elsewhere")
+    return wh[0]["outputs"][0]
+
+
+def _gate_if(fl: _Flow, node: dict, feats: str, s1: str):
+    cmp_node = _gate_condition(fl, s1, "gate (If)")
+    cond = cmp_node["outputs"][0]
+    t = cond
+    while t != node["inputs"][0]:                                   # Squeeze / ReduceMax / Reshape between the comparison and the If
+        cons = fl.consumers.get(t, [])
+        if len(cons) != 1 or cons[0]["op"] not in ("Squeeze", "Reshape", "ReduceMax", "ReduceMin", "Identity", "Cast"):
+            fl.refuse(f"gate (If): the condition passes through {[c['op'] for c in cons]}")
+        t = cons[0]["outputs"][0]
+    then_g, else_g = node["attrs"].get("then_branch"), node["attrs"].get("else_branch")
+    if not isinstance(then_g, dict) or not isinstance(else_g, dict):
+        fl.refuse("gate (If): branches are not readable graphs")
+    # else: the first network's score, passed through
+    ef = _Flow(else_g, fl.path)
+    src = else_g["outputs"][0] if else_g["outputs"] else ""
+    while src in ef.producer and ef.producer[src]["op"] in ("Identity", "Squeeze", "Unsqueeze", "Reshape"):
+        src = ef.data_input(ef.producer[src])
+    if src != s1 and src != _shape_only(fl, s1) and fl.producer.get(src, {}).get("op") not in ("Squeeze", "Unsqueeze", "Reshape", "Identity"):
+        fl.refuse(f"gate (If): the else-branch returns '{src}', not the first network's score")
+    # then: the second network applied to the same features (captured from the outer scope)
+    tf = _Flow(then_g, fl.path)
+    lin = [c for c in tf.consumers.get(feats, []) if c["op"] in ("Gemm", "MatMul")]
+    if len(lin) != 1:
+        fl.refuse(f"gate (If): the then-branch does not apply one network to the features ({[c['op'] for c in tf.consumers.get(feats, [])]})")
+    net2, tail2, _ = _walk_net(tf, lin[0], "network 1 (then-branch)")
+    if tail2 != ["Sigmoid"]:
+        fl.refuse(f"gate (If): the then-branch ends in {tail2}")
+    return net2, s1, node["outputs"][0]
+
+
 # ------------------------------------------------------------------------------------------- embedding CNN
+LEAKY_ALPHA = 0.2      # a(x) = max(max(0.2 x, x), -0.4)  (converting_google_speech_embedding_model.ipynb:871-879)
+ACT_FLOOR = -0.4
+
+
+def _conv_pads(fl: _Flow, n: dict, kh: int, kw: int, where: str):
+    at = n["attrs"]
+    if any(int(v) != 1 for v in (at.get("strides") or [1, 1])) or any(int(v) != 1 for v in (at.get("dilations") or [1, 1])) or int(at.get("group", 1)) != 1:
+        fl.refuse(f"{where}: strides / dilations / group = {at.get('strides')} / {at.get('dilations')} / {at.get('group', 1)}")
+    ap = at.get("auto_pad", "NOTSET") or "NOTSET"
+    if ap == "NOTSET":
+        p = [int(v) for v in (at.get("pads") or [0, 0, 0, 0])]
+    elif ap == "VALID":
+        p = [0, 0, 0, 0]
+    elif ap in ("SAME_UPPER", "SAME_LOWER"):
+        p = [(kh - 1) // 2, (kw - 1) // 2, (kh - 1) // 2, (kw - 1) // 2]      # stride 1, odd kernels: symmetric
+    else:
+        fl.refuse(f"{where}: auto_pad {ap}")
+    return p
+
+
 def load_embedding(path: str) -> dict:
+    """`embedding_model.onnx` -> {'conv': [HWIO] x 20, 'bn': [(gamma, beta, mean, var)] x 19} (weights.synthetic_embedding layout).
+
+    The graph is walked by dataflow from its input and EVERY operator on the way is interpreted and checked against what the kernels
+    compute (notebook cell 18: SURVEY 8a-E) -- the weights alone do not make the network:
+      * layout: Transpose NHWC -> NCHW at the input (and back / Squeeze / Reshape at the output);
+      * padding: zero padding of the MEL axis only, +-1 in front of the 3x3 and every 1x3 convolution, none on the time axis --
+        as a Pad node, as Conv `pads`, or as auto_pad on a 1x3 kernel;
+      * conv0 -> Relu -> BatchNorm; every other convolution but the last -> BatchNorm, where a BatchNorm is a BatchNormalization
+        node, a per-channel Mul / Add pair, or already folded into the convolution (scaled weights + bias);
+      * the activation after every BatchNorm: LeakyRelu(0.2) or Max(Mul(x, 0.2), x), then Clip(min=-0.4) or Max(., -0.4);
+      * MaxPool 2x2 / 1x2 exactly where weights.CNN_TOPOLOGY has them (kernel = stride, no padding).
+    Anything else is refused, naming the operator and the layer."""
     g = load_graph(path)
-    inits = g["initializers"]
-    convs, bns = [], {}
-    for i, n in enumerate(g["nodes"]):
-        if n["op"] == "Conv":
-            w = inits.get(n["inputs"][1])
+    fl = _Flow(g, path)
+    cur = fl.start()
+    topo = W.CNN_TOPOLOGY
+    nchw = False                    # layout of `cur`: tf2onnx graphs start NHWC and transpose once; torch exports start NCHW
+    pend = [0, 0, 0, 0]             # zero padding waiting for the next convolution: (time before, mel before, time after, mel after)
+    conv, bn = [], []
+    li = -1                         # layer whose convolution has been read
+    st = dict(relu=False, bn=False, leaky=False, floor=False, pool=False)
+    layout_known = False
+
+    def layer_done(where):
+        if li < 0:
+            return
+        kh, kw, ci, co, pool = topo[li]
+        if li == len(topo) - 1:
+            if any(st.values()):
+                fl.refuse(f"{where}: operators after the last convolution ({[k for k, v in st.items() if v]})")
+            return
+        need = dict(relu=li == 0, bn=True, leaky=True, floor=True, pool=pool is not None)
+        for k in ("relu", "bn", "leaky", "floor", "pool"):
+            if st[k] != need[k]:
+                fl.refuse(f"{where}: layer {li} {'lacks' if need[k] else 'has an unexpected'} {k} stage (found {[q for q, v in st.items() if v]})")
+
+    while True:
+        cons = fl.consumers.get(cur, [])
+        where = f"after conv {li}" if li >= 0 else "at the input"
+        if not cons:
+            break
+        # Max(Mul(x, 0.2), x): x has two consumers
+        if len(cons) == 2 and {c["op"] for c in cons} == {"Mul", "Max"}:
+            mul = next(c for c in cons if c["op"] == "Mul")
+            mx = next(c for c in cons if c["op"] == "Max")
+            if abs(_scalar(fl.const(mul)) - LEAKY_ALPHA) > 1e-6 or set(mx["inputs"]) != {cur, mul["outputs"][0]}:
+                fl.refuse(f"{where}: Mul / Max pair is not max({LEAKY_ALPHA} x, x) (factor {_scalar(fl.const(mul))})")
+            if st["leaky"] or st["floor"] or st["pool"] or not st["bn"]:
+                fl.refuse(f"{where}: leaky stage out of order")
+            st["leaky"] = True
+            cur = mx["outputs"][0]
+            continue
+        if len(cons) != 1:
+            fl.refuse(f"{where}: tensor '{cur}' feeds {[c['op'] for c in cons]}; the embedding network is a chain")
+        n = cons[0]
+        op = n["op"]
+        if op == "Transpose":
+            perm = [int(v) for v in (n["attrs"].get("perm") or [])]
+            if perm == [0, 3, 1, 2] and not nchw:
+                nchw = True
+            elif perm == [0, 2, 3, 1] and nchw and li == len(topo) - 1:
+                nchw = False
+            else:
+                fl.refuse(f"{where}: Transpose perm {perm}")
+            layout_known = True
+        elif op == "Pad":
+            pads = n["attrs"].get("pads")
+            if pads is None and len(n["inputs"]) > 1 and n["inputs"][1] in fl.inits:
+                pads = fl.inits[n["inputs"][1]].tolist()
+            val = n["attrs"].get("value", 0.0)
+            if len(n["inputs"]) > 2 and n["inputs"][2] in fl.inits:
+                val = _scalar(fl.inits[n["inputs"][2]])
+            if pads is None or len(pads) != 8 or (n["attrs"].get("mode", "constant") or "constant") != "constant" or float(val or 0.0) != 0.0:
+                fl.refuse(f"{where}: Pad with pads {pads}, mode {n['attrs'].get('mode')}, value {val}")
+            pads = [int(v) for v in pads]
+            hi, wi = (2, 3) if nchw else (1, 2)
+            if any(pads[k] for k in range(8) if k % 4 not in (hi, wi)):
+                fl.refuse(f"{where}: Pad touches the batch / channel axis: {pads}")
+            pend = [pend[0] + pads[hi], pend[1] + pads[wi], pend[2] + pads[4 + hi], pend[3] + pads[4 + wi]]
+        elif op == "Conv":
+            layer_done(where)
+            li += 1
+            st = dict(relu=False, bn=False, leaky=False, floor=False, pool=False)
+            if li >= len(topo):
+                fl.refuse(f"more than {len(topo)} convolutions")
+            if not nchw and layout_known is False and li == 0:
+                nchw = True                                      # no Transpose seen: the file is NCHW from the start (torch export)
+            kh, kw, ci, co, _pool = topo[li]
+            w = fl.inits.get(n["inputs"][1])
             if w is None or w.ndim != 4:
-                raise ValueError(f"{path}: Conv node {n['name']} has no 4-D weight initializer")
-            bias = inits.get(n["inputs"][2]) if len(n["inputs"]) > 2 else None
-            convs.append((np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)), np.float32), bias))        # OIHW -> HWIO
-        elif n["op"] == "BatchNormalization":
-            p = [inits.get(x) for x in n["inputs"][1:5]]
-            if any(x is None for x in p):
-                raise ValueError(f"{path}: BatchNormalization node {n['name']} without constant parameters")
+                fl.refuse(f"conv {li}: no constant 4-D weight")
+            if w.shape != (co, ci, kh, kw):
+                fl.refuse(f"conv {li}: OIHW weight {tuple(w.shape)}, expected {(co, ci, kh, kw)}")
+            p = _conv_pads(fl, n, kh, kw, f"conv {li}")
+            tot = [p[k] + pend[k] for k in range(4)]
+            want = [0, 1, 0, 1] if kw == 3 else [0, 0, 0, 0]
+            if tot != want:
+                fl.refuse(f"conv {li} ({kh}x{kw}): zero padding (time, mel, time, mel) = {tot}; the kernels pad the mel axis only: {want}")
+            pend = [0, 0, 0, 0]
+            bias = fl.inits.get(n["inputs"][2]) if len(n["inputs"]) > 2 and n["inputs"][2] else None
+            conv.append(np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)), np.float32))            # OIHW -> HWIO
+            if bias is not None and np.abs(bias).max() > 0:
+                if li == 0:
+                    fl.refuse("conv 0 carries a bias in front of its Relu; the kernel has no slot for it")
+                if li == len(topo) - 1:
+                    fl.refuse("the last convolution carries a bias; the kernel has no slot for it")
+                one = np.ones(co, np.float32)                      # a BatchNorm folded into the convolution: y = conv + bias
+                bn.append((one, np.asarray(bias, np.float32).reshape(co), np.zeros(co, np.float32), one - np.float32(W.BN_EPS)))
+                st["bn"] = True
+        elif op == "Relu":
+            if li != 0 or st["relu"] or st["bn"]:
+                fl.refuse(f"{where}: Relu (only conv 0 is followed by one, in front of its BatchNorm)")
+            st["relu"] = True
+        elif op == "BatchNormalization":
+            if li < 0 or li == len(topo) - 1 or st["leaky"] or st["floor"] or st["pool"] or (li == 0 and not st["relu"]):
+                fl.refuse(f"{where}: BatchNormalization out of order")
+            p = [fl.inits.get(x) for x in n["inputs"][1:5]]
+            co = topo[li][3]
+            if len(p) != 4 or any(x is None or x.shape != (co,) for x in p):
+                fl.refuse(f"{where}: BatchNormalization without four constant [{co}] parameters")
             eps = float(n["attrs"].get("epsilon", 1e-5))
             gm, bt, mu, var = (x.astype(np.float64) for x in p)
-            # re-express with this package's epsilon so that weights.bn_scale_shift reproduces the file's arithmetic
-            if abs(eps - W.BN_EPS) > 1e-12:
+            if abs(eps - W.BN_EPS) > 1e-12:                       # re-expressed with this package's epsilon
                 var = var + (eps - W.BN_EPS)
-            bns[len(convs) - 1] = (gm.astype(np.float32), bt.astype(np.float32), mu.astype(np.float32), var.astype(np.float32))
-    if len(convs) != len(W.CNN_TOPOLOGY):
-        raise ValueError(f"{path}: expected {len(W.CNN_TOPOLOGY)} Conv nodes, found {len(convs)}")
-    conv, bn = [], []
-    for li, ((w, bias), (kh, kw, ci, co, _)) in enumerate(zip(convs, W.CNN_TOPOLOGY)):
-        if w.shape != (kh, kw, ci, co):
-            raise ValueError(f"{path}: Conv {li} has HWIO shape {w.shape}, expected {(kh, kw, ci, co)}")
-        conv.append(w)
-        if li == len(convs) - 1:
-            if bias is not None and np.abs(bias).max() > 0:
-                raise ValueError(f"{path}: the last convolution carries a bias; the kernel has no slot for it")
-            continue
-        if li in bns:
-            if bias is not None and np.abs(bias).max() > 0:
-                gm, bt, mu, var = bns[li]
-                bns[li] = (gm, bt, mu - bias.astype(np.float32), var)          # BN(conv + b) == BN'(conv)
-            bn.append(bns[li])
-        elif bias is not None:
-            one = np.ones(co, np.float32)                                       # folded BatchNorm: y = conv + bias
-            bn.append((one, bias.astype(np.float32), np.zeros(co, np.float32), one - np.float32(W.BN_EPS)))
+            new = (gm, bt, mu, var)
+            if st["bn"]:                                           # a bias on the convolution AND a BatchNorm: BN(conv + b) = BN'(conv)
+                _one, b0, _z, _v = bn.pop()
+                new = (gm, bt, mu - b0.astype(np.float64), var)
+            bn.append(tuple(a.astype(np.float32) for a in new))
+            st["bn"] = True
+        elif op in ("Mul", "Add") and fl.const(n) is not None and fl.const(n).size == topo[max(li, 0)][3] and li >= 0 and not st["leaky"]:
+            # BatchNorm written as a per-channel affine map (Mul scale, Add shift)
+            co = topo[li][3]
+            c = np.asarray(fl.const(n), np.float64).reshape(-1)
+            shp = list(np.asarray(fl.const(n)).shape)
+            ch_axis = 1 if nchw else 3
+            if len(shp) > 1 and (len(shp) != 4 or shp[ch_axis] != co):
+                fl.refuse(f"{where}: per-channel {op} constant of shape {shp} in {'NCHW' if nchw else 'NHWC'} layout")
+            if li == len(topo) - 1 or (li == 0 and not st["relu"]):
+                fl.refuse(f"{where}: per-channel {op} out of order")
+            if not st["bn"]:
+                one = np.ones(co)
+                bn.append((one.astype(np.float32), np.zeros(co, np.float32), np.zeros(co, np.float32), (one - W.BN_EPS).astype(np.float32)))
+                st["bn"] = True
+            gm, bt, mu, var = (a.astype(np.float64) for a in bn.pop())
+            k = np.sqrt(var + W.BN_EPS)
+            scale, shift = gm / k, bt - mu * gm / k
+            scale, shift = (scale * c, shift * c) if op == "Mul" else (scale, shift + c)
+            bn.append((scale.astype(np.float32), shift.astype(np.float32), np.zeros(co, np.float32), (np.ones(co) - W.BN_EPS).astype(np.float32)))
+        elif op == "LeakyRelu":
+            if abs(float(n["attrs"].get("alpha", 0.01)) - LEAKY_ALPHA) > 1e-6:
+                fl.refuse(f"{where}: LeakyRelu alpha {n['attrs'].get('alpha', 0.01)}; the kernels apply {LEAKY_ALPHA}")
+            if st["leaky"] or st["floor"] or st["pool"] or not st["bn"]:
+                fl.refuse(f"{where}: LeakyRelu out of order")
+            st["leaky"] = True
+        elif op in ("Clip", "Max"):
+            if op == "Clip":
+                lo = n["attrs"].get("min")
+                hi_ = n["attrs"].get("max")
+                if lo is None and len(n["inputs"]) > 1 and n["inputs"][1] in fl.inits:
+                    lo = _scalar(fl.inits[n["inputs"][1]])
+                if hi_ is None and len(n["inputs"]) > 2 and n["inputs"][2] in fl.inits:
+                    hi_ = _scalar(fl.inits[n["inputs"][2]])
+                if hi_ is not None and float(hi_) < 3.0e38:
+                    fl.refuse(f"{where}: Clip with an upper bound {hi_}")
+            else:
+                lo = _scalar(fl.const(n))
+            if lo is None or abs(float(lo) - ACT_FLOOR) > 1e-6:
+                fl.refuse(f"{where}: {op} with lower bound {lo}; the kernels apply {ACT_FLOOR}")
+            if not st["leaky"] or st["floor"] or st["pool"]:
+                fl.refuse(f"{where}: the {ACT_FLOOR} floor must follow the leaky stage")
+            st["floor"] = True
+        elif op == "MaxPool":
+            pool = topo[li][4] if li >= 0 else None
+            ks = [int(v) for v in (n["attrs"].get("kernel_shape") or [])]
+            ss = [int(v) for v in (n["attrs"].get("strides") or ks)]
+            pp = [int(v) for v in (n["attrs"].get("pads") or [0, 0, 0, 0])]
+            if pool is None or ks != list(pool) or ss != list(pool) or any(pp) or int(n["attrs"].get("ceil_mode", 0)) or \
+                    (n["attrs"].get("auto_pad", "NOTSET") or "NOTSET") not in ("NOTSET", "VALID") or not nchw:
+                fl.refuse(f"{where}: MaxPool kernel {ks} strides {ss} pads {pp}; weights.CNN_TOPOLOGY has {pool} after layer {li}")
+            if not st["floor"] or st["pool"]:
+                fl.refuse(f"{where}: MaxPool before the activation")
+            st["pool"] = True
+        elif op in ("Squeeze", "Reshape", "Flatten", "Identity") and li == len(topo) - 1:
+            pass
         else:
-            raise ValueError(f"{path}: Conv {li} has neither a BatchNormalization nor a bias")
+            fl.refuse(f"{where}: operator {op} is not part of the speech-embedding network the kernels implement")
+        cur = n["outputs"][0]
+    layer_done("at the output")
+    if li != len(topo) - 1:
+        fl.refuse(f"expected {len(topo)} convolutions on the path from the input, found {li + 1}")
+    if any(pend):
+        fl.refuse(f"a Pad node {pend} is not followed by a convolution")
     return {"conv": conv, "bn": bn}
 
 

@@ -52,7 +52,7 @@ def _model(nodes, inits):
     return _vi((1 << 3) | 0) + _vi(8) + _ld(7, graph)
 
 
-def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True, tail=None, hidden_act="Relu"):
+def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True, tail=None, hidden_act="Relu", ln_eps=1e-5):
     nodes, inits, cur = [_node("Flatten", ["x"], ["f0"], [_attr_i("axis", 1)])], [], "f0"
     nets = [head["net"]] + ([head["net2"]] if head["kind"] == "gated" else [])
     for k, net in enumerate(nets):
@@ -71,9 +71,16 @@ def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True, tail=N
                 if ln is not None:
                     inits += [_tensor(f"n{k}g{li}", ln[0], raw), _tensor(f"n{k}be{li}", ln[1], raw)]
                     if layernorm_op:
-                        nodes.append(_node("LayerNormalization", [cur, f"n{k}g{li}", f"n{k}be{li}"], [f"n{k}n{li}"], [_attr_f("epsilon", 1e-5)]))
-                    else:
-                        nodes += [_node("Mul", [cur, f"n{k}g{li}"], [f"n{k}q{li}"]), _node("Add", [f"n{k}q{li}", f"n{k}be{li}"], [f"n{k}n{li}"])]
+                        nodes.append(_node("LayerNormalization", [cur, f"n{k}g{li}", f"n{k}be{li}"], [f"n{k}n{li}"], [_attr_f("epsilon", ln_eps)]))
+                    else:                                           # the decomposition older opsets export (torch < opset 17)
+                        t = f"n{k}L{li}"
+                        inits += [_tensor(t + "two", np.array(2.0, np.float32), raw), _tensor(t + "eps", np.array(ln_eps, np.float32), raw)]
+                        nodes += [_node("ReduceMean", [cur], [t + "m"], [_attr_ints("axes", [-1]), _attr_i("keepdims", 1)]),
+                                  _node("Sub", [cur, t + "m"], [t + "d"]), _node("Pow", [t + "d", t + "two"], [t + "p"]),
+                                  _node("ReduceMean", [t + "p"], [t + "v"], [_attr_ints("axes", [-1]), _attr_i("keepdims", 1)]),
+                                  _node("Add", [t + "v", t + "eps"], [t + "ve"]), _node("Sqrt", [t + "ve"], [t + "s"]),
+                                  _node("Div", [t + "d", t + "s"], [t + "q"]),
+                                  _node("Mul", [t + "q", f"n{k}g{li}"], [f"n{k}q{li}"]), _node("Add", [f"n{k}q{li}", f"n{k}be{li}"], [f"n{k}n{li}"])]
                     cur = f"n{k}n{li}"
                 nodes.append(_node(hidden_act, [cur], [f"n{k}r{li}"]))
                 cur = f"n{k}r{li}"
@@ -85,22 +92,37 @@ def write_head(path, head, layernorm_op=True, use_matmul=False, raw=True, tail=N
             nodes += [_node("Relu", [cur], [f"n{k}rr"]), _node("Softmax", [f"n{k}rr"], [f"n{k}out"])]
         else:
             nodes.append(_node("Sigmoid", [cur], [f"n{k}out"]))
+    if head["kind"] == "gated" and tail is None:               # docs/models/hey_jarvis.md:38: where(first > 0.5, second, first)
+        inits.append(_tensor("half", np.array([0.5], np.float32), raw))
+        nodes += [_node("Greater", ["n0out", "half"], ["gate"]), _node("Where", ["gate", "n1out", "n0out"], ["score"])]
     open(path, "wb").write(_model(nodes, inits))
 
 
+def _attr_ints(name, vals):
+    return _ld(1, name.encode()) + b"".join(_vi((8 << 3) | 0) + _vi(v) for v in vals) + _vi((20 << 3) | 0) + _vi(7)
+
+
+def _attr_s(name, v):
+    return _ld(1, name.encode()) + _ld(4, v.encode()) + _vi((20 << 3) | 0) + _vi(3)
+
+
 def write_embedding(path, emb, fold_last_bns=0):
+    """Plain idiom, NCHW from the input on (what torch.onnx.export of the notebook's network would give): Conv with `pads`,
+    BatchNormalization nodes (or folded into the last few convolutions), LeakyRelu + Clip(min) attribute form, MaxPool."""
     nodes, inits, cur = [], [], "x"
     n = len(emb["conv"])
     for li, w in enumerate(emb["conv"]):
+        kh, kw, _ci, _co, pool = W.CNN_TOPOLOGY[li]
         inits.append(_tensor(f"w{li}", np.transpose(w, (3, 2, 0, 1))))                       # HWIO -> OIHW
-        folded = li < n - 1 and li >= n - 1 - fold_last_bns
+        folded = li < n - 1 and li >= n - 1 - fold_last_bns and li > 0
+        pads = [_attr_ints("pads", [0, 1, 0, 1])] if kw == 3 else []
         if folded:
             scale, shift = W.bn_scale_shift(emb["bn"][li])
             inits[-1] = _tensor(f"w{li}", np.transpose(w * scale, (3, 2, 0, 1)))
             inits.append(_tensor(f"b{li}", shift))
-            nodes.append(_node("Conv", [cur, f"w{li}", f"b{li}"], [f"c{li}"]))
+            nodes.append(_node("Conv", [cur, f"w{li}", f"b{li}"], [f"c{li}"], pads))
         else:
-            nodes.append(_node("Conv", [cur, f"w{li}"], [f"c{li}"]))
+            nodes.append(_node("Conv", [cur, f"w{li}"], [f"c{li}"], pads))
         cur = f"c{li}"
         if li == 0:
             nodes.append(_node("Relu", [cur], ["r0"]))
@@ -110,6 +132,12 @@ def write_embedding(path, emb, fold_last_bns=0):
                 inits.append(_tensor(f"{nm}{li}", arr))
             nodes.append(_node("BatchNormalization", [cur, f"g{li}", f"b{li}", f"m{li}", f"v{li}"], [f"n{li}"], [_attr_f("epsilon", W.BN_EPS)]))
             cur = f"n{li}"
+        if li < n - 1:
+            nodes += [_node("LeakyRelu", [cur], [f"l{li}"], [_attr_f("alpha", 0.2)]), _node("Clip", [f"l{li}"], [f"a{li}"], [_attr_f("min", -0.4)])]
+            cur = f"a{li}"
+            if pool:
+                nodes.append(_node("MaxPool", [cur], [f"p{li}"], [_attr_ints("kernel_shape", list(pool)), _attr_ints("strides", list(pool))]))
+                cur = f"p{li}"
     open(path, "wb").write(_model(nodes, inits))
 
 
@@ -174,14 +202,6 @@ def test_melspectrogram_check(tmp_path):
 
 
 # ---- voice-activity network (onnx_ingest.load_vad): recognised by structure, anything else refused -------------------------
-def _attr_ints(name, vals):
-    return _ld(1, name.encode()) + b"".join(_vi((8 << 3) | 0) + _vi(v) for v in vals) + _vi((20 << 3) | 0) + _vi(7)
-
-
-def _attr_s(name, v):
-    return _ld(1, name.encode()) + _ld(4, v.encode()) + _vi((20 << 3) | 0) + _vi(3)
-
-
 def write_vad(path, vad, lstm_hidden=64, strides=(1, 2, 2, 1), with_basis=True, basis_len=256):
     """The stand-in architecture of csrc/owwhip_vad.h as an ONNX graph: [STFT basis Conv] -> 4 x (Conv1d k=3 + Relu) -> 2 x LSTM
     (ONNX gate order i, o, f, c) -> Relu -> 1x1 Conv (64 -> 1) -> Sigmoid."""
@@ -238,4 +258,351 @@ def test_vad_round_trip_and_refusals(tmp_path):
         onnx_ingest.load_vad(path)
     write_head(path, W.synthetic_head("alexa", 77))         # a wake-word head is not a VAD
     with pytest.raises(ValueError, match="operators found"):
+        onnx_ingest.load_vad(path)
+
+
+# =====================================================================================================================
+# Second, independent writer: the idioms the REAL files are likely to use.  It shares nothing with the
+# writer above -- its own protobuf encoder (packed dims, int64 tensors, ValueInfo inputs / outputs, opset imports, Constant
+# nodes, graph-valued attributes) -- and emits
+#   * tf2onnx-style embedding graphs (the notebook converts a Keras model): NHWC input, one Transpose to NCHW, explicit Pad
+#     nodes (opset-11 form: pads as an int64 input) or Conv pads / auto_pad, BatchNorm folded into the Conv bias for layers
+#     1-18 but a standalone BatchNormalization (or a per-channel Mul + Add) after conv0's Relu, the activation as
+#     Max(Mul(x, 0.2), x) -> Max(., -0.4) or as LeakyRelu + Clip with tensor bounds, weights through Constant nodes or stored
+#     HWIO behind a Transpose, a Transpose / Squeeze / Reshape tail;
+#   * torch.onnx.export-style heads: Reshape or Flatten, Gemm with transB, opset-17 LayerNormalization AND its
+#     decomposition (Mul(d, d) instead of Pow), the hey_jarvis gate as Greater + Where and as an If with subgraphs.
+# Each variant must load to the same weights as the plain writer's file, or be refused naming what was found.
+class PB:
+    """Tiny protobuf message builder: PB().i(field, int).f(field, float).b(field, bytes | str | PB) ... .done()"""
+
+    def __init__(self):
+        self.buf = bytearray()
+
+    @staticmethod
+    def varint(x: int) -> bytes:
+        x &= 0xFFFFFFFFFFFFFFFF
+        out = bytearray()
+        while x >= 0x80:
+            out.append((x & 0x7F) | 0x80)
+            x >>= 7
+        out.append(x)
+        return bytes(out)
+
+    def i(self, field, x):
+        self.buf += self.varint(field << 3) + self.varint(int(x))
+        return self
+
+    def f(self, field, x):
+        self.buf += self.varint((field << 3) | 5) + struct.pack("<f", float(x))
+        return self
+
+    def b(self, field, payload):
+        if isinstance(payload, PB):
+            payload = payload.done()
+        elif isinstance(payload, str):
+            payload = payload.encode()
+        self.buf += self.varint((field << 3) | 2) + self.varint(len(payload)) + bytes(payload)
+        return self
+
+    def done(self) -> bytes:
+        return bytes(self.buf)
+
+
+class G2:
+    """Graph under construction (writer 2)."""
+    FLOAT, INT64 = 1, 7
+
+    def __init__(self, in_name="input_1", opset=13):
+        self.nodes, self.inits, self.opset, self.n = [], [], opset, 0
+        self.inputs, self.outputs = [in_name], []
+
+    def name(self, stem="t"):
+        self.n += 1
+        return f"{stem}:{self.n}"
+
+    @staticmethod
+    def tensor(name, arr, as_float_data=False):
+        arr = np.asarray(arr)
+        t = PB()
+        if arr.ndim:
+            t.b(1, b"".join(PB.varint(d) for d in arr.shape))                 # packed dims
+        if arr.dtype.kind == "i":
+            t.i(2, G2.INT64).b(8, name).b(9, arr.astype("<i8").tobytes())
+        elif as_float_data:
+            t.i(2, G2.FLOAT).b(4, arr.astype("<f4").tobytes()).b(8, name)     # float_data, packed
+        else:
+            t.i(2, G2.FLOAT).b(8, name).b(9, arr.astype("<f4").tobytes())
+        return t
+
+    def const(self, arr, stem="const", via_node=False, as_float_data=False):
+        nm = self.name(stem)
+        if via_node:                                                            # tf2onnx leaves many constants as Constant nodes
+            attr = PB().b(1, "value").b(5, self.tensor("", arr, as_float_data)).i(20, 4)
+            self.nodes.append(PB().b(2, nm).b(3, self.name("Constant")).b(4, "Constant").b(5, attr))
+        else:
+            self.inits.append(self.tensor(nm, arr, as_float_data))
+        return nm
+
+    def op(self, op, inputs, n_out=1, out=None, **attrs):
+        outs = [out] if out else [self.name(op) for _ in range(n_out)]
+        nd = PB()
+        for x in inputs:
+            nd.b(1, x)
+        for o in outs:
+            nd.b(2, o)
+        nd.b(3, self.name("node")).b(4, op)
+        for k, v in attrs.items():
+            a = PB().b(1, k)
+            if isinstance(v, float):
+                a.f(2, v).i(20, 1)
+            elif isinstance(v, int):
+                a.i(3, v).i(20, 2)
+            elif isinstance(v, str):
+                a.b(4, v).i(20, 3)
+            elif isinstance(v, G2):
+                a.b(6, v.graph()).i(20, 5)
+            else:
+                a.b(8, b"".join(PB.varint(int(q)) for q in v)).i(20, 7)        # packed ints
+            nd.b(5, a)
+        self.nodes.append(nd)
+        return outs[0] if n_out == 1 else outs
+
+    def graph(self) -> PB:
+        g = PB()
+        for nd in self.nodes:
+            g.b(1, nd)
+        g.b(2, "graph2")
+        for t in self.inits:
+            g.b(5, t)
+        for nm in self.inputs:
+            g.b(11, PB().b(1, nm))
+        for nm in self.outputs:
+            g.b(12, PB().b(1, nm))
+        return g
+
+    def save(self, path):
+        m = PB().i(1, 8).b(2, "writer2").b(8, PB().b(1, "").i(2, self.opset)).b(7, self.graph())
+        open(path, "wb").write(m.done())
+
+
+def write_embedding_tf2onnx(path, emb, pad="node", act="maxmul", bn0="node", weights="const_node", tail="transpose_reshape",
+                            leaky=0.2, floor=-0.4, time_pad=0, pool_override=None, extra_op=None):
+    g = G2("input_1", opset=13)
+    cur = g.op("Transpose", ["input_1"], perm=[0, 3, 1, 2])                                   # NHWC -> NCHW
+    n = len(emb["conv"])
+    for li, w in enumerate(emb["conv"]):
+        kh, kw, _ci, co, pool = W.CNN_TOPOLOGY[li]
+        attrs = dict(kernel_shape=[kh, kw], strides=[1, 1], dilations=[1, 1], group=1)
+        if kw == 3 or time_pad:
+            if pad == "node":                                                                 # ZeroPadding2D -> Pad (pads as an input)
+                cur = g.op("Pad", [cur, g.const(np.array([0, 0, time_pad, 1 if kw == 3 else 0] * 2, np.int64), "pads")], mode="constant")
+            elif pad == "attr":
+                attrs["pads"] = [time_pad, 1 if kw == 3 else 0] * 2
+            elif pad == "auto" and kh == 1:
+                attrs["auto_pad"] = "SAME_UPPER"
+            else:
+                attrs["pads"] = [time_pad, 1 if kw == 3 else 0] * 2
+        oihw = np.transpose(w, (3, 2, 0, 1))
+        ins = [cur]
+        fold = 0 < li < n - 1
+        if fold:
+            scale, shift = W.bn_scale_shift(emb["bn"][li])
+            oihw = oihw * scale[:, None, None, None]
+        if weights == "hwio_transpose":                                                       # stored HWIO, transposed in the graph
+            ins.append(g.op("Transpose", [g.const(np.transpose(oihw, (2, 3, 1, 0)), "kernel")], perm=[3, 2, 0, 1]))
+        else:
+            ins.append(g.const(oihw, "kernel", via_node=(weights == "const_node" and li % 2 == 0)))
+        if fold:
+            ins.append(g.const(shift, "bias", as_float_data=True))
+        cur = g.op("Conv", ins, **attrs)
+        if li == n - 1:
+            break
+        if li == 0:
+            cur = g.op("Relu", [cur])
+            gm, bt, mu, var = emb["bn"][0]
+            if bn0 == "node":
+                cur = g.op("BatchNormalization", [cur] + [g.const(a, "bn") for a in (gm, bt, mu, var)], epsilon=float(W.BN_EPS))
+            else:                                                                             # decomposed into a per-channel affine map
+                scale, shift = W.bn_scale_shift(emb["bn"][0])
+                cur = g.op("Mul", [cur, g.const(scale.reshape(1, co, 1, 1), "scale")])
+                cur = g.op("Add", [cur, g.const(shift.reshape(1, co, 1, 1), "shift")])
+        if extra_op and li == 5:
+            cur = g.op(extra_op, [cur])
+        if act == "maxmul" or (act == "mixed" and li % 2):
+            m = g.op("Mul", [cur, g.const(np.array(leaky, np.float32), "alpha")])
+            cur = g.op("Max", [m, cur])
+            cur = g.op("Max", [cur, g.const(np.array(floor, np.float32), "floor")])
+        else:
+            cur = g.op("LeakyRelu", [cur], alpha=float(leaky))
+            cur = g.op("Clip", [cur, g.const(np.array(floor, np.float32), "lo")])             # opset >= 11: bounds are inputs
+        if pool:
+            pk = pool_override if (pool_override and li == 2) else list(pool)
+            cur = g.op("MaxPool", [cur], kernel_shape=pk, strides=pk)
+    if tail == "transpose_reshape":
+        cur = g.op("Transpose", [cur], perm=[0, 2, 3, 1])
+        cur = g.op("Reshape", [cur, g.const(np.array([-1, 1, 1, 96], np.int64), "shape")], out="conv2d_19")
+    else:
+        cur = g.op("Squeeze", [cur], out="conv2d_19", axes=[2, 3])
+    g.outputs = [cur]
+    g.save(path)
+
+
+def write_head_torch(path, head, ln="op17", gate="where", flatten="Reshape", thr=0.5, swap=False, ln_eps=1e-5, gemm_alpha=1.0):
+    g = G2("onnx::Flatten_0", opset=17)
+    T, hid = head["T"], head["hidden"]
+    if flatten == "Reshape":
+        feats = g.op("Reshape", ["onnx::Flatten_0", g.const(np.array([-1, T * 96], np.int64), "shape")])
+    else:
+        feats = g.op("Flatten", ["onnx::Flatten_0"], axis=1)
+
+    def mlp(gr, net, x):
+        cur = x
+        for li in (1, 2, 3):
+            w, b = net[f"w{li}"], net[f"b{li}"]
+            cur = gr.op("Gemm", [cur, gr.const(w.T, f"fc{li}.weight"), gr.const(b, f"fc{li}.bias")], alpha=float(gemm_alpha), beta=1.0, transB=1)
+            if li == 3:
+                break
+            lnp = net.get(f"ln{li}")
+            if lnp is not None:
+                gm, bt = gr.const(lnp[0], "ln.weight"), gr.const(lnp[1], "ln.bias")
+                if ln == "op17":
+                    cur = gr.op("LayerNormalization", [cur, gm, bt], axis=-1, epsilon=float(ln_eps))
+                else:                                                       # opset < 17 export of nn.LayerNorm
+                    mean = gr.op("ReduceMean", [cur], axes=[-1], keepdims=1)
+                    d = gr.op("Sub", [cur, mean])
+                    var = gr.op("ReduceMean", [gr.op("Mul", [d, d])], axes=[-1], keepdims=1)
+                    std = gr.op("Sqrt", [gr.op("Add", [var, gr.const(np.array(ln_eps, np.float32), "eps")])])
+                    cur = gr.op("Add", [gr.op("Mul", [gr.op("Div", [d, std]), gm]), bt])
+            cur = gr.op("Relu", [cur])
+        return gr.op("Sigmoid", [cur]) if head["kind"] != "multiclass" else gr.op("Softmax", [gr.op("Relu", [cur])], axis=-1)
+
+    s1 = mlp(g, head["net"], feats)
+    out = s1
+    if head["kind"] == "gated":
+        half = g.const(np.array(thr, np.float32), "thr")
+        cond = g.op("Greater", [s1, half])
+        if gate == "where":
+            s2 = mlp(g, head["net2"], feats)
+            out = g.op("Where", [cond, s1, s2] if swap else [cond, s2, s1])
+        else:                                                               # torch.jit.script-style control flow: If with subgraphs
+            flag = g.op("Squeeze", [cond])
+            then_g, else_g = G2("", 17), G2("", 17)
+            then_g.inputs = else_g.inputs = []
+            then_g.n = 1000
+            then_g.outputs = [mlp(then_g, head["net2"], feats)]             # `feats` is captured from the outer scope
+            else_g.outputs = [else_g.op("Identity", [s1])]
+            if swap:
+                then_g, else_g = else_g, then_g
+            out = g.op("If", [flag], then_branch=then_g, else_branch=else_g)
+    g.outputs = [out]
+    g.save(path)
+
+
+def _same_embedding(a, b, atol=0.0):
+    assert len(a["conv"]) == len(b["conv"]) == 20 and len(a["bn"]) == len(b["bn"]) == 19
+    for li, (x, y) in enumerate(zip(a["conv"], b["conv"])):
+        sa, sb = (W.bn_scale_shift(a["bn"][li])[0], W.bn_scale_shift(b["bn"][li])[0]) if li < 19 else (1.0, 1.0)
+        np.testing.assert_allclose(x * sa, y * sb, rtol=0, atol=atol, err_msg=f"conv {li} (x BatchNorm scale)")
+    for li in range(19):
+        np.testing.assert_allclose(W.bn_scale_shift(a["bn"][li])[1], W.bn_scale_shift(b["bn"][li])[1], rtol=0, atol=atol, err_msg=f"shift {li}")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                                                  # Pad nodes, Max(Mul) activation, BN node after conv0, Constant nodes
+    dict(pad="attr", act="leakyclip", bn0="affine", weights="init", tail="squeeze"),
+    dict(pad="auto", act="mixed", weights="hwio_transpose"),
+], ids=["pad-node_maxmul", "pads-attr_leakyclip_affine-bn0", "auto-pad_mixed_hwio"])
+def test_embedding_tf2onnx_idioms_load_to_the_same_network(tmp_path, kw):
+    emb = W.synthetic_embedding(55)
+    plain, tf = os.path.join(tmp_path, "plain.onnx"), os.path.join(tmp_path, "tf2onnx.onnx")
+    write_embedding(plain, emb)
+    write_embedding_tf2onnx(tf, emb, **kw)
+    a, b = onnx_ingest.load_embedding(plain), onnx_ingest.load_embedding(tf)
+    _same_embedding(a, b, atol=2e-7)                                         # (folding rounds w * scale to fp32 once)
+    x = np.random.default_rng(2).normal(10, 1.5, (2, 76, 32, 1)).astype(np.float32)
+    np.testing.assert_allclose(O.embedding_stage(x, b, np.float64), O.embedding_stage(x, emb, np.float64), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("kw,why", [
+    (dict(leaky=0.3), "0.3"),                                                # another slope
+    (dict(act="leakyclip", leaky=0.01), "LeakyRelu alpha"),
+    (dict(floor=-0.5), "lower bound -0.5"),
+    (dict(time_pad=1), "pad the mel axis only"),                             # 'same' padding on the time axis too
+    (dict(pool_override=[2, 1]), "MaxPool kernel"),
+    (dict(extra_op="Tanh"), "operator Tanh"),
+    (dict(extra_op="Relu"), "Relu"),
+])
+def test_embedding_graphs_that_compute_something_else_are_refused_by_name(tmp_path, kw, why):
+    path = os.path.join(tmp_path, "odd.onnx")
+    write_embedding_tf2onnx(path, W.synthetic_embedding(55), **kw)
+    with pytest.raises(ValueError, match=why):
+        onnx_ingest.load_embedding(path)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("alexa", dict(ln="op17")), ("alexa", dict(ln="decomposed", flatten="Flatten")), ("timer", dict()),
+    ("hey_jarvis", dict(gate="where")), ("hey_jarvis", dict(gate="if", ln="decomposed")),
+], ids=["ln-op17", "ln-decomposed", "multiclass", "gate-where", "gate-if"])
+def test_head_torch_export_idioms_load_to_the_same_head(tmp_path, name, kw):
+    head = W.synthetic_head(name, 77)
+    plain, th = os.path.join(tmp_path, "plain.onnx"), os.path.join(tmp_path, "torch.onnx")
+    write_head(plain, head)
+    write_head_torch(th, head, **kw)
+    a, b = onnx_ingest.load_head(plain), onnx_ingest.load_head(th)
+    assert (a["kind"], a["T"], a["hidden"], a["n_out"]) == (b["kind"], b["T"], b["hidden"], b["n_out"]) == (head["kind"], head["T"], head["hidden"], head["n_out"])
+    for net in ("net", "net2"):
+        if net in head:
+            for k, v in head[net].items():
+                for x, y, z in ((v, a[net][k], b[net][k]),) if not isinstance(v, tuple) else zip(v, a[net][k], b[net][k]):
+                    if x is not None:
+                        np.testing.assert_array_equal(x, y)
+                        np.testing.assert_array_equal(x, z)
+    feats = np.random.default_rng(1).normal(0, 2, (5, head["T"], 96)).astype(np.float32)
+    np.testing.assert_array_equal(O.head_stage(feats, b, np.float32), O.head_stage(feats, head, np.float32))
+
+
+@pytest.mark.parametrize("kw,why", [
+    (dict(gate="where", thr=0.7), "gate threshold 0.7"),
+    (dict(gate="where", swap=True), "SECOND network"),
+    (dict(gate="if", swap=True), "then-branch|else-branch"),
+    (dict(ln="op17", ln_eps=1e-3), "epsilon 0.001"),
+    (dict(ln="decomposed", ln_eps=1e-6), "epsilon 1e-06"),
+    (dict(gemm_alpha=0.5), "alpha"),
+])
+def test_heads_that_compute_something_else_are_refused_by_name(tmp_path, kw, why):
+    path = os.path.join(tmp_path, "odd.onnx")
+    write_head_torch(path, W.synthetic_head("hey_jarvis", 77), **kw)
+    with pytest.raises(ValueError, match=why):
+        onnx_ingest.load_head(path)
+
+
+def test_two_networks_without_a_gate_are_refused(tmp_path):
+    path = os.path.join(tmp_path, "nogate.onnx")
+    write_head(path, W.synthetic_head("hey_jarvis", 77), tail=["Sigmoid"])            # writer 1 emits the routing only for tail=None
+    with pytest.raises(ValueError, match="no comparison"):
+        onnx_ingest.load_head(path)
+
+
+def test_vad_reader_turns_every_parsing_failure_into_a_refusal(tmp_path):
+    """a Silero-like file with If subgraphs, or an LSTM node without its optional inputs, must come back as the
+    ValueError that names the host-side way out -- not as an IndexError / KeyError from the middle of the reader."""
+    path = os.path.join(tmp_path, "silero_vad.onnx")
+    g = G2("input", 16)
+    sr_ok = g.op("Equal", ["sr", g.const(np.array(16000, np.int64), "sr16k")])
+    then_g, else_g = G2("", 16), G2("", 16)
+    then_g.inputs = else_g.inputs = []
+    then_g.outputs = [then_g.op("LSTM", ["input"], hidden_size=64)]                    # no W / R / B inputs at all
+    else_g.outputs = [else_g.op("Identity", ["input"])]
+    out = g.op("If", [sr_ok], then_branch=then_g, else_branch=else_g)
+    g.op("LSTM", [out], hidden_size=64)
+    g.op("LSTM", [out], hidden_size=64)
+    for li, (cin, cout, _s) in enumerate(W.VAD_ENC):
+        g.op("Conv", [out, g.const(np.zeros((cout, cin, 3), np.float32), "w")], strides=[_s], pads=[1, 1])
+    g.outputs = [out]
+    g.save(path)
+    with pytest.raises(ValueError, match="oww_push_vad"):
+        onnx_ingest.load_vad(path)
+    open(path, "wb").write(b"\x3a\xff\xff\xff\x0f" + b"\x00" * 10)                     # a length prefix that runs past the end of the file
+    with pytest.raises(ValueError):
         onnx_ingest.load_vad(path)
