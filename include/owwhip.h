@@ -87,6 +87,17 @@ int  oww_add_head(oww_ctx* h, const void* blob, size_t nbytes);     /* returns h
  * utils.py:84-93 -- are REFUSED here with OWW_ERANGE (message names the deviation; use use_mfma = 1 for them) instead of scoring
  * differently later.  Adds ~0.05-0.3 s to the call.  (OWW_NO_COMMIT_SELFTEST=1 in the environment skips step (2): development only.) */
 int  oww_commit(oww_ctx* h);
+/* Optional, before oww_commit, use_mfma = 3 only (ignored by the fp32 families): calibration audio of the caller's domain -- int16
+ * [n_streams][n_frames * 1280], host pointer, copied.  oww_commit derives the fp16-split kernels' scale ladder from, and runs its
+ * f16x3-vs-fp32 self-test on, the built-in synthetic probes (silence, noise at five levels, square waves) PLUS this audio, cut into
+ * 16-frame segments (at most 224 of them are used).  The reference's fp32 graphs have no range to calibrate (utils.py:84-93); the
+ * Python layer passes speech (the reference's three fixture clips at several gains) by default.  pcm = NULL clears the set. */
+int  oww_set_calibration(oww_ctx* h, const int16_t* pcm, int32_t n_streams, int32_t n_frames);
+/* What oww_commit measured and decided (use_mfma = 3; any pointer may be NULL): absmax[l] = largest |activation| of CNN layer l over
+ * the probe set on the exact-fp32 kernels; exps[l] = the layer's power-of-two scale exponent, exps[20] = the exponent the heads' GEMM
+ * applies to the features; n_probe_streams = 32 built-in + the caller's 16-frame segments; selftest = {max |embedding - fp32|,
+ * max |embedding|, max |raw score - fp32|} of the fp16-split replay of the probes. */
+int  oww_calibration_info(oww_ctx* h, float absmax[20], int32_t exps[21], int32_t* n_probe_streams, float selftest[3]);
 int  oww_n_labels(const oww_ctx* h);  /* total score columns = sum of n_out over heads */
 
 /* ---- per-stream state (AudioFeatures.reset utils.py:172-178 + Model.reset model.py:226-230) -----

@@ -33,6 +33,8 @@ SYMBOLS = {
     "oww_load_embedding": (C.c_int, [_P, _P, C.c_size_t]),
     "oww_add_head": (C.c_int, [_P, _P, C.c_size_t]),
     "oww_commit": (C.c_int, [_P]),
+    "oww_set_calibration": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "oww_calibration_info": (C.c_int, [_P, _P, _P, _P, _P]),
     "oww_n_labels": (C.c_int, [_P]),
     "oww_reset": (C.c_int, [_P, _P, C.c_int32, _P]),
     "oww_set_postproc": (C.c_int, [_P, _P, _P, C.c_int32]),

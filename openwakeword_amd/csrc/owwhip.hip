@@ -111,10 +111,19 @@ void pack_rr(const float* w, int ntaps, int cin, int cout, std::vector<float>& o
                     }
 }
 
-// the f16 halves of 2^8 * w must stay finite: |w| < 255 (trained linear weights are orders of magnitude below); heads and VAD
+// the f16 halves of 2^8 * w must stay finite: |w| < 255 (trained linear weights are orders of magnitude below); VAD network
 bool hx_in_range(const float* w, size_t n) {
     for (size_t i = 0; i < n; ++i) if (!(std::fabs(w[i]) * owh::WSCALE < 65000.f)) return false;
     return true;
+}
+// heads: the power-of-two exponent e that puts the largest |w| of a matrix at 2^11 .. 2^12 (its f16 halves then carry 22 bits for
+// every weight down to 2^-13 of the largest; no weight magnitude is refused); -1000 when a weight is not finite
+int hx_weight_exp(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) { if (!std::isfinite(w[i])) return -1000; m = std::max(m, std::fabs(w[i])); }
+    int e2 = 0;
+    if (m > 0.f) std::frexp(m, &e2);                 // m < 2^e2
+    return std::min(100, std::max(-100, 12 - e2));
 }
 
 // Half channel tiles of the fp16-split family (24 = 16 + 8, 72 = 64 + 8 channels).  The MFMA D layout puts row 4j + e of a tile into
@@ -214,7 +223,7 @@ void pad_hx_rows(const float* v, int C, float mul, std::vector<float>& out) {
         for (int r = 0; r < 16; ++r) { const int c = hx_row_channel(t, r, C); if (c >= 0) out[t * 16 + r] = v[c] * mul; }
 }
 // heads layer 1 (owh::heads_hx_kernel): k-step major [K/32][NH/16][part][64][8]; lane (i, g), half q <-> input 32ks + 8g + q
-void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, std::vector<float>& out) {
+void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, const double* colmul /*[NH]*/, std::vector<float>& out) {
     const int nks = K / 32, nct = NH / 16;
     std::vector<_Float16> hbuf((size_t)nks * nct * 2 * 64 * 8, (_Float16)0.f);
     for (int ks = 0; ks < nks; ++ks)
@@ -222,8 +231,8 @@ void pack_hx_w1(const float* wcat /*[K][NH]*/, int K, int NH, std::vector<float>
             for (int lane = 0; lane < 64; ++lane)
                 for (int q = 0; q < 8; ++q) {
                     const int i = lane & 15, g = lane >> 4;
-                    const float v = wcat[(size_t)(32 * ks + 8 * g + q) * NH + 16 * ct + i] * owh::WSCALE;
-                    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                    const double v = (double)wcat[(size_t)(32 * ks + 8 * g + q) * NH + 16 * ct + i] * colmul[16 * ct + i];
+                    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (double)hi);
                     const size_t blk = ((size_t)ks * nct + ct) * 2;
                     hbuf[(blk * 64 + lane) * 8 + q] = hi;
                     hbuf[((blk + 1) * 64 + lane) * 8 + q] = lo;
@@ -294,6 +303,7 @@ struct HostBuf {                      // host image of the device weight buffer 
 struct NetHost {
     int hidden, n_out, has_ln, T, final_act, head, role, out_col;
     const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // into the owning head blob
+    int hx_e1 = 0, hx_e2 = 0;         // fp16-split heads: power-of-two scales of w1 / w2 (hx_weight_exp)
 };
 struct HeadHost {
     int kind, T, hidden, n_out, has_ln;
@@ -400,6 +410,8 @@ struct oww_ctx {
     // (and the pooled input of conv19) is re-scaled by 2^hx_xexp[stage], the embedding by 2^-hx_e[19] when it is stored.
     int hx_e[20] = {}, hx_ein[20] = {}, hx_xexp[5] = {};
     float hx_absmax[20] = {};        // largest |activation| of each layer in the calibration run (exact-fp32 kernels)
+    std::vector<int16_t> cal_user;   // oww_set_calibration: caller's calibration audio as [n_seg][CAL_T * 1280] segments
+    int hx_efeat = 0;                // heads: the features enter the first GEMM multiplied by 2^hx_efeat (largest probe |embedding| at 2^9..2^10)
     float hx_selftest_err = 0.f, hx_selftest_ref = 0.f, hx_selftest_score_err = 0.f;   // commit-time f16-split vs exact-fp32 comparison
     bool fuse = false;               // f16-split family: mel front end fused into stage A for one-chunk streaming steps (owwhip_fused.h)
     const int16_t* fuse_pcm = nullptr;   // set by launch_step for the duration of a fused step
@@ -669,7 +681,9 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                     owh::HeadHxNet& o = q.net[i];
                     o.w2hx = g.d_w2hx[i]; o.b1 = d.b1; o.ln1g = d.ln1g; o.ln1b = d.ln1b; o.b2 = d.b2; o.ln2g = d.ln2g; o.ln2b = d.ln2b;
                     o.w3 = d.w3; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
+                    o.u1 = std::ldexp(1.0f, -(h->hx_efeat + n.hx_e1)); o.u2 = std::ldexp(1.0f, -n.hx_e2);
                 }
+                q.fscale = std::ldexp(1.0f, h->hx_efeat);
                 const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
                 const int lds = owh::HX_NBUF * g.n_nets * 8 * 1024;
                 switch (g.n_nets) {
@@ -1036,16 +1050,26 @@ int park_state(oww_ctx* h, int n_streams, bool save) {
 //  (3) replays the probes through the handle's own f16-split kernels and compares the embeddings (and, with heads loaded, the raw
 //      head outputs) with the fp32 run: weights for which the two differ by more than the north-star tolerance are refused with
 //      OWW_ERANGE at commit instead of scoring differently later.
-constexpr int CAL_NP = 32, CAL_T = 16;
+// Probes run in batches of CAL_NP streams x CAL_T frames (every handle has at least 32 padded streams): batch 0 is the built-in
+// synthetic set, further batches carry the caller's calibration audio (oww_set_calibration: speech), cut into CAL_T-frame segments.
+constexpr int CAL_NP = 32, CAL_T = 16, CAL_MAX_BATCHES = 8;
 struct HxCalib {
-    std::vector<int16_t> pcm;        // [CAL_T][CAL_NP][1280]
-    std::vector<float> ref_emb;      // [CAL_T][CAL_NP][96]   exact-fp32 embeddings of the probe run
-    std::vector<float> ref_raw;      // [CAL_T][CAL_NP][NL]   exact-fp32 raw head outputs
+    int nb = 1;                      // batches
+    std::vector<int16_t> pcm;        // [nb][CAL_T][CAL_NP][1280]
+    std::vector<float> ref_emb;      // [nb][CAL_T][CAL_NP][96]   exact-fp32 embeddings of the probe run
+    std::vector<float> ref_raw;      // [nb][CAL_T][CAL_NP][NL]   exact-fp32 raw head outputs
     int NL = 0;
 };
 
-void make_probe_pcm(std::vector<int16_t>& pcm) {
-    pcm.assign((size_t)CAL_T * CAL_NP * OWW_CHUNK, 0);
+void make_probe_pcm(std::vector<int16_t>& pcm, const std::vector<int16_t>& user /*[n_seg][CAL_T * 1280]*/) {
+    const size_t seg = (size_t)CAL_T * OWW_CHUNK, n_seg = user.size() / seg;
+    const int nb = 1 + (int)((n_seg + CAL_NP - 1) / CAL_NP);
+    pcm.assign((size_t)nb * CAL_T * CAL_NP * OWW_CHUNK, 0);
+    for (size_t k = 0; k < n_seg; ++k) {
+        const size_t b = 1 + k / CAL_NP, i = k % CAL_NP;
+        for (int it = 0; it < CAL_T; ++it)
+            memcpy(&pcm[((b * CAL_T + it) * CAL_NP + i) * OWW_CHUNK], &user[k * seg + (size_t)it * OWW_CHUNK], OWW_CHUNK * sizeof(int16_t));
+    }
     uint64_t st = 0x9E3779B97F4A7C15ull;
     auto u01 = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((st >> 11) + 1) * (1.0 / 9007199254740993.0); };
     const double amps[5] = {30, 300, 3000, 12000, 32767};
@@ -1077,7 +1101,8 @@ int probe_step(oww_ctx* t, const int16_t* d_chunk, bool heads) {
 }
 
 int calibrate_hx(oww_ctx* h, HxCalib& cal) {
-    make_probe_pcm(cal.pcm);
+    make_probe_pcm(cal.pcm, h->cal_user);
+    cal.nb = (int)(cal.pcm.size() / ((size_t)CAL_T * CAL_NP * OWW_CHUNK));
     oww_config c2 = h->cfg;
     c2.n_streams = CAL_NP; c2.max_chunks = 1; c2.use_mfma = 1; c2.debug_layers = 1; c2.stream = nullptr;
     c2.feature_ring = h->TR;
@@ -1110,15 +1135,18 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
         hipLaunchKernelGGL(fill_kernel, dim3(CAL_NP), dim3(256), 0, t->stream, t->d_mel, (size_t)CAL_NP * 256, 1.0f);
         if ((rc = run_cnn(t, CAL_NP, 256, 0))) break;
         absmax();
-        // (b) the probe audio
-        cal.ref_emb.assign((size_t)CAL_T * CAL_NP * 96, 0.f);
-        cal.ref_raw.assign((size_t)CAL_T * CAL_NP * std::max(t->NL, 1), 0.f);
-        for (int it = 0; it < CAL_T && !rc; ++it) {
-            if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)it * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
+        // (b) the probe audio, batch by batch from the reset state
+        cal.ref_emb.assign((size_t)cal.nb * CAL_T * CAL_NP * 96, 0.f);
+        cal.ref_raw.assign((size_t)cal.nb * CAL_T * CAL_NP * std::max(t->NL, 1), 0.f);
+        for (int bt = 0; bt < cal.nb * CAL_T && !rc; ++bt) {
+            const int it = bt % CAL_T;
+            if (it == 0 && bt > 0 && (rc = do_reset(t, nullptr, CAL_NP, nullptr))) break;
+            // (the upload waits for the previous step: one staging buffer, stream-ordered copies from pageable memory are synchronous)
+            if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
             if ((rc = probe_step(t, d_chunk, true))) break;
             absmax();
-            if (hipMemcpyAsync(&cal.ref_emb[(size_t)it * CAL_NP * 96], t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
-                (t->NL > 0 && hipMemcpyAsync(&cal.ref_raw[(size_t)it * CAL_NP * t->NL], t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+            if (hipMemcpyAsync(&cal.ref_emb[(size_t)bt * CAL_NP * 96], t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+                (t->NL > 0 && hipMemcpyAsync(&cal.ref_raw[(size_t)bt * CAL_NP * t->NL], t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
         }
         if (rc) break;
         unsigned mx[20];
@@ -1147,6 +1175,7 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
         }
         h->hx_ein[19] = cl(3 - ex(18));
         h->hx_e[19] = h->hx_ein[19] + 2;                        // conv19: no activation, its output is un-scaled when the embedding is stored
+        h->hx_efeat = cl(10 - ex(19));                          // the heads' GEMM takes the (true-unit) feature ring at this scale
         for (int st = 0; st < 5; ++st) {
             const int last = st == 0 ? 2 : first[st] + 3, nxt = last + 1;
             h->hx_xexp[st] = h->hx_ein[nxt] - h->hx_e[last];
@@ -1166,14 +1195,15 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
 int selftest_hx(oww_ctx* h, const HxCalib& cal) {
     int16_t* d_chunk = nullptr;
     if (hipMalloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) return fail(OWW_ENOMEM, "oww_commit: out of device memory (self-test)");
-    std::vector<float> emb((size_t)CAL_T * CAL_NP * 96), raw((size_t)CAL_T * CAL_NP * std::max(h->NL, 1));
+    std::vector<float> emb((size_t)cal.nb * CAL_T * CAL_NP * 96), raw((size_t)cal.nb * CAL_T * CAL_NP * std::max(h->NL, 1));
     int rc = 0;
     float* saved_dbg = h->d_dbg; h->d_dbg = nullptr;
-    for (int it = 0; it < CAL_T && !rc; ++it) {
-        if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)it * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
+    for (int bt = 0; bt < cal.nb * CAL_T && !rc; ++bt) {
+        if (bt % CAL_T == 0 && bt > 0 && (rc = do_reset(h, nullptr, CAL_NP, nullptr))) break;
+        if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
         if ((rc = probe_step(h, d_chunk, true))) break;
-        if (hipMemcpyAsync(&emb[(size_t)it * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            (h->NL > 0 && hipMemcpyAsync(&raw[(size_t)it * CAL_NP * h->NL], h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+        if (hipMemcpyAsync(&emb[(size_t)bt * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            (h->NL > 0 && hipMemcpyAsync(&raw[(size_t)bt * CAL_NP * h->NL], h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
     }
     h->d_dbg = saved_dbg;
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(OWW_EHIP, "oww_commit: self-test run failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1323,6 +1353,37 @@ int oww_load_vad(oww_ctx* h, const void* blob, size_t nbytes) {
     if (hdr[0] != 1 || hdr[1] != 256 || hdr[2] != 64 || hdr[3] != 128 || hdr[4] != 64)
         return fail(OWW_EINVAL, "oww_load_vad: unsupported geometry (version %d, n_fft %d, hop %d, bins %d, hidden %d)", hdr[0], hdr[1], hdr[2], hdr[3], hdr[4]);
     h->vad_blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
+    return OWW_OK;
+    OWW_GUARD_END
+}
+
+int oww_set_calibration(oww_ctx* h, const int16_t* pcm, int32_t n_streams, int32_t n_frames) {
+    OWW_GUARD_BEGIN
+    if (!h) return fail(OWW_EINVAL, "oww_set_calibration: null handle");
+    if (h->committed) return fail(OWW_ESTATE, "oww_set_calibration: call before oww_commit");
+    h->cal_user.clear();
+    if (!pcm || n_streams < 1 || n_frames < 1) return OWW_OK;          // (clears the set)
+    const size_t seg = (size_t)CAL_T * OWW_CHUNK;
+    const int per = (n_frames + CAL_T - 1) / CAL_T;                     // CAL_T-frame segments per stream (the last one zero-padded)
+    const size_t n_seg = std::min<size_t>((size_t)n_streams * per, (size_t)(CAL_MAX_BATCHES - 1) * CAL_NP);
+    h->cal_user.assign(n_seg * seg, 0);
+    for (size_t k = 0; k < n_seg; ++k) {
+        const size_t s = k / per, part = k % per;
+        const size_t first = part * seg, n = std::min(seg, (size_t)n_frames * OWW_CHUNK - first);
+        memcpy(&h->cal_user[k * seg], pcm + s * (size_t)n_frames * OWW_CHUNK + first, n * sizeof(int16_t));
+    }
+    return OWW_OK;
+    OWW_GUARD_END
+}
+
+int oww_calibration_info(oww_ctx* h, float absmax[20], int32_t exps[21], int32_t* n_probe_streams, float selftest[3]) {
+    OWW_GUARD_BEGIN
+    if (!h || !h->committed) return fail(OWW_ESTATE, "oww_calibration_info: handle not committed");
+    if (!h->hx) return fail(OWW_ESTATE, "oww_calibration_info: only the fp16-split family (use_mfma = 3) calibrates");
+    if (absmax) memcpy(absmax, h->hx_absmax, sizeof h->hx_absmax);
+    if (exps) { for (int l = 0; l < 20; ++l) exps[l] = h->hx_e[l]; exps[20] = h->hx_efeat; }
+    if (n_probe_streams) *n_probe_streams = CAL_NP + (int32_t)(h->cal_user.size() / ((size_t)CAL_T * OWW_CHUNK));
+    if (selftest) { selftest[0] = h->hx_selftest_err; selftest[1] = h->hx_selftest_ref; selftest[2] = h->hx_selftest_score_err; }
     return OWW_OK;
     OWW_GUARD_END
 }
@@ -1484,12 +1545,21 @@ int oww_commit(oww_ctx* h) {
         pack_mfma(wcat.data(), g.T, 96, g.NH, pk);
         GOff go{hb.add(pk), hb.add(bcat), 0, {}};
         if (h->hx) {
-            if (!hx_in_range(wcat.data(), wcat.size())) return fail(OWW_EINVAL, "head weights too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1");
-            pack_hx_w1(wcat.data(), (int)K, g.NH, pk);
+            // every net's two matrices on their own power-of-two scale (hx_weight_exp); undone on the fp32 accumulators (HeadHxNet::u1, u2)
+            std::vector<double> colmul(g.NH);
+            for (int gi = 0; gi < g.n_nets; ++gi) {
+                NetHost& n = h->nets[g.nets[gi]];
+                n.hx_e1 = hx_weight_exp(n.w1, K * 64); n.hx_e2 = hx_weight_exp(n.w2, 64 * 64);
+                if (n.hx_e1 == -1000 || n.hx_e2 == -1000) return fail(OWW_EINVAL, "head weights are not finite");
+                for (int c = 0; c < 64; ++c) colmul[64 * gi + c] = std::ldexp(1.0, n.hx_e1);
+            }
+            pack_hx_w1(wcat.data(), (int)K, g.NH, colmul.data(), pk);
             go.w1hx = hb.add(pk);
             for (int gi = 0; gi < g.n_nets; ++gi) {
-                if (!hx_in_range(h->nets[g.nets[gi]].w2, 64 * 64)) return fail(OWW_EINVAL, "head weights too large for the fp16-split kernels (use_mfma = 3); use use_mfma = 1");
-                pack_hx(h->nets[g.nets[gi]].w2, 1, 64, 64, pk); go.w2hx.push_back(hb.add(pk));
+                const NetHost& n = h->nets[g.nets[gi]];
+                std::vector<double> cm2(64, std::ldexp(1.0, n.hx_e2));
+                HxFold fold; fold.colmul = cm2.data();
+                pack_hx(n.w2, 1, 64, 64, pk, &fold); go.w2hx.push_back(hb.add(pk));
             }
         }
         goff.push_back(go);

@@ -1388,6 +1388,7 @@ struct HeadHxNet {
     const float *w2hx;                       // [4 oct][2 ks][2 part][64][8 halves]
     const float *b1, *ln1g, *ln1b, *b2, *ln2g, *ln2b, *w3, *b3;
     int has_ln, role, head, out_col;
+    float u1, u2;                            // exact power-of-two un-scales of the two accumulators: 2^-(e_feat + e_w1), 2^-e_w2
 };
 // Optional tail of the heads kernel: Model.predict's post-processing (model.py:330-381 -- first-5 zeroing, patience / debounce
 // over the 30-deep score ring, ring append, VAD gate) and the step's frame-counter advance for the same streams, instead of two
@@ -1420,6 +1421,11 @@ struct HeadHxParams {
     const int* ids;             // oww_step_masked with few participants: the n_ids participating streams (position k of the launch = stream
     int n_ids;                  // ids[k]); nullptr = streams s_base .. S-1
     int s_base;                 // block-pipelined step: first stream of this launch (S = one past its last)
+    // Like every CNN layer, the first GEMM runs on a calibrated power-of-two scale: the features are multiplied by fscale = 2^e_feat
+    // as they are loaded (oww_commit puts the probe set's largest |embedding| at 2^9..2^10 -- a factor 64 below the f16 overflow, and
+    // embeddings of order 1e-4 keep the low halves of their split), each net's weights are stored as halves of 2^e_w w with the
+    // largest at 2^11..2^12 (no fixed 2^8: weights of any magnitude fit), and HeadHxNet::u1 / u2 undo both on the fp32 accumulator.
+    float fscale;
 };
 
 __device__ __forceinline__ float xsum4(float v) {      // sum over the four j groups (lanes p, p+16, p+32, p+48)
@@ -1430,12 +1436,12 @@ __device__ __forceinline__ float xsum4(float v) {      // sum over the four j gr
 
 template <int NN>
 __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__ bias, const float* __restrict__ g,
-                                        const float* __restrict__ b, int has_ln, int j) {
+                                        const float* __restrict__ b, int has_ln, int j, float unscale) {
     // h: the 64 hidden values of one net for this lane's stream: tile ct, register e <-> hidden 16ct + 4j + e
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * j);
-        h[ct] = h[ct] * WUNSCALE + bb;
+        h[ct] = h[ct] * unscale + bb;
     }
     if (has_ln) {
         float sum = 0.f;
@@ -1514,8 +1520,8 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
         for (int t = 0; t < 2; ++t) {
             const uint32_t slot = p.ext ? (uint32_t)tr : (slot0[t] + (uint32_t)tr) % (uint32_t)p.TR;
             const float* src = frow[t] + (size_t)slot * 96 + c0;
-            r[t][0] = *reinterpret_cast<const f32x4*>(src);
-            r[t][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            r[t][0] = *reinterpret_cast<const f32x4*>(src) * p.fscale;
+            r[t][1] = *reinterpret_cast<const f32x4*>(src + 4) * p.fscale;
         }
     };
     f32x4 acc[NCT][2];
@@ -1566,7 +1572,7 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 h1[4] = {acc[4 * n][t], acc[4 * n + 1][t], acc[4 * n + 2][t], acc[4 * n + 3][t]};
-            ln_relu<NN>(h1, net.b1, net.ln1g, net.ln1b, net.has_ln, j);
+            ln_relu<NN>(h1, net.b1, net.ln1g, net.ln1b, net.has_ln, j, net.u1);
             Op ho[2];
             to_ops<4>(h1, ho);
             f32x4 h2[4];
@@ -1584,7 +1590,7 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
                 h2[oct] = a2;
                 if (oct == 0) nan_guard(bad, a2[0]);
             }
-            ln_relu<NN>(h2, net.b2, net.ln2g, net.ln2b, net.has_ln, j);
+            ln_relu<NN>(h2, net.b2, net.ln2g, net.ln2b, net.has_ln, j, net.u2);
             float z = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {

@@ -12,6 +12,7 @@ Thin by design: blob packing + ctypes calls.  All arithmetic happens in the HIP 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
@@ -88,6 +89,28 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_CAL_CLIPS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resources", "calibration_clips.npz")
+
+
+def default_calibration_pcm() -> Optional[np.ndarray]:
+    """Speech for the commit-time calibration / self-test of the fp16-split kernels (oww_set_calibration): int16 [12, 16 * 1280].
+    The three 16 kHz clips are the reference's own test fixtures (/root/reference/tests/data/{alexa_test,hey_mycroft_test,hey_jane}.wav,
+    2.4 s of speech in all; shipped as resources/calibration_clips.npz), each tiled to 16 frames as recorded, peak-normalised to full
+    scale, and 20 dB down, plus one half-period-shifted copy of each: the loudness range a microphone front end delivers, with the
+    spectral and temporal structure noise and square waves do not have.  None when the resource file is absent."""
+    if not os.path.exists(_CAL_CLIPS):
+        return None
+    z = np.load(_CAL_CLIPS)
+    n = 16 * CHUNK
+    rows = []
+    for k in sorted(z.files):
+        x = z[k].astype(np.float64)
+        full = x * (32767.0 / max(1.0, np.abs(x).max()))
+        for y in (x, full, 0.1 * x, np.roll(full, len(x) // 2)):
+            rows.append(np.clip(np.rint(np.resize(y, n)), -32768, 32767).astype(np.int16))
+    return np.stack(rows)
+
+
 class StreamEngine:
     """One GPU, S streams.  `heads` maps model name -> head dict (see weights.synthetic_head).
 
@@ -97,9 +120,13 @@ class StreamEngine:
 
     def __init__(self, n_streams: int, heads: Dict[str, dict], embedding: Optional[dict] = None,
                  device: int = 0, max_chunks: int = 1, use_mfma: int = 3, debug_layers: bool = False,
-                 feature_ring: int = 0, hip_stream: int = 0, vad: Optional[dict] = None, vad_threshold: float = 0.0):
+                 feature_ring: int = 0, hip_stream: int = 0, vad: Optional[dict] = None, vad_threshold: float = 0.0,
+                 calibration_pcm: Union[np.ndarray, str, None] = "default"):
         """`vad`: weights of the on-device voice-activity stand-in network (weights.synthetic_vad layout); when given, every
-        step also runs it on the frame's two 640-sample sub-frames and gates the scores with `vad_threshold` (model.py:366-381)."""
+        step also runs it on the frame's two 640-sample sub-frames and gates the scores with `vad_threshold` (model.py:366-381).
+        `calibration_pcm` (use_mfma = 3): audio of the deployment's domain, int16 [n, k * 1280], that oww_commit adds to its built-in
+        probes when it calibrates the activation scales and holds the fp16-split kernels to the exact-fp32 ones; "default" = speech
+        (default_calibration_pcm), None = the synthetic probes only."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self._inflight: List[np.ndarray] = []
@@ -128,6 +155,15 @@ class StreamEngine:
             if vad is not None:
                 blob = pack_vad_blob(vad)
                 _lib.check(self._lib.oww_load_vad(self._h, _ptr(blob), blob.nbytes))
+            if isinstance(calibration_pcm, str):
+                calibration_pcm = default_calibration_pcm() if calibration_pcm == "default" else None
+            if calibration_pcm is not None and int(use_mfma) == 3:
+                cal = np.ascontiguousarray(calibration_pcm, dtype=np.int16)
+                if cal.ndim != 2 or cal.shape[1] < CHUNK:
+                    raise ValueError("calibration_pcm must be int16 [n_streams, n_frames * 1280]")
+                n_frames = cal.shape[1] // CHUNK
+                cal = np.ascontiguousarray(cal[:, :n_frames * CHUNK])
+                _lib.check(self._lib.oww_set_calibration(self._h, _ptr(cal), cal.shape[0], n_frames))
             _lib.check(self._lib.oww_commit(self._h))
             if vad_threshold:
                 _lib.check(self._lib.oww_set_vad_threshold(self._h, float(vad_threshold)))
@@ -283,6 +319,17 @@ class StreamEngine:
         arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
         weakref.finalize(buf, self._lib.oww_host_free, C.c_void_p(p.value))
         return arr
+
+    def calibration_info(self) -> Dict[str, object]:
+        """What oww_commit measured on its probe set (fp16-split family): per-layer |activation| maxima, the power-of-two scale
+        exponents (CNN layers and the heads' feature scale), the number of probe streams and the commit-time self-test errors."""
+        absmax = np.zeros(20, np.float32)
+        exps = np.zeros(21, np.int32)
+        n = C.c_int32(0)
+        st = np.zeros(3, np.float32)
+        _lib.check(self._lib.oww_calibration_info(self._h, _ptr(absmax), _ptr(exps), C.byref(n), _ptr(st)))
+        return {"absmax": absmax, "layer_exp": exps[:20].copy(), "feature_exp": int(exps[20]), "n_probe_streams": int(n.value),
+                "selftest_embedding_err": float(st[0]), "selftest_embedding_max": float(st[1]), "selftest_score_err": float(st[2])}
 
     def self_test(self, n_frames: int = 24, pcm: Optional[np.ndarray] = None, tol: float = 1e-3) -> Dict[str, float]:
         """Deploy-time check of the default f16-split kernels against the exact-fp32 family on THIS engine's weights.

@@ -488,7 +488,7 @@ class BatchedModel:
 
     def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict, None] = None,
                  device: int = 0, max_chunks: int = 1, hip_stream: int = 0, vad_weights: Optional[dict] = None,
-                 vad_threshold: float = 0.0, use_mfma: Optional[int] = None):
+                 vad_threshold: float = 0.0, use_mfma: Optional[int] = None, calibration_pcm="default"):
         # same weight resolution as Model: real .onnx files (heads AND the shared embedding network) unless synthetic
         # weights are asked for explicitly -- never a random-init embedding under real heads
         seed, emb, given = resolve_weights(weights)
@@ -513,8 +513,10 @@ class BatchedModel:
                 except Exception as e:               # refused by name (ValueError) or unreadable in a way the reader did not foresee
                     import warnings
                     warnings.warn(f"{e} -- the VAD gate of this BatchedModel waits for push_vad() scores", RuntimeWarning)
+        # calibration_pcm: audio of the deployment's domain for the commit-time calibration / self-test of the fp16-split kernels
+        # (StreamEngine); "default" = speech shipped with the package
         self.engine = make_engine(n_streams, heads, emb, use_mfma, device=device, max_chunks=max_chunks, hip_stream=hip_stream,
-                                  vad=vad_weights, vad_threshold=vad_threshold)
+                                  vad=vad_weights, vad_threshold=vad_threshold, calibration_pcm=calibration_pcm)
         self.labels: List[str] = []
         self._keep: List[int] = []
         col = 0

@@ -52,7 +52,27 @@ def _regime(name):
             sgn = np.where(np.arange(g.size) % 3 == 0, -1.0, 1.0).astype(np.float32)
             emb["bn"][l] = (g * sgn, b, m, v)
         return emb, 1234
+    if name in ("tiny_embedding", "huge_embedding"):
+        # embeddings of order 1e-4 (1e+5): the last convolution 1e-4 x (1e+4 x) and the heads' first layer the inverse.  Round 3 fed
+        # the heads' f16-split GEMM features in true units -- tiny ones lost their low halves, and only the commit-time comparison
+        # stood between that and a wrong score; since round 4 the features enter the GEMM at a calibrated power-of-two scale and
+        # every weight matrix has its own (HeadHxParams::fscale, HeadHxNet::u1 / u2), so both regimes must simply PASS.
+        emb = copy.deepcopy(base)
+        f = 1e-4 if name == "tiny_embedding" else 1e4
+        emb["conv"][19] = (emb["conv"][19] * f).astype(np.float32)
+        return emb, 1234
     raise KeyError(name)
+
+
+def _heads_for(name, hseed):
+    heads = {n: W.synthetic_head(n, hseed) for n in HEADS}
+    if name in ("tiny_embedding", "huge_embedding"):
+        f = 1e4 if name == "tiny_embedding" else 1e-4
+        for h in heads.values():
+            for net in ("net", "net2"):
+                if net in h:
+                    h[net]["w1"] = (h[net]["w1"] * f).astype(np.float32)
+    return heads
 
 
 def _pcm():
@@ -63,10 +83,10 @@ def _pcm():
     return np.clip(np.round(np.stack(rows)), -32768, 32767).astype(np.int16)
 
 
-@pytest.mark.parametrize("name", ["seed1", "seed2", "seed3", "hot", "cold", "conv_1e-3", "negative_bn"])
+@pytest.mark.parametrize("name", ["seed1", "seed2", "seed3", "hot", "cold", "conv_1e-3", "negative_bn", "tiny_embedding", "huge_embedding"])
 def test_default_family_matches_float64_oracle_or_refuses(name):
     emb, hseed = _regime(name)
-    heads = {n: W.synthetic_head(n, hseed) for n in HEADS}
+    heads = _heads_for(name, hseed)
     pcm = _pcm()
     noise = W.synthetic_pcm(1, 64000, seed=3, rms=600.0)[0]
     proto = O.OracleModel(heads, emb, dtype=np.float64, init_noise=noise)
@@ -97,6 +117,9 @@ def test_default_family_matches_float64_oracle_or_refuses(name):
             scale_e = max(scale_e, float(np.abs(w).max()))
         assert eng.range_status() is False
         print(f"\n{name}: refused={refused} max|score - oracle64| = {worst_s:.2e}, max|emb - oracle64| = {worst_e:.2e} on |emb| <= {scale_e:.3g}")
+        if name in ("tiny_embedding", "huge_embedding"):
+            assert not refused, "the heads' calibrated scales must carry these embeddings, not refuse them"
+            assert (scale_e < 5e-3) if name == "tiny_embedding" else (scale_e > 1e4)
         assert worst_s <= TOL_SCORE
         assert worst_e <= TOL_EMB * max(1.0, scale_e)
     finally:
@@ -104,19 +127,55 @@ def test_default_family_matches_float64_oracle_or_refuses(name):
 
 
 def test_commit_refuses_what_the_split_cannot_carry():
-    """Head weights whose 2^8-scaled f16 halves overflow are refused by value; an embedding network whose folded weights leave the
-    f16 range (a BatchNorm scale of 1e9 on one layer with nothing downstream to absorb it) is refused by the range check of the
-    fold or by the commit-time comparison with the exact-fp32 run -- in every case with OwwRangeError / OwwError at creation."""
+    """What stays refused: a layer scales all its channels by ONE power of two, so an embedding network with a BatchNorm scale of 1e9
+    on a single channel (its neighbours at 1) has folded weights 2^30 apart inside one layer -- outside what f16 halves can hold -- and
+    is refused by the range check of the fold or by the commit-time comparison with the exact-fp32 run, with OwwRangeError / OwwError
+    at creation; non-finite head weights are refused by value.  (A network whose embeddings are uniformly huge is NOT refused any
+    more: see the huge_embedding regime.)"""
     from openwakeword_amd._lib import OwwError
     emb = W.synthetic_embedding(1234)
     heads = {"alexa": W.synthetic_head("alexa", 1234)}
     bad = copy.deepcopy(emb)
     g, b, m, v = bad["bn"][18]
-    bad["bn"][18] = ((g * 1e9).astype(np.float32), b, m, v)              # embeddings of order 1e9 reach the heads
+    g = g.copy(); g[0] *= 1e9
+    bad["bn"][18] = (g.astype(np.float32), b, m, v)
     with pytest.raises(OwwError):
         StreamEngine(4, heads, bad)
+    nan_head = copy.deepcopy(heads)
+    nan_head["alexa"]["net"]["w1"][3, 5] = np.inf
+    with pytest.raises(OwwError, match="not finite"):
+        StreamEngine(4, nan_head, emb)
     eng = StreamEngine(4, heads, bad, use_mfma=1)                       # exact fp32 takes them
     try:
         assert np.isfinite(eng.step(W.synthetic_pcm(4, 1280, seed=1))).all()
     finally:
         eng.close()
+
+
+def test_commit_calibrates_and_self_tests_on_speech():
+    """oww_commit's probe set = 32 synthetic streams + the package's speech (the reference's three fixture clips at several gains,
+    oww_set_calibration); the ladder's maxima come from the union, the f16-split replay of ALL probes agrees with the exact-fp32 run,
+    a caller can pass audio of its own domain, and creating a handle stays well under half a second."""
+    import time
+    from openwakeword_amd import engine as E
+    emb = W.synthetic_embedding(1234)
+    heads = {n: W.synthetic_head(n, 1234) for n in HEADS}
+    speech = E.default_calibration_pcm()
+    assert speech is not None and speech.shape == (12, 16 * 1280) and speech.dtype == np.int16
+    StreamEngine(4, heads, emb).close()                                   # (first creation pays the library load)
+    t0 = time.perf_counter()
+    eng = StreamEngine(4, heads, emb)
+    dt = time.perf_counter() - t0
+    syn = StreamEngine(4, heads, emb, calibration_pcm=None)
+    own = StreamEngine(4, heads, emb, calibration_pcm=np.concatenate([speech, speech[:, ::-1]], axis=1)[:7])    # 7 streams x 32 frames
+    try:
+        a, b, c = eng.calibration_info(), syn.calibration_info(), own.calibration_info()
+        assert (a["n_probe_streams"], b["n_probe_streams"], c["n_probe_streams"]) == (32 + 12, 32, 32 + 14)
+        assert (a["absmax"] >= b["absmax"]).all() and np.isfinite(a["absmax"]).all()      # a superset of the probes
+        assert a["selftest_score_err"] < 1e-4 and a["selftest_embedding_err"] < 2e-4 * max(1.0, a["selftest_embedding_max"])
+        assert 2.0 ** 9 <= a["absmax"][19] * 2.0 ** a["feature_exp"] < 2.0 ** 10          # the heads see the largest probe embedding there
+        print(f"\ncommit with speech calibration: {dt * 1e3:.0f} ms; layers whose maximum comes from speech: "
+              f"{np.nonzero(a['absmax'] > b['absmax'])[0].tolist()}; self-test {a['selftest_embedding_err']:.2e} / {a['selftest_score_err']:.2e}")
+        assert dt < 0.5
+    finally:
+        eng.close(); syn.close(); own.close()
