@@ -1141,6 +1141,7 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
         for (int bt = 0; bt < cal.nb * CAL_T && !rc; ++bt) {
             const int it = bt % CAL_T;
             if (it == 0 && bt > 0 && (rc = do_reset(t, nullptr, CAL_NP, nullptr))) break;
+            if (getenv("OWW_DEBUG_CALIB")) { const hipError_t e = hipStreamSynchronize(t->stream); fprintf(stderr, "calibrate: probe step %d of %d (%s)\n", bt, cal.nb * CAL_T, hipGetErrorString(e)); }
             // (the upload waits for the previous step: one staging buffer, stream-ordered copies from pageable memory are synchronous)
             if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
             if ((rc = probe_step(t, d_chunk, true))) break;
@@ -1174,7 +1175,15 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
             }
         }
         h->hx_ein[19] = cl(3 - ex(18));
-        h->hx_e[19] = h->hx_ein[19] + 2;                        // conv19: no activation, its output is un-scaled when the embedding is stored
+        // conv19: no BatchNorm, no activation, and its accumulator is un-scaled in fp32 when the embedding is stored -- nothing pins its
+        // output range, so the exponent step is chosen for the WEIGHTS: the largest |w| 2^step at 2^11..2^12 (a network whose last
+        // layer is 1e-4 x weaker keeps 22 bits per weight: tests/test_weight_regimes.py, tiny_embedding)
+        {
+            const float* q = h->emb_blob.data();
+            for (int l = 0; l < 19; ++l) q += (size_t)kLayers[l].kh * kLayers[l].kw * kLayers[l].cin * kLayers[l].cout + 2 * kLayers[l].cout;
+            const int step = hx_weight_exp(q, (size_t)kLayers[19].kh * kLayers[19].kw * kLayers[19].cin * kLayers[19].cout);
+            h->hx_e[19] = cl(h->hx_ein[19] + (step == -1000 ? 2 : step));
+        }
         h->hx_efeat = cl(10 - ex(19));                          // the heads' GEMM takes the (true-unit) feature ring at this scale
         for (int st = 0; st < 5; ++st) {
             const int last = st == 0 ? 2 : first[st] + 3, nxt = last + 1;
@@ -1200,6 +1209,7 @@ int selftest_hx(oww_ctx* h, const HxCalib& cal) {
     float* saved_dbg = h->d_dbg; h->d_dbg = nullptr;
     for (int bt = 0; bt < cal.nb * CAL_T && !rc; ++bt) {
         if (bt % CAL_T == 0 && bt > 0 && (rc = do_reset(h, nullptr, CAL_NP, nullptr))) break;
+        if (getenv("OWW_DEBUG_CALIB")) { const hipError_t e = hipStreamSynchronize(h->stream); fprintf(stderr, "self-test: probe step %d of %d (%s)\n", bt, cal.nb * CAL_T, hipGetErrorString(e)); }
         if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
         if ((rc = probe_step(h, d_chunk, true))) break;
         if (hipMemcpyAsync(&emb[(size_t)bt * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||

@@ -127,29 +127,43 @@ def test_default_family_matches_float64_oracle_or_refuses(name):
 
 
 def test_commit_refuses_what_the_split_cannot_carry():
-    """What stays refused: a layer scales all its channels by ONE power of two, so an embedding network with a BatchNorm scale of 1e9
-    on a single channel (its neighbours at 1) has folded weights 2^30 apart inside one layer -- outside what f16 halves can hold -- and
-    is refused by the range check of the fold or by the commit-time comparison with the exact-fp32 run, with OwwRangeError / OwwError
-    at creation; non-finite head weights are refused by value.  (A network whose embeddings are uniformly huge is NOT refused any
-    more: see the huge_embedding regime.)"""
+    """What oww_commit still refuses, and what it no longer has to.  Non-finite weights are refused by value (heads) or by the
+    calibration run (embedding network: "non-finite activations in exact fp32").  A BatchNorm scale of 1e9 on ONE channel of a late
+    layer -- its neighbours at 1 -- used to be the example of a network the f16 halves cannot hold; with every layer, conv19 and the
+    heads on calibrated scales it must now either be refused or agree with the exact-fp32 family of the same weights (it agrees: the
+    other channels vanish below that layer's fp32 round-off as well).  A network whose embeddings are uniformly huge is not refused
+    any more either: see the huge_embedding regime."""
     from openwakeword_amd._lib import OwwError
     emb = W.synthetic_embedding(1234)
     heads = {"alexa": W.synthetic_head("alexa", 1234)}
-    bad = copy.deepcopy(emb)
-    g, b, m, v = bad["bn"][18]
-    g = g.copy(); g[0] *= 1e9
-    bad["bn"][18] = (g.astype(np.float32), b, m, v)
-    with pytest.raises(OwwError):
-        StreamEngine(4, heads, bad)
     nan_head = copy.deepcopy(heads)
     nan_head["alexa"]["net"]["w1"][3, 5] = np.inf
     with pytest.raises(OwwError, match="not finite"):
         StreamEngine(4, nan_head, emb)
-    eng = StreamEngine(4, heads, bad, use_mfma=1)                       # exact fp32 takes them
+    broken = copy.deepcopy(emb)
+    broken["conv"][7][0, 1, 2, 3] = np.nan
+    with pytest.raises(OwwError, match="non-finite"):
+        StreamEngine(4, heads, broken)
+    hot1 = copy.deepcopy(emb)
+    g, b, m, v = hot1["bn"][18]
+    g = g.copy(); g[0] *= 1e9
+    hot1["bn"][18] = (g.astype(np.float32), b, m, v)
+    pcm = W.synthetic_pcm(4, 1280 * 8, seed=1)
+    exact = StreamEngine(4, heads, hot1, use_mfma=1)
     try:
-        assert np.isfinite(eng.step(W.synthetic_pcm(4, 1280, seed=1))).all()
+        want = np.stack([exact.step_raw(pcm[:, 1280 * t:1280 * (t + 1)]) for t in range(8)])
     finally:
-        eng.close()
+        exact.close()
+    try:
+        eng = StreamEngine(4, heads, hot1)
+    except OwwError as e:
+        assert "use_mfma = 1" in str(e)
+    else:
+        try:
+            got = np.stack([eng.step_raw(pcm[:, 1280 * t:1280 * (t + 1)]) for t in range(8)])
+            assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-3 and eng.range_status() is False
+        finally:
+            eng.close()
 
 
 def test_commit_calibrates_and_self_tests_on_speech():
