@@ -685,12 +685,19 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 }
                 q.fscale = std::ldexp(1.0f, h->hx_efeat);
                 const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
-                const int lds = owh::HX_NBUF * g.n_nets * 8 * 1024;
-                switch (g.n_nets) {
-                    case 1: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;
-                    case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<2>, grid, block, lds, st, q); break;
-                    case 3: hipLaunchKernelGGL(owh::heads_hx_kernel<3>, grid, block, lds, st, q); break;
-                    default: hipLaunchKernelGGL(owh::heads_hx_kernel<4>, grid, block, lds, st, q); break;
+                // a launch that leaves workgroups alone on their CUs runs the deep weight ring (owwhip_hx.h: HX_NBUF_DEEP); same results
+                const bool deep = (int)grid.x <= 2 * 256;                     // (MI355X: 256 CUs)
+                const int lds = (deep ? owh::HX_NBUF_DEEP : owh::HX_NBUF) * g.n_nets * 8 * 1024;
+                constexpr int DP = owh::HX_NBUF_DEEP;
+                switch (g.n_nets * 2 + (deep ? 1 : 0)) {
+                    case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;
+                    case 3: hipLaunchKernelGGL((owh::heads_hx_kernel<1, DP>), grid, block, lds, st, q); break;
+                    case 4: hipLaunchKernelGGL(owh::heads_hx_kernel<2>, grid, block, lds, st, q); break;
+                    case 5: hipLaunchKernelGGL((owh::heads_hx_kernel<2, DP>), grid, block, lds, st, q); break;
+                    case 6: hipLaunchKernelGGL(owh::heads_hx_kernel<3>, grid, block, lds, st, q); break;
+                    case 7: hipLaunchKernelGGL((owh::heads_hx_kernel<3, DP>), grid, block, lds, st, q); break;
+                    case 8: hipLaunchKernelGGL(owh::heads_hx_kernel<4>, grid, block, lds, st, q); break;
+                    default: hipLaunchKernelGGL((owh::heads_hx_kernel<4, DP>), grid, block, lds, st, q); break;
                 }
                 continue;
             }
@@ -1316,6 +1323,9 @@ int oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes) {
         if (l < 19) want += 2 * (size_t)kLayers[l].cout;
     }
     if (nbytes != want * 4) return fail(OWW_EINVAL, "oww_load_embedding: blob is %zu bytes, expected %zu", nbytes, want * 4);
+    // (a NaN weight would not fail later: the max()-based activation swallows it, in every kernel family)
+    for (size_t i = 0; i < want; ++i)
+        if (!std::isfinite(((const float*)blob)[i])) return fail(OWW_EINVAL, "oww_load_embedding: weights are not finite (float %zu of the blob)", i);
     h->emb_blob.assign((const float*)blob, (const float*)blob + want);
     return OWW_OK;
     OWW_GUARD_END
@@ -1337,6 +1347,8 @@ int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
     if (nbytes != 32 + per_net * n_nets * 4)
         return fail(OWW_EINVAL, "oww_add_head: blob is %zu bytes, expected %zu", nbytes, 32 + per_net * n_nets * 4);
     hh.blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
+    for (size_t i = 0; i < hh.blob.size(); ++i)
+        if (!std::isfinite(hh.blob[i])) return fail(OWW_EINVAL, "oww_add_head: head weights are not finite (float %zu of the blob)", i);
     h->heads.push_back(std::move(hh));
     return (int)h->heads.size() - 1;
     OWW_GUARD_END
@@ -1726,6 +1738,10 @@ int oww_commit(oww_ctx* h) {
     if (int rc = set_lds(owh::heads_hx_kernel<2>, owh::HX_NBUF * 2 * 8 * 1024)) return rc;
     if (int rc = set_lds(owh::heads_hx_kernel<3>, owh::HX_NBUF * 3 * 8 * 1024)) return rc;
     if (int rc = set_lds(owh::heads_hx_kernel<4>, owh::HX_NBUF * 4 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<1, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 1 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<2, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 2 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<3, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 3 * 8 * 1024)) return rc;
+    if (int rc = set_lds(owh::heads_hx_kernel<4, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 4 * 8 * 1024)) return rc;
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stageA_kernel<false>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stage_kernel<CfgB, true, false>, CfgB::LDS_BYTES)) return rc;

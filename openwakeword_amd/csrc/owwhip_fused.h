@@ -152,12 +152,8 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         const int16_t* tail_row = q.tail + (size_t)s * 480;
         const int16_t* pcm_row = q.pcm + (size_t)s * 1280;
         fetch_pass(tail_row, pcm_row, 0, lane, raw);
-#ifdef OWF_EXP_NOMEL              // (timing experiment only: one FFT pass instead of four -> what the mel phase costs)
-        for (int f2 = 0; f2 < 1; ++f2) {
-#else
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
-#endif
             wave_sync();                         // the previous pass's readers of the planes / power rows are done (same wave)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

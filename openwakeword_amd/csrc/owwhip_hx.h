@@ -207,12 +207,8 @@ __device__ __forceinline__ void load_tile_h(f32x4 (&t)[NCT], const float* __rest
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-#ifdef OWR_EXP_NOLOAD
-            t[ct][e] = (float)(lane + ct * 4 + e) * 1e-3f;
-#else
             if (HALF && ct == NCT - 1 && e >= 2) t[ct][e] = 0.f;
             else t[ct][e] = base[(ct * 4 + e) * 64 + lane];
-#endif
         }
 }
 template <int NCT, bool HALF>
@@ -222,11 +218,7 @@ __device__ __forceinline__ void store_tile_h(const f32x4 (&t)[NCT], float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (HALF && ct == NCT - 1 && e >= 2) continue;
-#ifdef OWR_EXP_NOSTORE
-            if (t[ct][e] == 12345.678f) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
-#else
             base[(ct * 4 + e) * 64 + lane] = t[ct][e];
-#endif
         }
 }
 
@@ -388,12 +380,10 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                 }
             }
         }
-#ifndef OWH_EXP_NOGUARD_MEL
         if (oct == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) nan_guard(bad, res[t][0]);
         }
-#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
@@ -567,11 +557,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
                 }
         }
         if (oct > 0) {                                       // epilogue of the previous tile
-#ifdef OWH_EXP_NOGUARD_TIME
-            if (false) {
-#else
             if (GUARD && oct == 1) {
-#endif
 #pragma unroll
                 for (int r = 0; r < NR; ++r) nan_guard(bad, prev[r][0]);
             }
@@ -1485,15 +1471,21 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
 constexpr int HX_WG = OWH_HEADS_WG, HX_NBUF = OWH_HEADS_NBUF;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NN>
+// NBUF = weight chunks in the LDS ring (NBUF - 1 in flight ahead of the one being consumed).  Large launches run several workgroups
+// per CU, which cover each other's DMA latency: the double buffer (HX_NBUF) is enough and a deeper ring only costs LDS (measured).
+// A SMALL launch (BASELINE configs[1]: 4,096 streams = 32 workgroups on 256 CUs) is one workgroup alone on its CU walking 48 k-steps
+// of 0.8 us of MFMA work each behind a 1.5-2 us L2 -> LDS round trip: HX_NBUF_DEEP chunks keep three in flight.  Same arithmetic
+// in the same order, so a stream's scores do not depend on which instantiation ran (batch invariance is tested bit for bit).
+constexpr int HX_NBUF_DEEP = 4;
+template <int NN, int NBUF = HX_NBUF>
 __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p) {
     using namespace owr;
     constexpr int NCT = NN * 4;                 // hidden tiles of 16
     constexpr int NBLK = NCT * 2;               // 1 KB blocks per k-step chunk
     constexpr int CHUNK = NBLK * 256;           // floats
     constexpr int LPT = (NBLK + HX_WG - 1) / HX_WG;       // DMA instructions per thread and chunk
-    constexpr int D = HX_NBUF - 1;              // chunks in flight ahead of the one being consumed
-    extern __shared__ __attribute__((aligned(16))) float hbuf[];      // HX_NBUF x CHUNK
+    constexpr int D = NBUF - 1;                 // chunks in flight ahead of the one being consumed
+    extern __shared__ __attribute__((aligned(16))) float hbuf[];      // NBUF x CHUNK
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KST = p.T * 3;
@@ -1535,10 +1527,10 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ks = 0; ks < KST; ++ks) {
-        const float* cur = hbuf + (ks % HX_NBUF) * CHUNK;
+        const float* cur = hbuf + (ks % NBUF) * CHUNK;
         if (ks + 1 < KST) load_raw(ks + 1, raw);                // older than the chunk issued next
         if (ks + D < KST)                                       // slot of chunk ks-1: every wave passed the last barrier
-            issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hbuf + ((ks + D) % HX_NBUF) * CHUNK, wave, lane);
+            issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hbuf + ((ks + D) % NBUF) * CHUNK, wave, lane);
 #pragma unroll
         for (int c2 = 0; c2 < NCT; c2 += 2) {
             const f16x8 ah0 = lds_h(cur, c2 * 2 + 0, lane), al0 = lds_h(cur, c2 * 2 + 1, lane);

@@ -668,11 +668,7 @@ constexpr int MEL_PBINS = 120;          // FFT bins 2..121 are the only ones the
 // wave through LDS needs no s_barrier -- only the outstanding LDS operations must have been issued/completed and the
 // compiler must not move accesses across this point
 __device__ __forceinline__ void wave_sync() {
-#ifdef OWF_EXP_NOSYNC          // (timing experiment only: results are wrong; what the wave-local LDS round trips of the FFT cost)
-    asm volatile("" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
 }
 
 // The 672(+8) samples wave `wave` needs for frames 2*wave, 2*wave+1 of group g of stream s, as raw int16 in registers

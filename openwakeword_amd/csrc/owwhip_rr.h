@@ -263,9 +263,6 @@ template <int NBLK, int WG_WAVES = owr::WG_WAVES>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
     const float* base = uniform_ptr(gsrc + wave * 256);
     const unsigned voff = lane * 4;
-#ifdef OWR_EXP_NODMA
-    return;
-#endif
 #pragma unroll
     for (int u = 0; u < (NBLK + WG_WAVES - 1) / WG_WAVES; ++u) {
         const int i = u * WG_WAVES + wave;
@@ -275,12 +272,8 @@ __device__ __forceinline__ void issue_chunk(const float* __restrict__ gsrc, floa
     }
 }
 __device__ __forceinline__ void chunk_sync() {
-#ifndef OWR_EXP_NOWAIT          // (timing experiments only: results are wrong without the wait / barrier)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifndef OWR_EXP_NOBARRIER
     __syncthreads();
-#endif
 }
 __device__ __forceinline__ f32x4 lds_w(const float* buf, int blk, int lane) {
     return *reinterpret_cast<const f32x4*>(buf + (blk * 64 + lane) * 4);
@@ -398,22 +391,14 @@ __device__ __forceinline__ void load_tile(f32x4 (&t)[NCT], const float* __restri
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-#ifdef OWR_EXP_NOLOAD            // (timing experiment: how much of a stage is exposed state / input load latency)
-        for (int e = 0; e < 4; ++e) t[ct][e] = (float)(lane + ct * 4 + e) * 1e-3f;
-#else
         for (int e = 0; e < 4; ++e) t[ct][e] = base[(ct * 4 + e) * 64 + lane];
-#endif
 }
 template <int NCT>
 __device__ __forceinline__ void store_tile(const f32x4 (&t)[NCT], float* __restrict__ base, int lane) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-#ifdef OWR_EXP_NOSTORE
-        for (int e = 0; e < 4; ++e) if (t[ct][e] == 12345.678f) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
-#else
         for (int e = 0; e < 4; ++e) base[(ct * 4 + e) * 64 + lane] = t[ct][e];
-#endif
 }
 
 // debug: dense [rows][F][C] dump of a tile row for the streams it holds (tests only)

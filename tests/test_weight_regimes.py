@@ -127,8 +127,8 @@ def test_default_family_matches_float64_oracle_or_refuses(name):
 
 
 def test_commit_refuses_what_the_split_cannot_carry():
-    """What oww_commit still refuses, and what it no longer has to.  Non-finite weights are refused by value (heads) or by the
-    calibration run (embedding network: "non-finite activations in exact fp32").  A BatchNorm scale of 1e9 on ONE channel of a late
+    """What is still refused, and what no longer has to be.  Non-finite weights are refused by value when they are loaded, in every
+    kernel family.  A BatchNorm scale of 1e9 on ONE channel of a late
     layer -- its neighbours at 1 -- used to be the example of a network the f16 halves cannot hold; with every layer, conv19 and the
     heads on calibrated scales it must now either be refused or agree with the exact-fp32 family of the same weights (it agrees: the
     other channels vanish below that layer's fp32 round-off as well).  A network whose embeddings are uniformly huge is not refused
@@ -141,9 +141,11 @@ def test_commit_refuses_what_the_split_cannot_carry():
     with pytest.raises(OwwError, match="not finite"):
         StreamEngine(4, nan_head, emb)
     broken = copy.deepcopy(emb)
-    broken["conv"][7][0, 1, 2, 3] = np.nan
-    with pytest.raises(OwwError, match="non-finite"):
+    broken["conv"][7][0, 1, 2, 3] = np.nan                  # (would hide behind the max()-based activation: refused when loaded)
+    with pytest.raises(OwwError, match="not finite"):
         StreamEngine(4, heads, broken)
+    with pytest.raises(OwwError, match="not finite"):
+        StreamEngine(4, heads, broken, use_mfma=1)
     hot1 = copy.deepcopy(emb)
     g, b, m, v = hot1["bn"][18]
     g = g.copy(); g[0] *= 1e9
