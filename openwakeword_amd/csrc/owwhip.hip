@@ -687,17 +687,19 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
                 // a launch that leaves workgroups alone on their CUs runs the deep weight ring (owwhip_hx.h: HX_NBUF_DEEP); same results
                 const bool deep = (int)grid.x <= 2 * 256;                     // (MI355X: 256 CUs)
-                const int lds = (deep ? owh::HX_NBUF_DEEP : owh::HX_NBUF) * g.n_nets * 8 * 1024;
-                constexpr int DP = owh::HX_NBUF_DEEP;
-                switch (g.n_nets * 2 + (deep ? 1 : 0)) {
+                const int nn = std::min(g.n_nets, 4);
+                const int nbuf = deep ? (nn <= 2 ? owh::HeadsDeep<1>::NBUF : owh::HeadsDeep<4>::NBUF) : owh::HX_NBUF;
+                (void)nbuf;
+                const int lds = 0;                                  // (the ring slots are static LDS objects: owwhip_hx.h hslot)
+                switch (nn * 2 + (deep ? 1 : 0)) {
                     case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;
-                    case 3: hipLaunchKernelGGL((owh::heads_hx_kernel<1, DP>), grid, block, lds, st, q); break;
+                    case 3: hipLaunchKernelGGL((owh::heads_hx_kernel<1, owh::HeadsDeep<1>::NBUF>), grid, block, lds, st, q); break;
                     case 4: hipLaunchKernelGGL(owh::heads_hx_kernel<2>, grid, block, lds, st, q); break;
-                    case 5: hipLaunchKernelGGL((owh::heads_hx_kernel<2, DP>), grid, block, lds, st, q); break;
+                    case 5: hipLaunchKernelGGL((owh::heads_hx_kernel<2, owh::HeadsDeep<2>::NBUF>), grid, block, lds, st, q); break;
                     case 6: hipLaunchKernelGGL(owh::heads_hx_kernel<3>, grid, block, lds, st, q); break;
-                    case 7: hipLaunchKernelGGL((owh::heads_hx_kernel<3, DP>), grid, block, lds, st, q); break;
+                    case 7: hipLaunchKernelGGL((owh::heads_hx_kernel<3, owh::HeadsDeep<3>::NBUF>), grid, block, lds, st, q); break;
                     case 8: hipLaunchKernelGGL(owh::heads_hx_kernel<4>, grid, block, lds, st, q); break;
-                    default: hipLaunchKernelGGL((owh::heads_hx_kernel<4, DP>), grid, block, lds, st, q); break;
+                    default: hipLaunchKernelGGL((owh::heads_hx_kernel<4, owh::HeadsDeep<4>::NBUF>), grid, block, lds, st, q); break;
                 }
                 continue;
             }
@@ -1734,14 +1736,6 @@ int oww_commit(oww_ctx* h) {
     h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
     if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(owf::hmelA_kernel<true>, owf::FA_LDS_BYTES)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<1>, owh::HX_NBUF * 1 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<2>, owh::HX_NBUF * 2 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<3>, owh::HX_NBUF * 3 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<4>, owh::HX_NBUF * 4 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<1, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 1 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<2, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 2 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<3, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 3 * 8 * 1024)) return rc;
-    if (int rc = set_lds(owh::heads_hx_kernel<4, owh::HX_NBUF_DEEP>, owh::HX_NBUF_DEEP * 4 * 8 * 1024)) return rc;
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stageA_kernel<false>, CfgA::LDS_BYTES)) return rc;
     if (int rc = set_lds(stage_kernel<CfgB, true, false>, CfgB::LDS_BYTES)) return rc;

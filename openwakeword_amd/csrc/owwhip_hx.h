@@ -17,6 +17,8 @@
 // f16 split of D registers 0..3 of channel tiles 2ks and 2ks+1 of the same lane: again no data movement between layers,
 // only the split (3 VALU ops per value) after the BatchNorm/activation epilogue.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "owwhip_rr.h"
 
 namespace owh {
@@ -315,7 +317,7 @@ template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ init, float cl, int wave, int lane,
-                                            lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
+                                            lanemask_t& bad, float* wbuf1) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
     // (interleaved order: the row shift by SH = 16 / F lanes zero-fills exactly the stream-edge lanes and the masks are not used)
@@ -325,8 +327,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
+        const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
+        float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
         if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
         f32x4 res[NT], accs[2][NT];
@@ -437,15 +439,15 @@ template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_
 __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], float* wbuf,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
-                                             lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
+                                             lanemask_t& bad, float* wbuf1) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int SH = 16 / F, KSF = KSI - 1;
     constexpr int NBLK = (3 * KSF + NMK) * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
+        const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
+        float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
         if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
         f32x4 res[NT], accs[2][NT];
@@ -521,7 +523,7 @@ template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = O
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
-                                             lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
+                                             lanemask_t& bad, float* wbuf1) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = 3 * KSI * 2;
@@ -530,8 +532,8 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
     for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
         if (oct < NCTO) {
-            const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
-            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
+            const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
+            float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
             if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
             else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);           // folded BatchNorm shift = the chain's start value
@@ -646,7 +648,7 @@ template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, i
 __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1)[KSF], const Op (&in)[NR][KSF], const Op (&M)[NR][NMK],
                                               f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
                                               const float* __restrict__ init, float cl, int wave, int lane,
-                                              lanemask_t& bad, int wbs = owr::WBUF_FLOATS) {
+                                              lanemask_t& bad, float* wbuf1) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = (3 * KSF + NMK) * 2;
@@ -655,8 +657,8 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
     for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
         if (oct < NCTO) {
-            const float* cur = wbuf + ((CH0 + oct) & 1) * wbs;
-            float* nxt = wbuf + ((CH0 + oct + 1) & 1) * wbs;
+            const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
+            float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
             if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
             else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);
@@ -782,7 +784,12 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
-    __shared__ __attribute__((aligned(16))) float wbuf[2 * WBS];
+    // the two halves of the weight double buffer are two DISTINCT LDS objects.  The compiler orders every LDS read behind pending
+    // LDS-DMA writes (global_load_lds) it cannot prove disjoint, with s_waitcnt vmcnt(0): with one array of two halves it stalled
+    // each wave on the chunk it had JUST issued (the prefetch of chunk i + 1) before reading chunk i -- no overlap of the weight
+    // stream with a wave's own MFMAs, in half of all chunk steps.  Distinct objects carry distinct alias scopes: no such wait.
+    __shared__ __attribute__((aligned(16))) float wbuf[WBS];
+    __shared__ __attribute__((aligned(16))) float wbuf1[WBS];
     __shared__ __attribute__((aligned(16))) float sbn[4][NCT * 16];      // per layer: K * BatchNorm shift in tile row order = accumulator start values
     __shared__ __attribute__((aligned(16))) float hlds[HLDS ? WG * 2 * HROW : 4];
     float* const hl = hlds + (HLDS ? wave * 2 * HROW : 0);
@@ -820,9 +827,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMA) {
         Op Mx[R][NMKA];
         merge_mel_rems<KSA, R, F, NPRA>(Xo, Mx);
-        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, WBS);
+        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, wbuf1);
     } else
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, WBS);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, wbuf1);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane, p.dbg_mul[0]);
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, WBS);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, wbuf1);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -866,7 +873,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, WBS);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, wbuf1);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -879,9 +886,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMC) {
         Op Mc[R][NMKC];
         merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
-        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, WBS);
+        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, wbuf1);
     } else
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, WBS);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, wbuf1);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
@@ -905,7 +912,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad, WBS);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad, wbuf1);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad, WBS);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad, wbuf1);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -986,7 +993,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         to_ops<NCT>(Pl, Po[0]);
         f32x4 E[1][NCT];
         // (no guard here: an out-of-range input of conv19 yields a NaN embedding, which the heads kernel's guard reports)
-        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, 0.f, wave, lane, bad, WBS);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, 0.f, wave, lane, bad, wbuf1);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
         const bool on19 = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (pos & 7), p.S - 1)] != 0);   // lanes 8..15 mirror 0..7
         if (on19) {
             store_tile<NCT>(T1, h19, lane);
@@ -1471,27 +1478,47 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
 constexpr int HX_WG = OWH_HEADS_WG, HX_NBUF = OWH_HEADS_NBUF;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// NBUF = weight chunks in the LDS ring (NBUF - 1 in flight ahead of the one being consumed).  Large launches run several workgroups
-// per CU, which cover each other's DMA latency: the double buffer (HX_NBUF) is enough and a deeper ring only costs LDS (measured).
-// A SMALL launch (BASELINE configs[1]: 4,096 streams = 32 workgroups on 256 CUs) is one workgroup alone on its CU walking 48 k-steps
-// of 0.8 us of MFMA work each behind a 1.5-2 us L2 -> LDS round trip: HX_NBUF_DEEP chunks keep three in flight.  Same arithmetic
-// in the same order, so a stream's scores do not depend on which instantiation ran (batch invariance is tested bit for bit).
-constexpr int HX_NBUF_DEEP = 4;
+// NBUF = slots of the weight ring in LDS (and of the feature ring in registers); D = NBUF - 1 k-steps are in flight ahead of the one
+// being consumed: the weight chunk of k-step i + D (L2 -> LDS, global_load_lds) and, issued right AFTER it, the feature rows of the
+// same k-step (HBM / L2 -> VGPRs).  VMEM reads return in order, so the wait the compiler places in front of the f16 split of k-step
+// i + 1's features also covers that k-step's weight chunk -- no counted s_waitcnt is needed, only the workgroup barrier that
+// publishes the other waves' chunk parts.
+// Every slot is its OWN LDS object (hslot<>): the compiler orders an LDS read behind every pending LDS-DMA write it cannot prove
+// disjoint (s_waitcnt vmcnt(0)); with one ring array that made each wave wait for the chunk it had just issued before it read the
+// current one -- the prefetch never overlapped the wave's own MFMAs.  The k loop is unrolled by NBUF so that slots are static.
+// Large launches run several workgroups per CU, which cover each other's latencies: two slots (HX_NBUF) are enough.  A SMALL launch
+// (BASELINE configs[1]: 4,096 streams = 32 workgroups on 256 CUs) is one workgroup alone on its CU walking 48 k-steps of ~0.35 us of
+// MFMA work each behind a 1.5-2 us memory round trip: the deep instantiation keeps 5 (two nets or fewer) or 3 k-steps in flight.
+// Same arithmetic in the same order, so a stream's scores do not depend on which instantiation ran (batch invariance is tested bit
+// for bit: test_large_batch_properties).
+template <int NN> struct HeadsDeep { static constexpr int NBUF = NN <= 2 ? 6 : 4; };
+template <int U, int N, class F>
+__device__ __forceinline__ void static_for_while(F&& f) {        // f(integral_constant<U>) for U = 0 .. N-1 while it returns true
+    if constexpr (U < N) {
+        if (f(std::integral_constant<int, U>{})) static_for_while<U + 1, N>(f);
+    }
+}
+template <int FLOATS, int I>
+__device__ __forceinline__ float* hslot() {
+    __shared__ __attribute__((aligned(16))) float slot[FLOATS];
+    return slot;
+}
+template <int FLOATS, int I>
+__device__ __forceinline__ float* hslot_at(int i) {         // slot i of 0..I (i is a compile-time value after unrolling)
+    if constexpr (I == 0) return hslot<FLOATS, 0>();
+    else return i == I ? hslot<FLOATS, I>() : hslot_at<FLOATS, I - 1>(i);
+}
 template <int NN, int NBUF = HX_NBUF>
-__global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p) {
+__global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(HeadHxParams p) {
     using namespace owr;
     constexpr int NCT = NN * 4;                 // hidden tiles of 16
     constexpr int NBLK = NCT * 2;               // 1 KB blocks per k-step chunk
     constexpr int CHUNK = NBLK * 256;           // floats
-    constexpr int LPT = (NBLK + HX_WG - 1) / HX_WG;       // DMA instructions per thread and chunk
     constexpr int D = NBUF - 1;                 // chunks in flight ahead of the one being consumed
-    extern __shared__ __attribute__((aligned(16))) float hbuf[];      // NBUF x CHUNK
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KST = p.T * 3;
-#pragma unroll
-    for (int c = 0; c < D; ++c)
-        if (c < KST) issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)c * CHUNK, hbuf + c * CHUNK, wave, lane);
+    issue_chunk<NBLK, HX_WG>(p.w1hx, hslot<CHUNK, 0>(), wave, lane);      // chunk 0 flies while the stream addresses are set up
 
     // this lane's streams (two tiles of 16) and the address of ring row t
     int s[2];
@@ -1504,33 +1531,45 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
         if (p.ext) { frow[t] = p.feat + (size_t)s[t] * p.T * 96; slot0[t] = 0; }
         else { frow[t] = p.feat + (size_t)s[t] * p.TR * 96; slot0[t] = p.nfeat[s[t]] + (uint32_t)(2 * p.TR - p.T + 1); }
     }
-    // features of k-step ks as loaded (two 16-byte pieces per tile); the f16 split happens one iteration later, so that
-    // waiting for them never waits for the weight chunk issued after them
+    // features of k-step ks as loaded (two 16-byte pieces per tile); the f16 split happens when the k-step is next in line
     auto load_raw = [&](int ks, f32x4 (&r)[2][2]) {
         const int tr = ks / 3, c0 = (ks % 3) * 32 + 8 * j;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const uint32_t slot = p.ext ? (uint32_t)tr : (slot0[t] + (uint32_t)tr) % (uint32_t)p.TR;
             const float* src = frow[t] + (size_t)slot * 96 + c0;
-            r[t][0] = *reinterpret_cast<const f32x4*>(src) * p.fscale;
-            r[t][1] = *reinterpret_cast<const f32x4*>(src + 4) * p.fscale;
+            r[t][0] = *reinterpret_cast<const f32x4*>(src);        // (scaled when they are split: nothing may wait for a load here)
+            r[t][1] = *reinterpret_cast<const f32x4*>(src + 4);
         }
     };
     f32x4 acc[NCT][2];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { acc[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     Op bcur[2];
-    f32x4 raw[2][2];
-    load_raw(0, raw);
-    bcur[0] = split_pair<false>(raw[0][0], raw[0][1]);
-    bcur[1] = split_pair<false>(raw[1][0], raw[1][1]);          // (vmcnt(0): also the first chunks have landed)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 raw[NBUF][2][2];                      // feature rows of the k-steps in flight (slot = k-step mod NBUF, static after unrolling)
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < KST) {
+            if (c > 0) issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)c * CHUNK, hslot_at<CHUNK, NBUF - 1>(c), wave, lane);     // (chunk 0: issued at kernel start)
+            asm volatile("" ::: "memory");      // program order = issue order: chunk c, then the features of k-step c
+            load_raw(c, raw[c]);
+        }
+    const float fsc = p.fscale;
+    bcur[0] = split_pair<false>(raw[0][0][0] * fsc, raw[0][0][1] * fsc);
+    bcur[1] = split_pair<false>(raw[0][1][0] * fsc, raw[0][1][1] * fsc);    // (waiting for these features = chunk 0 has landed: in-order return)
+    pin_op(bcur[0]); pin_op(bcur[1]);
     __syncthreads();
-    for (int ks = 0; ks < KST; ++ks) {
-        const float* cur = hbuf + (ks % NBUF) * CHUNK;
-        if (ks + 1 < KST) load_raw(ks + 1, raw);                // older than the chunk issued next
-        if (ks + D < KST)                                       // slot of chunk ks-1: every wave passed the last barrier
-            issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hbuf + ((ks + D) % NBUF) * CHUNK, wave, lane);
+    // one k-step: ring slot u (static), prefetch of k-step ks + D into slot (u + D) % NBUF, MFMAs, hand-over to k-step ks + 1
+    auto kstep = [&](int ks, auto uc, auto always) {
+        constexpr int u = decltype(uc)::value;
+        constexpr bool ALWAYS = decltype(always)::value;        // main loop: every k-step of the group prefetches and has a successor
+        const float* cur = hslot_at<CHUNK, NBUF - 1>(u);
+        if (ALWAYS || ks + D < KST) {                           // slot of k-step ks-1: every wave passed the last barrier, its features are split
+            constexpr int un = (u + D) % NBUF;
+            issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hslot_at<CHUNK, NBUF - 1>(un), wave, lane);
+            asm volatile("" ::: "memory");
+            load_raw(ks + D, raw[un]);
+        }
 #pragma unroll
         for (int c2 = 0; c2 < NCT; c2 += 2) {
             const f16x8 ah0 = lds_h(cur, c2 * 2 + 0, lane), al0 = lds_h(cur, c2 * 2 + 1, lane);
@@ -1544,15 +1583,33 @@ __global__ __launch_bounds__(64 * HX_WG, 2) void heads_hx_kernel(HeadHxParams p)
                 }
             }
         }
-        if (ks + 1 < KST) {
-            bcur[0] = split_pair<false>(raw[0][0], raw[0][1]);
-            bcur[1] = split_pair<false>(raw[1][0], raw[1][1]);
-            // chunk ks+1 must have landed; the chunks ks+2 .. ks+D issued after it may stay in flight
-            if (ks + D < KST) wait_vmcnt<(D - 1) * LPT>();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        if (ALWAYS || ks + 1 < KST) {
+            // k-step ks+1: its features are younger than its weight chunk, so the split's wait covers this wave's part of the chunk;
+            // the barrier covers the other waves' parts.  Everything issued for k-steps ks+2 .. ks+D stays in flight.
+            constexpr int u1 = (u + 1) % NBUF;
+            bcur[0] = split_pair<false>(raw[u1][0][0] * fsc, raw[u1][0][1] * fsc);
+            bcur[1] = split_pair<false>(raw[u1][1][0] * fsc, raw[u1][1][1] * fsc);
+            pin_op(bcur[0]); pin_op(bcur[1]);                   // (the split -- and with it the wait -- stays in front of the barrier)
+            // a bare s_barrier: __syncthreads() carries a workgroup-scope release fence, which on this target is s_waitcnt vmcnt(0) --
+            // it would drain every prefetch in flight at every k-step.  What the barrier has to order is already ordered: this wave's
+            // part of chunk ks+1 has landed (the wait above), its LDS reads of chunk ks have returned (they fed the MFMAs above), and
+            // the memory clobber keeps the compiler from moving LDS accesses across it.
+            asm volatile("s_barrier" ::: "memory");
         }
-    }
+    };
+    auto group = [&](int ks0, auto always) {                    // NBUF consecutive k-steps, slots 0 .. NBUF-1
+        constexpr bool ALWAYS = decltype(always)::value;
+        static_for_while<0, NBUF>([&](auto uc) {
+            constexpr int U = decltype(uc)::value;
+            if (!ALWAYS && ks0 + U >= KST) return false;
+            kstep(ks0 + U, uc, always);
+            return true;
+        });
+    };
+    int ks0 = 0;
+    // main loop: straight-line groups (no conditional issue: the compiler's wait counts stay exact, nothing waits for the newest prefetch)
+    for (; ks0 + NBUF - 1 + D < KST; ks0 += NBUF) group(ks0, std::true_type{});
+    for (; ks0 < KST; ks0 += NBUF) group(ks0, std::false_type{});        // the last D .. NBUF + D - 1 k-steps
     lanemask_t bad = 0;
     nan_guard(bad, acc[0][0][0]);               // a feature beyond the f16 range
     nan_guard(bad, acc[0][1][0]);
