@@ -1587,6 +1587,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
             // k-step ks+1: its features are younger than its weight chunk, so the split's wait covers this wave's part of the chunk;
             // the barrier covers the other waves' parts.  Everything issued for k-steps ks+2 .. ks+D stays in flight.
             constexpr int u1 = (u + 1) % NBUF;
+            __builtin_amdgcn_sched_barrier(0);                  // the split (and the wait for its features) stays BEHIND this k-step's MFMAs
             bcur[0] = split_pair<false>(raw[u1][0][0] * fsc, raw[u1][0][1] * fsc);
             bcur[1] = split_pair<false>(raw[u1][1][0] * fsc, raw[u1][1][1] * fsc);
             pin_op(bcur[0]); pin_op(bcur[1]);                   // (the split -- and with it the wait -- stays in front of the barrier)

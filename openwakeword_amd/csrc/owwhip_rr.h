@@ -284,13 +284,13 @@ __device__ __forceinline__ f32x4 lds_w(const float* buf, int blk, int lane) {
 template <int NCTI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, bool HIN = false, bool HOUT = false>
 __device__ __forceinline__ void conv_mel_lds(const f32x4 (&in)[NT][NCTI], f32x4 (&out)[NT][NCTO], float* wbuf,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
-                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane) {
+                                             const float* __restrict__ scale, const float* __restrict__ shift, int wave, int lane, float* wbuf1) {
     const int pos = lane & 15, j = lane >> 4;
     const bool first = (pos & (F - 1)) == 0, last = (pos & (F - 1)) == F - 1;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
+        float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
         if (oct + 1 < NCTO) issue_chunk<3 * NCTI>(w + (size_t)(oct + 1) * 3 * NCTI * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
         // out[p] = tap0[p-1] + tap1[p] + tap2[p+1] (zero beyond a stream's F positions).  Tap order 0, 2, 1: the two taps
@@ -345,12 +345,12 @@ template <int NCTI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, bool HIN 
 __device__ __forceinline__ void conv_time_lds(const f32x4 (&h0)[NCTI], const f32x4 (&h1)[NCTI], const f32x4 (&in)[NR][NCTI],
                                               f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w,
                                               const float* __restrict__ w_next, const float* __restrict__ scale,
-                                              const float* __restrict__ shift, int wave, int lane) {
+                                              const float* __restrict__ shift, int wave, int lane, float* wbuf1) {
     const int j = lane >> 4;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = wbuf + ((CH0 + oct) & 1) * WBUF_FLOATS;
-        float* nxt = wbuf + ((CH0 + oct + 1) & 1) * WBUF_FLOATS;
+        const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
+        float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
         if (oct + 1 < NCTO) issue_chunk<3 * NCTI>(w + (size_t)(oct + 1) * 3 * NCTI * 256, nxt, wave, lane);
         else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK>(w_next, nxt, wave, lane);
         f32x4 acc[NR];
@@ -521,7 +521,10 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: addresses built from it stay in SGPRs
     int g = blockIdx.x * C::WAVES + wave;
-    __shared__ __attribute__((aligned(16))) float wbuf[2 * WBUF_FLOATS];
+    // (two distinct LDS objects, not one array of two halves: see owh::hstage_kernel -- the compiler otherwise waits for the chunk a
+    //  wave has just issued before it lets the wave read the current one)
+    __shared__ __attribute__((aligned(16))) float wbuf[WBUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float wbuf1[WBUF_FLOATS];
     // folded BatchNorm of the four layers in LDS: global loads of them would be hoisted over the chunk barriers into
     // ~50 live registers; LDS reads stay inside their chunk
     __shared__ __attribute__((aligned(16))) float sbn[4][2][NCT * 16];
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
 
     // conv a: 1x3, CIN -> C
     f32x4 Ya[RP][NCT];
-    conv_mel_lds<NCTI, NCT, RP, F, true, 0, NB, C::HIN, C::HOUT>(X, Ya, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane);
+    conv_mel_lds<NCTI, NCT, RP, F, true, 0, NB, C::HIN, C::HOUT>(X, Ya, wbuf, p.w[0], p.w[1], sbn[0][0], sbn[0][1], wave, lane, wbuf1);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C, C::HOUT>(Ya[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * RP + r, p.S, lane);
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     load_tile<NCT>(H0, hb, lane);
     load_tile<NCT>(H1, hb + NCT * 4 * 64, lane);
     f32x4 Yb[RP][NCT];
-    conv_time_lds<NCT, NCT, RP, true, NCT, NB, C::HOUT, C::HOUT>(H0, H1, Ya, Yb, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane);
+    conv_time_lds<NCT, NCT, RP, true, NCT, NB, C::HOUT, C::HOUT>(H0, H1, Ya, Yb, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane, wbuf1);
     if (active) {
         store_tile<NCT>(Ya[RP - 2], hb, lane);
         store_tile<NCT>(Ya[RP - 1], hb + NCT * 4 * 64, lane);
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     OWR_SB();
     // conv c: 1x3
     f32x4 Yc[RP][NCT];
-    conv_mel_lds<NCT, NCT, RP, F, true, 2 * NCT, NB, C::HOUT, C::HOUT>(Yb, Yc, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane);
+    conv_mel_lds<NCT, NCT, RP, F, true, 2 * NCT, NB, C::HOUT, C::HOUT>(Yb, Yc, wbuf, p.w[2], p.w[3], sbn[2][0], sbn[2][1], wave, lane, wbuf1);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < RP; ++r) dump_tile<NCT, F, C::C, C::HOUT>(Yc[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * RP + r, p.S, lane);
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     // conv d: 3x1 over [hist_d(2) ; Yc]
     load_tile<NCT>(H0, hd, lane);
     load_tile<NCT>(H1, hd + NCT * 4 * 64, lane);
-    conv_time_lds<NCT, NCT, RP, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), C::HOUT, C::HOUT>(H0, H1, Yc, Yd, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], wave, lane);
+    conv_time_lds<NCT, NCT, RP, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), C::HOUT, C::HOUT>(H0, H1, Yc, Yd, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], wave, lane, wbuf1);
     if (active) {
         store_tile<NCT>(Yc[RP - 2], hd, lane);
         store_tile<NCT>(Yc[RP - 1], hd + NCT * 4 * 64, lane);
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         load_tile<NCT>(H0, h19, lane);
         load_tile<NCT>(H1, h19 + NCT * 4 * 64, lane);
         f32x4 E[1][NCT];
-        conv_time_lds<NCT, NCT, 1, false, 4 * NCT, 0>(H0, H1, Pl, E, wbuf, p.w19, nullptr, nullptr, nullptr, wave, lane);
+        conv_time_lds<NCT, NCT, 1, false, 4 * NCT, 0>(H0, H1, Pl, E, wbuf, p.w19, nullptr, nullptr, nullptr, wave, lane, wbuf1);
         if (active) {
             store_tile<NCT>(H1, h19, lane);
             store_tile<NCT>(Pl[0], h19 + NCT * 4 * 64, lane);

@@ -304,7 +304,8 @@ __device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builti
 
 __global__ __launch_bounds__(64 * L_WG, 2) void vad_lstm_kernel(VadLstmParams p) {
     using namespace owr;
-    __shared__ __attribute__((aligned(16))) float wbuf[2 * L_CHUNK];
+    __shared__ __attribute__((aligned(16))) float wbuf[L_CHUNK];          // (two distinct LDS objects: see owh::hstage_kernel)
+    __shared__ __attribute__((aligned(16))) float wbuf1[L_CHUNK];
     __shared__ __attribute__((aligned(16))) float sb[2 * 256];
     __shared__ __attribute__((aligned(16))) float swd[64];
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(64 * L_WG, 2) void vad_lstm_kernel(VadLstmParams p)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int cc = (l * 4 + u) * 2 + hh;                    // chunk number inside this time step (16 per step)
-                    const float* cur = wbuf + (cc & 1) * L_CHUNK;
-                    float* nxt = wbuf + ((cc + 1) & 1) * L_CHUNK;
+                    const float* cur = (cc & 1) ? wbuf1 : wbuf;
+                    float* nxt = ((cc + 1) & 1) ? wbuf1 : wbuf;
                     issue_chunk<L_CHUNK_BLOCKS, L_WG>(p.w + (size_t)((cc + 1) & 15) * L_CHUNK, nxt, wave, lane);
 #pragma unroll
                     for (int gt = 0; gt < 2; ++gt) {
