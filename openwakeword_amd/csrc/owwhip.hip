@@ -53,6 +53,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 struct LayerDef { int kh, kw, cin, cout; };
+constexpr int kSmallLaunchWgs = 2 * 256;      // stage / heads launches of at most two workgroups per CU (MI355X: 256 CUs) use the deep weight rings
 const LayerDef kLayers[20] = {
     {3, 3, 1, 24},
     {1, 3, 24, 24}, {3, 1, 24, 24},
@@ -599,19 +600,28 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     {
         RStageParams p{}; fill(p, h->d_xA, h->d_xB, 3, 2, 3, RB::SPT);
         Timed t(h, 2);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG, OWH_WG_B>), dim3((p.n_groups + OWH_WG_B - 1) / OWH_WG_B), dim3(64 * OWH_WG_B), 0, st, p);
+        // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
+        const int nwg = (p.n_groups + OWH_WG_B - 1) / OWH_WG_B;
+        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, false, OWH_WG_B, 3>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
+        else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG, OWH_WG_B>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xB, h->d_xC, 7, 4, 5, RC::SPT);
         Timed t(h, 3);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG, OWH_WG_C>), dim3((p.n_groups + OWH_WG_C - 1) / OWH_WG_C), dim3(64 * OWH_WG_C), 0, st, p);
+        // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
+        const int nwg = (p.n_groups + OWH_WG_C - 1) / OWH_WG_C;
+        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, false, OWH_WG_C, 3>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
+        else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG, OWH_WG_C>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
         RStageParams p{}; fill(p, h->d_xC, h->d_xD, 11, 6, 7, RD::SPT);
         Timed t(h, 4);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG, OWH_WG_D>), dim3((p.n_groups + OWH_WG_D - 1) / OWH_WG_D), dim3(64 * OWH_WG_D), 0, st, p);
+        // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
+        const int nwg = (p.n_groups + OWH_WG_D - 1) / OWH_WG_D;
+        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, false, OWH_WG_D, 3>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
+        else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG, OWH_WG_D>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     {
@@ -619,7 +629,10 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         p.hist19 = h->d_state[10]; p.w19 = h->d_conv[19]; p.feat = h->d_feat; p.emb = h->d_emb; p.nfeat = h->d_nfeat; p.TR = h->TR;
         p.dbg_off[4] = dbg_off[19];
         Timed t(h, 5);
-        if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG, OWH_WG_E>), dim3((p.n_groups + OWH_WG_E - 1) / OWH_WG_E), dim3(64 * OWH_WG_E), 0, st, p);
+        // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
+        const int nwg = (p.n_groups + OWH_WG_E - 1) / OWH_WG_E;
+        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, false, OWH_WG_E, 3>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
+        else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG, OWH_WG_E>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
     HIPCHK(hipGetLastError());
@@ -686,7 +699,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 q.fscale = std::ldexp(1.0f, h->hx_efeat);
                 const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
                 // a launch that leaves workgroups alone on their CUs runs the deep weight ring (owwhip_hx.h: HX_NBUF_DEEP); same results
-                const bool deep = (int)grid.x <= 2 * 256;                     // (MI355X: 256 CUs)
+                const bool deep = (int)grid.x <= kSmallLaunchWgs;
                 const int nn = std::min(g.n_nets, 4);
                 const int nbuf = deep ? (nn <= 2 ? owh::HeadsDeep<1>::NBUF : owh::HeadsDeep<4>::NBUF) : owh::HX_NBUF;
                 (void)nbuf;

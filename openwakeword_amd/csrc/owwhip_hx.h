@@ -311,13 +311,79 @@ using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
 #define OWH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
+// ---- weight-chunk ring of the stage kernels ----------------------------------------------------------------------------------------
+// A layer's weights arrive as NCTO chunks (one output-channel tile each: 6..18 KB), L2 -> LDS by global_load_lds, shared by the
+// workgroup's waves.  NS slots, P = NS - 1 chunks in flight ahead of the one being consumed; chunks past a layer's end are the first
+// chunks of the next layer (w_next), so the stream never drains at a layer boundary.
+//  * every slot is its own LDS object: the compiler orders each LDS read behind every pending LDS-DMA write it cannot prove disjoint
+//    (s_waitcnt vmcnt(0)).  With one array of two halves (rounds 1-3) a wave waited for the chunk it had JUST issued before it read
+//    the current one, in every second chunk step: the prefetch never overlapped the wave's own MFMAs.  Distinct objects carry distinct
+//    alias scopes and the wait is gone (B -7 %, C -6 %, D -3 %, E -4 % at 131,072 streams; E -12 % at 4,096).
+//  * NS = 2 (large launches): end of a step = s_waitcnt vmcnt(0) + __syncthreads().  Other workgroups of the CU cover the rest.
+//  * NS = 3 (small launches, where a workgroup is alone on its CU and each chunk step is ~0.3 us of MFMA work behind a ~1 us
+//    L2 -> LDS round trip): end of step i = s_waitcnt vmcnt(K) with K = the DMA instructions this wave issued in step i (chunk
+//    i + 2 may stay in flight; VMEM reads return in order, so at most K outstanding means chunk i + 1 has landed -- stores that are
+//    still in flight can only make the wait longer) + a BARE s_barrier: __syncthreads() carries a workgroup release fence, which on
+//    this target is another vmcnt(0).  Same arithmetic in the same order: results do not depend on NS (tested bit for bit).
+// s_waitcnt vmcnt(N) as the BUILTIN (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait"), not inline
+// asm: the compiler's own wait-count bookkeeping reads a real S_WAITCNT and stops believing the older LDS-DMA writes are pending --
+// behind an asm wait it adds its own (full) vmcnt(0) in front of the next LDS read of a slot it thinks is still being written
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+    asm volatile("" ::: "memory");
+}
+template <int NS> struct WRing { float* s[3]; };
+// a chunk with the SAME number of DMA instructions in every wave (no branch on the wave index): blocks past the end re-load the last
+// block (same source, same destination, same data).  Straight-line issue keeps the compiler's wait counts exact -- behind a branch it
+// falls back to vmcnt(0) in front of the next read of that slot -- and makes the counted wait below exact for every wave.
+template <int NBLK, int WG>
+__device__ __forceinline__ void issue_chunk_uniform(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
+    const unsigned voff = lane * 4;
+#pragma unroll
+    for (int u = 0; u < (NBLK + WG - 1) / WG; ++u) {
+        const int i = min(u * WG + wave, NBLK - 1);
+        const float* base = owr::uniform_ptr(gsrc + i * 256);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
+                                         (__attribute__((address_space(3))) void*)(ldst + i * 256), 16, 0, 0);
+    }
+}
+template <int NS, int NBLK, int WG>
+__device__ __forceinline__ void ring_issue(const float* __restrict__ gsrc, float* ldst, int wave, int lane) {
+    if constexpr (NS == 2) owr::issue_chunk<NBLK, WG>(gsrc, ldst, wave, lane);
+    else issue_chunk_uniform<NBLK, WG>(gsrc, ldst, wave, lane);
+}
+template <int NS, int CH, int NBLK, int NCTO, int NEXT_NBLK, int WG>
+__device__ __forceinline__ const float* ring_begin(const WRing<NS>& r, int oct, const float* __restrict__ w, const float* __restrict__ w_next,
+                                                   int wave, int lane) {
+    constexpr int P = NS - 1;
+    const int c = oct + P;                                   // the chunk issued in this step (past NCTO: the next layer's)
+    float* dst = r.s[(CH + oct + P) % NS];                   // its slot held chunk oct - 1: every wave passed the last barrier
+    if (c < NCTO) ring_issue<NS, NBLK, WG>(w + (size_t)c * NBLK * 256, dst, wave, lane);
+    else if (NEXT_NBLK > 0 && c - NCTO < P) ring_issue<NS, (NEXT_NBLK > 0 ? NEXT_NBLK : 1), WG>(w_next + (size_t)(c - NCTO) * NEXT_NBLK * 256, dst, wave, lane);
+    return r.s[(CH + oct) % NS];
+}
+template <int NS, int NBLK, int NCTO, int NEXT_NBLK, int WG>
+__device__ __forceinline__ void ring_end(int oct) {
+    if (!(oct + 1 < NCTO || NEXT_NBLK > 0)) return;          // no chunk oct + 1 in this launch
+    if constexpr (NS == 2) owr::chunk_sync();
+    else {
+        constexpr int P = NS - 1;
+        const int c = oct + P;
+        if (c < NCTO) wait_vmcnt<(NBLK + WG - 1) / WG>();
+        else if (NEXT_NBLK > 0 && c - NCTO < P) wait_vmcnt<(NEXT_NBLK + WG - 1) / WG>();
+        else wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+    }
+}
+
 // chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
 // 1x3 (mel) layer: NT tiles in operand form -> NT fp32 D tiles (BatchNorm + activation applied)
-template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, bool REM2 = false>
-__device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], float* wbuf,
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, bool REM2 = false, int NS = 2>
+__device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], const WRing<NS>& ring,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ init, float cl, int wave, int lane,
-                                            lanemask_t& bad, float* wbuf1) {
+                                            lanemask_t& bad) {
     using namespace owr;
     const int pos = lane & 15, j = lane >> 4;
     // (interleaved order: the row shift by SH = 16 / F lanes zero-fills exactly the stream-edge lanes and the masks are not used)
@@ -327,10 +393,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     constexpr int NBLK = 3 * KSI * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
-        float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
-        if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+        const float* cur = ring_begin<NS, CH0, NBLK, NCTO, NEXT_NBLK, WG>(ring, oct, w, w_next, wave, lane);
         f32x4 res[NT], accs[2][NT];
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
@@ -391,7 +454,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
             if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
             else { out[t][oct] = act_t<BN, false>(res[t], cl); pin_t<false>(out[t][oct]); }
         }
-        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+        ring_end<NS, NBLK, NCTO, NEXT_NBLK, WG>(oct);
     }
 }
 
@@ -435,21 +498,18 @@ __device__ __forceinline__ void merge_mel_rems(const Op (&in)[NT][KSI], Op (&M)[
         }
     }
 }
-template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
-__device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], float* wbuf,
+template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, int NS = 2>
+__device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], const WRing<NS>& ring,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
-                                             lanemask_t& bad, float* wbuf1) {
+                                             lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int SH = 16 / F, KSF = KSI - 1;
     constexpr int NBLK = (3 * KSF + NMK) * 2;
 #pragma unroll
     for (int oct = 0; oct < NCTO; ++oct) {
-        const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
-        float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
-        if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-        else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+        const float* cur = ring_begin<NS, CH0, NBLK, NCTO, NEXT_NBLK, WG>(ring, oct, w, w_next, wave, lane);
         f32x4 res[NT], accs[2][NT];
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
@@ -502,7 +562,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
             if (HOUT && oct == NCTO - 1) { out[t][oct] = act_t<BN, true>(res[t], cl); pin_t<true>(out[t][oct]); }
             else { out[t][oct] = act_t<BN, false>(res[t], cl); pin_t<false>(out[t][oct]); }
         }
-        if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+        ring_end<NS, NBLK, NCTO, NEXT_NBLK, WG>(oct);
     }
 }
 
@@ -519,11 +579,11 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #ifndef OWH_PIPE_M
 #define OWH_PIPE_M 0       // the same interleave hint in the K-merged time layers (stage C): same-box A/B 1.555 -> 1.525 ms WITHOUT it
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0, bool REM2 = false>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0, bool REM2 = false, int NS = 2>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
-                                             float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
+                                             const WRing<NS>& ring, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
-                                             lanemask_t& bad, float* wbuf1) {
+                                             lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = 3 * KSI * 2;
@@ -532,10 +592,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
     for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
         if (oct < NCTO) {
-            const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
-            float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
-            if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+            const float* cur = ring_begin<NS, CH0, NBLK, NCTO, NEXT_NBLK, WG>(ring, oct, w, w_next, wave, lane);
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);           // folded BatchNorm shift = the chain's start value
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = I;
@@ -579,7 +636,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
         if (oct < NCTO) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) prev[r] = acc[r];
-                if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+                ring_end<NS, NBLK, NCTO, NEXT_NBLK, WG>(oct);
         }
     }
 }
@@ -644,11 +701,11 @@ __device__ __forceinline__ void merge_rems(const RemPairs (&rem)[NR + 2], Op (&M
     }
 }
 
-template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false>
+template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, int NS = 2>
 __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1)[KSF], const Op (&in)[NR][KSF], const Op (&M)[NR][NMK],
-                                              f32x4 (&out)[NR][NCTO], float* wbuf, const float* __restrict__ w, const float* __restrict__ w_next,
+                                              f32x4 (&out)[NR][NCTO], const WRing<NS>& ring, const float* __restrict__ w, const float* __restrict__ w_next,
                                               const float* __restrict__ init, float cl, int wave, int lane,
-                                              lanemask_t& bad, float* wbuf1) {
+                                              lanemask_t& bad) {
     using namespace owr;
     const int j = lane >> 4;
     constexpr int NBLK = (3 * KSF + NMK) * 2;
@@ -657,10 +714,7 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
     for (int oct = 0; oct <= NCTO; ++oct) {
         f32x4 acc[NR];
         if (oct < NCTO) {
-            const float* cur = ((CH0 + oct) & 1) ? wbuf1 : wbuf;
-            float* nxt = ((CH0 + oct + 1) & 1) ? wbuf1 : wbuf;
-            if (oct + 1 < NCTO) issue_chunk<NBLK, WG>(w + (size_t)(oct + 1) * NBLK * 256, nxt, wave, lane);
-            else if (NEXT_NBLK > 0) issue_chunk<NEXT_NBLK, WG>(w_next, nxt, wave, lane);
+            const float* cur = ring_begin<NS, CH0, NBLK, NCTO, NEXT_NBLK, WG>(ring, oct, w, w_next, wave, lane);
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = I;
@@ -713,7 +767,7 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
         if (oct < NCTO) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) prev[r] = acc[r];
-                if (oct + 1 < NCTO || NEXT_NBLK > 0) chunk_sync();
+                ring_end<NS, NBLK, NCTO, NEXT_NBLK, WG>(oct);
         }
     }
 }
@@ -750,8 +804,8 @@ __device__ __forceinline__ void load_tile_lds(f32x4 (&t)[NCT], const float* base
         }
 }
 
-template <class C, bool LAST, bool DBG, int WG = OWH_WG>
-__global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStageParams p) {
+template <class C, bool LAST, bool DBG, int WG = OWH_WG, int NS = 2>
+__global__ __launch_bounds__(64 * WG, (NS == 3 && C::WPS > 2 ? 2 : C::WPS)) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
@@ -784,12 +838,11 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int g = blockIdx.x * WG + wave;
-    // the two halves of the weight double buffer are two DISTINCT LDS objects.  The compiler orders every LDS read behind pending
-    // LDS-DMA writes (global_load_lds) it cannot prove disjoint, with s_waitcnt vmcnt(0): with one array of two halves it stalled
-    // each wave on the chunk it had JUST issued (the prefetch of chunk i + 1) before reading chunk i -- no overlap of the weight
-    // stream with a wave's own MFMAs, in half of all chunk steps.  Distinct objects carry distinct alias scopes: no such wait.
+    // the slots of the weight ring are DISTINCT LDS objects (see WRing above)
     __shared__ __attribute__((aligned(16))) float wbuf[WBS];
     __shared__ __attribute__((aligned(16))) float wbuf1[WBS];
+    __shared__ __attribute__((aligned(16))) float wbuf2[NS == 3 ? WBS : 4];
+    const WRing<NS> ring{{wbuf, wbuf1, wbuf2}};
     __shared__ __attribute__((aligned(16))) float sbn[4][NCT * 16];      // per layer: K * BatchNorm shift in tile row order = accumulator start values
     __shared__ __attribute__((aligned(16))) float hlds[HLDS ? WG * 2 * HROW : 4];
     float* const hl = hlds + (HLDS ? wave * 2 * HROW : 0);
@@ -798,7 +851,8 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if (p.glist) g = p.glist[g];          // a masked step with few participants runs only the groups that hold one (owwhip.hip: build_active_lists)
     else g += p.g_base;                   // block-pipelined step: this launch covers groups g_base .. g_base + n_groups - 1
     lanemask_t bad = 0;
-    issue_chunk<NBAM, WG>(p.w[0], wbuf, wave, lane);
+    ring_issue<NS, NBAM, WG>(p.w[0], wbuf, wave, lane);
+    if (NS == 3) ring_issue<NS, NBAM, WG>(p.w[0] + (size_t)NBAM * 256, wbuf1, wave, lane);   // (two chunks in flight from the start)
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
         sbn[l][c] = p.shift[l][c];
@@ -827,9 +881,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMA) {
         Op Mx[R][NMKA];
         merge_mel_rems<KSA, R, F, NPRA>(Xo, Mx);
-        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Mx, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, wbuf1);
+        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT, NS>(Xo, Mx, Y, ring, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
     } else
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT>(Xo, Y, wbuf, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad, wbuf1);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT, false, NS>(Xo, Y, ring, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane, p.dbg_mul[0]);
@@ -855,7 +909,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, wbuf1);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT, NS>(H0F, H1F, AoF, M, Y, ring, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -873,7 +927,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad, wbuf1);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2, NS>(H0, H1, Ao, Y, ring, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -886,9 +940,9 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     if constexpr (MMC) {
         Op Mc[R][NMKC];
         merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
-        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT>(Ao, Mc, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, wbuf1);
+        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, NS>(Ao, Mc, Y, ring, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     } else
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2>(Ao, Y, wbuf, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad, wbuf1);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2, NS>(Ao, Y, ring, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
@@ -912,7 +966,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT>(H0F, H1F, AoF, M, Y, wbuf, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad, wbuf1);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT, NS>(H0F, H1F, AoF, M, Y, ring, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -929,7 +983,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2>(H0, H1, Ao, Y, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad, wbuf1);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2, NS>(H0, H1, Ao, Y, ring, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -993,7 +1047,7 @@ __global__ __launch_bounds__(64 * WG, C::WPS) void hstage_kernel(owr::RStagePara
         to_ops<NCT>(Pl, Po[0]);
         f32x4 E[1][NCT];
         // (no guard here: an out-of-range input of conv19 yields a NaN embedding, which the heads kernel's guard reports)
-        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false>(H0, H1, Po, E, wbuf, p.w19, nullptr, nullptr, 0.f, wave, lane, bad, wbuf1);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
+        conv_time_hx<KS, NCT, 1, false, 4 * NCT, 0, WG, false, false, OWH_PIPE != 0, false, NS>(H0, H1, Po, E, ring, p.w19, nullptr, nullptr, 0.f, wave, lane, bad);      // (conv19's packed weights carry 1 / K of its input: true embeddings)
         const bool on19 = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (pos & 7), p.S - 1)] != 0);   // lanes 8..15 mirror 0..7
         if (on19) {
             store_tile<NCT>(T1, h19, lane);
@@ -1476,8 +1530,6 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
 #define OWH_HEADS_NBUF 2
 #endif
 constexpr int HX_WG = OWH_HEADS_WG, HX_NBUF = OWH_HEADS_NBUF;
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 // NBUF = slots of the weight ring in LDS (and of the feature ring in registers); D = NBUF - 1 k-steps are in flight ahead of the one
 // being consumed: the weight chunk of k-step i + D (L2 -> LDS, global_load_lds) and, issued right AFTER it, the feature rows of the
 // same k-step (HBM / L2 -> VGPRs).  VMEM reads return in order, so the wait the compiler places in front of the f16 split of k-step
