@@ -412,6 +412,8 @@ struct oww_ctx {
     int hx_e[20] = {}, hx_ein[20] = {}, hx_xexp[5] = {};
     float hx_absmax[20] = {};        // largest |activation| of each layer in the calibration run (exact-fp32 kernels)
     std::vector<int16_t> cal_user;   // oww_set_calibration: caller's calibration audio as [n_seg][CAL_T * 1280] segments
+    int small_wgs = kSmallLaunchWgs, small_wgs_heads = kSmallLaunchWgs;   // A/B aids: OWW_SMALL_WGS / OWW_SMALL_WGS_HEADS (0 = never the deep rings)
+    bool ring3_always[4] = {};       // A/B aid (OWW_RING3_ALWAYS="BCDE"): the three-slot weight ring of stages B..E at any launch size
     int hx_efeat = 0;                // heads: the features enter the first GEMM multiplied by 2^hx_efeat (largest probe |embedding| at 2^9..2^10)
     float hx_selftest_err = 0.f, hx_selftest_ref = 0.f, hx_selftest_score_err = 0.f;   // commit-time f16-split vs exact-fp32 comparison
     bool fuse = false;               // f16-split family: mel front end fused into stage A for one-chunk streaming steps (owwhip_fused.h)
@@ -602,7 +604,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 2);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_B - 1) / OWH_WG_B;
-        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, false, OWH_WG_B, 3>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
+        if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[0])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, false, OWH_WG_B, 3>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG, OWH_WG_B>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
@@ -611,7 +613,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 3);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_C - 1) / OWH_WG_C;
-        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, false, OWH_WG_C, 3>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
+        if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[1])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, false, OWH_WG_C, 3>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG, OWH_WG_C>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
@@ -620,7 +622,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 4);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_D - 1) / OWH_WG_D;
-        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, false, OWH_WG_D, 3>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
+        if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[2])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, false, OWH_WG_D, 3>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG, OWH_WG_D>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
@@ -631,7 +633,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 5);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_E - 1) / OWH_WG_E;
-        if (HX && !DBG && nwg <= kSmallLaunchWgs) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, false, OWH_WG_E, 3>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
+        if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[3])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, false, OWH_WG_E, 3>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG, OWH_WG_E>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
     }
@@ -699,7 +701,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 q.fscale = std::ldexp(1.0f, h->hx_efeat);
                 const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
                 // a launch that leaves workgroups alone on their CUs runs the deep weight ring (owwhip_hx.h: HX_NBUF_DEEP); same results
-                const bool deep = (int)grid.x <= kSmallLaunchWgs;
+                const bool deep = (int)grid.x <= h->small_wgs_heads;
                 const int nn = std::min(g.n_nets, 4);
                 const int nbuf = deep ? (nn <= 2 ? owh::HeadsDeep<1>::NBUF : owh::HeadsDeep<4>::NBUF) : owh::HX_NBUF;
                 (void)nbuf;
@@ -1746,6 +1748,9 @@ int oww_commit(oww_ctx* h) {
         }
     }
     h->fuse = h->hx && !getenv("OWW_NO_FUSE");
+    if (const char* e = getenv("OWW_SMALL_WGS")) h->small_wgs = atoi(e);
+    if (const char* e = getenv("OWW_SMALL_WGS_HEADS")) h->small_wgs_heads = atoi(e);
+    if (const char* e = getenv("OWW_RING3_ALWAYS")) for (int i = 0; i < 4; ++i) h->ring3_always[i] = strchr(e, "BCDE"[i]) != nullptr;
     h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
     if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(owf::hmelA_kernel<true>, owf::FA_LDS_BYTES)) return rc;

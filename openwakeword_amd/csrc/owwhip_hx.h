@@ -373,7 +373,9 @@ __device__ __forceinline__ void ring_end(int oct) {
         if (c < NCTO) wait_vmcnt<(NBLK + WG - 1) / WG>();
         else if (NEXT_NBLK > 0 && c - NCTO < P) wait_vmcnt<(NEXT_NBLK + WG - 1) / WG>();
         else wait_vmcnt<0>();
-        asm volatile("s_barrier" ::: "memory");
+        // lgkmcnt(0): this wave's LDS reads of chunk oct have RETURNED before the barrier lets another wave restage that slot in the
+        // next step (the MFMAs that consume them -- and the waits in front of those -- may be scheduled behind the bare barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -1647,7 +1649,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
             // it would drain every prefetch in flight at every k-step.  What the barrier has to order is already ordered: this wave's
             // part of chunk ks+1 has landed (the wait above), its LDS reads of chunk ks have returned (they fed the MFMAs above), and
             // the memory clobber keeps the compiler from moving LDS accesses across it.
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (lgkmcnt(0): this wave's reads of the slot have returned)
         }
     };
     auto group = [&](int ks0, auto always) {                    // NBUF consecutive k-steps, slots 0 .. NBUF-1
