@@ -354,6 +354,7 @@ struct oww_ctx {
     float* d_w = nullptr;
     const float *d_hann = nullptr, *d_taps = nullptr;
     const int* d_mstart = nullptr;
+    const int* d_meloff = nullptr; const unsigned* d_meldst = nullptr;   // fused front end: compact tap table (oww_commit)
     const float* d_conv[20] = {};     // layer 0: natural [9][24]; 1..19: packed (mfma) or natural (valu)
     const float* d_scale[20] = {};
     const float* d_shift[20] = {};
@@ -570,7 +571,7 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
             owf::MelAParams q{};
             q.a = p; q.a.mel = nullptr; q.a.n_streams = h->S;          // the PCM buffer holds the S real streams only
             if (h->blk_s1 > 0) { q.a.s_base = h->blk_s0; q.a.n_streams = std::min(h->S, h->blk_s1) - h->blk_s0; }
-            q.pcm = h->fuse_pcm; q.tail = h->d_tail; q.nfeat = h->d_nfeat; q.hann = h->d_hann; q.mel_start = h->d_mstart; q.mel_taps = h->d_taps;
+            q.pcm = h->fuse_pcm; q.tail = h->d_tail; q.nfeat = h->d_nfeat; q.hann = h->d_hann; q.mel_start = h->d_mstart; q.mel_taps = h->d_taps; q.mel_off = h->d_meloff; q.mel_dst = h->d_meldst;
             q.mel_out = h->cfg.debug_layers ? h->d_mel : nullptr;
             const int per_cu = std::max(1, std::min(12 / owf::FA_WG, 163840 / owf::FA_LDS_BYTES));     // persistent: 12 waves per CU
             const int g2 = std::max(1, std::min((q.a.n_streams + owf::FA_WG - 1) / owf::FA_WG, 256 * per_cu));
@@ -1479,6 +1480,60 @@ int oww_commit(oww_ctx* h) {
     const size_t o_hann = hb.add(h->mel_blob.data(), 400);
     const size_t o_start = hb.add(h->mel_blob.data() + 400, 32);          // int32 bit patterns
     const size_t o_taps = hb.add(h->mel_blob.data() + 432, 512);
+    // fused front end: the sparse mel taps read a COMPACT copy of each frame's power row -- one segment per mel bin, [first tap ..
+    // last non-zero tap] -- whose segment starts have pairwise different residues mod 32, so that the 32 lanes of a tap read hit 32
+    // different LDS banks (the plain power row gave three bins per bank for every tap: most of the launch's bank conflicts).  Every
+    // power bin belongs to at most two triangular filters, hence two destinations per bin (mel_dst: lo / hi 16 bits; kMelJunk = none).
+    size_t o_meloff = 0, o_meldst = 0;
+    {
+        constexpr int kMelTable = 250, kMelJunk = 250;           // floats of a frame's table; bins without a second filter store here
+        const int32_t* start = reinterpret_cast<const int32_t*>(h->mel_blob.data() + 400);
+        const float* taps = h->mel_blob.data() + 432;
+        int nz[32], first[32];
+        for (int m = 0; m < 32; ++m) {
+            nz[m] = 0;
+            for (int t = 0; t < 16; ++t) if (taps[m * 16 + t] != 0.f) nz[m] = t + 1;
+            first[m] = start[m] - 2;                              // power-row index of tap 0 (the kernels keep FFT bins 2..121)
+        }
+        int off[32], best[32], best_end = 1 << 30;
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        for (int it = 0; it < 20000 && best_end > kMelTable; ++it) {                // randomised first-fit; a few hundred tries are enough
+            int order[32];
+            for (int i = 0; i < 32; ++i) order[i] = i;
+            for (int i = 31; i > 0; --i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; std::swap(order[i], order[st % (uint64_t)(i + 1)]); }
+            unsigned used = 0; int cur = 0, end = 0;
+            for (int i = 0; i < 32; ++i) {
+                const int m = order[i];
+                int o = cur;
+                while (used >> (o & 31) & 1u) ++o;
+                used |= 1u << (o & 31); off[m] = o; cur = o + nz[m];
+                end = std::max(end, o + 16);                      // a lane reads 16 taps from its start
+            }
+            if (end < best_end) { best_end = end; memcpy(best, off, sizeof off); }
+        }
+        if (best_end > kMelTable) {                               // (cannot happen for a 32-filter bank of <= 16 taps; plain prefix layout)
+            int cur = 0;
+            for (int m = 0; m < 32; ++m) { best[m] = cur; cur += nz[m]; }
+            if (cur + 16 > kMelTable) return fail(OWW_EINVAL, "oww_commit: the mel filter bank has more than %d taps", kMelTable - 16);
+        }
+        std::vector<float> dst(128, 0.f);
+        for (int i = 0; i < 120; ++i) {
+            uint32_t d[2] = {kMelJunk, kMelJunk}; int n = 0;
+            for (int m = 0; m < 32; ++m) {
+                const int t = i - first[m];
+                if (t >= 0 && t < nz[m] && taps[m * 16 + t] != 0.f) {
+                    if (n == 2) return fail(OWW_EINVAL, "oww_commit: FFT bin %d feeds more than two mel filters (not a triangular filter bank)", i + 2);
+                    d[n++] = (uint32_t)(best[m] + t);
+                }
+            }
+            const uint32_t packed = d[0] | (d[1] << 16);
+            memcpy(&dst[i], &packed, 4);
+        }
+        std::vector<float> offf(32);
+        for (int m = 0; m < 32; ++m) { const int32_t v = best[m]; memcpy(&offf[m], &v, 4); }
+        o_meloff = hb.add(offf.data(), 32);
+        o_meldst = hb.add(dst.data(), 128);
+    }
     size_t o_conv[20], o_scale[20] = {}, o_shift[20] = {};
     {
         const float* q = h->emb_blob.data();
@@ -1642,6 +1697,7 @@ int oww_commit(oww_ctx* h) {
     HIPCHK(hipMalloc(&h->d_w, hb.data.size() * sizeof(float)));
     HIPCHK(hipMemcpy(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
     h->d_hann = h->d_w + o_hann; h->d_mstart = reinterpret_cast<const int*>(h->d_w + o_start); h->d_taps = h->d_w + o_taps;
+    h->d_meloff = reinterpret_cast<const int*>(h->d_w + o_meloff); h->d_meldst = reinterpret_cast<const unsigned*>(h->d_w + o_meldst);
     if (h->vad) {
         h->d_vad_hann = h->d_w + o_vhann; h->d_vad_encw = h->d_w + o_vencw; h->d_vad_encb = h->d_w + o_vencb;
         h->d_vad_lstmw = h->d_w + o_vlw; h->d_vad_lstmb = h->d_w + o_vlb; h->d_vad_wd = h->d_w + o_vwd;

@@ -40,6 +40,8 @@ struct MelAParams {
     const float* hann;      // [400]
     const int* mel_start;   // [32]
     const float* mel_taps;  // [32][16]
+    const int* mel_off;     // [32]  start of mel bin m's segment in a frame's compact power table (residues mod 32 pairwise different)
+    const unsigned* mel_dst;// [120] the (at most two) table slots power bin i feeds: lo / hi 16 bits (250 = none)
     float* mel_out;         // optional [S][8][32]: keep the rows for oww_get_mel (debug handles)
 };
 
@@ -47,7 +49,7 @@ struct MelAParams {
 constexpr int FA_W0 = 2 * 256, FA_W1 = 12 * 256, FA_W2 = 14 * 256, FA_BN = 3 * 2 * 32, FA_MT = owh::sa::WAVE_HALVES / 2, FA_Z = 2 * 576, FA_GT = 512;
 constexpr int FA_OFF_W0 = 0, FA_OFF_W1 = FA_OFF_W0 + FA_W0, FA_OFF_W2 = FA_OFF_W1 + FA_W1, FA_OFF_BN = FA_OFF_W2 + FA_W2;
 constexpr int FA_OFF_HANN = FA_OFF_BN + FA_BN, FA_OFF_TW1 = FA_OFF_HANN + 512, FA_OFF_TW2 = FA_OFF_TW1 + 2 * 8 * 64;
-constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16 * 32, FA_OFF_GT = FA_OFF_MS + 32, FA_OFF_MEL = FA_OFF_GT + FA_GT;
+constexpr int FA_OFF_TAPS = FA_OFF_TW2 + 2 * 8 * 8, FA_OFF_MS = FA_OFF_TAPS + 16 * 32, FA_OFF_DST = FA_OFF_MS + 32, FA_OFF_GT = FA_OFF_DST + 128, FA_OFF_MEL = FA_OFF_GT + FA_GT;
 constexpr int FA_OFF_Z = FA_OFF_MEL + FA_WG * FA_MT + ((4 - (FA_WG * FA_MT) % 4) % 4);
 constexpr int FA_LDS_BYTES = (FA_OFF_Z + FA_WG * FA_Z) * 4;
 static_assert(FA_OFF_Z % 4 == 0 && FA_OFF_W1 % 4 == 0 && FA_OFF_W2 % 4 == 0 && FA_OFF_GT % 4 == 0 && FA_OFF_MEL % 4 == 0 && FA_MT % 4 == 0, "16-byte aligned blocks");
@@ -109,9 +111,13 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         t_tw2[tid] = cs; t_tw2[64 + tid] = sn;
     }
     for (int i = tid; i < 512; i += NT) t_taps[i] = q.mel_taps[(i & 31) * 16 + (i >> 5)];
-    if (tid < 32) s_ms[tid] = q.mel_start[tid] - 2;
+    if (tid < 32) s_ms[tid] = q.mel_off[tid];
+    if (tid < 128) reinterpret_cast<unsigned*>(fl + FA_OFF_DST)[tid] = q.mel_dst[tid];
     for (int i = tid; i < FA_WG * FA_MT; i += NT) fl[FA_OFF_MEL + i] = 0.f;      // (hi / lo planes of every wave: zero columns = the mel-axis padding)
     owh::stageA_fill_gather_table(reinterpret_cast<int*>(fl + FA_OFF_GT), tid, NT);
+    // the FFT planes start finite: a tap read past the end of a mel bin's segment (against a zero tap) may fall into a gap of the
+    // compact power tables that no FFT stage has written yet, and 0 x NaN would poison the sum
+    for (int i = tid; i < FA_WG * FA_Z; i += NT) fl[FA_OFF_Z + i] = 0.f;
     __syncthreads();
     _Float16* sP = reinterpret_cast<_Float16*>(fl + FA_OFF_MEL + wave * FA_MT);
     const int* gtab = reinterpret_cast<const int*>(fl + FA_OFF_GT);
@@ -135,10 +141,11 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         float* xr = planes + z;                   // FFT planes; the sample window and the two power rows alias them (owk::mel_kernel)
         float* xi = xr + 576;
         float* sx = xr;
+        // compact power tables of the pass's two frames (256 words each: the words 128..383 of either plane, which the last FFT
+        // stage leaves unused): one segment per mel bin, segment starts on 32 different banks -- the tap reads below are conflict-free
         float* pw0 = xr + 128;
-        float* pw1 = xr + 257;                    // (one word off pw0's bank phase: the two frames' tap reads below are 2-way instead of
-                                                  //  4-way bank-conflicted; rows pw0 [128, 248) and pw1 [257, 377) stay inside the
-                                                  //  words 128..383 the last FFT stage leaves unused)
+        float* pw1 = xi + 128;
+        const unsigned* s_dst = reinterpret_cast<const unsigned*>(fl + FA_OFF_DST + z);
         const float* s_hann = fl + FA_OFF_HANN + z;
         const float* s_tw1 = fl + FA_OFF_TW1 + z;   // [re / im][k 8][lane 64]: exp(-2 pi i lane k / 512)
         const float* s_tw2 = fl + FA_OFF_TW2 + z;   // [re / im][k 8][m0 8]:    exp(-2 pi i m0 k / 64)
@@ -235,8 +242,10 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 const float zr = xr[k], zi = xi[k], yr = xr[512 - k], yi = xi[512 - k];
                 const float ar = zr + yr, ai = zi - yi;
                 const float br = zi + yi, bi = zr - yr;
-                pw0[i] = 0.25f * (ar * ar + ai * ai);
-                pw1[i] = 0.25f * (br * br + bi * bi);
+                const float p0 = 0.25f * (ar * ar + ai * ai), p1 = 0.25f * (br * br + bi * bi);
+                const unsigned d = s_dst[i];                  // every FFT bin feeds at most two (neighbouring) triangular filters
+                pw0[d & 0xffffu] = p0; pw0[d >> 16] = p0;
+                pw1[d & 0xffffu] = p1; pw1[d >> 16] = p1;
             }
             wave_sync();
             {
