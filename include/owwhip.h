@@ -120,9 +120,11 @@ int  oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshol
 int  oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, float bias, float threshold);
 
 /* ---- VAD gate of Model.predict (model.py:366-381) for the batched path -------------------------------------------------
- * The voice-activity NETWORK is not part of this library (silero_vad.onnx is a release asset whose graph is not in the reference
- * checkout): the caller supplies one VAD score per stream and step -- the mean over the step's 640-sample sub-frames that
- * VAD.__call__ appends (vad.py:98-130) -- and the library keeps the per-stream score ring and applies the gate: when the largest
+ * Two ways to feed the gate.  (1) External network (the reference's silero_vad.onnx is a release asset whose graph is not in the
+ * reference checkout, so it cannot be built into this library): the caller supplies one VAD score per stream and step -- the mean
+ * over the step's 640-sample sub-frames that VAD.__call__ appends (vad.py:98-130) -- with oww_push_vad.  (2) A network on the device:
+ * oww_load_vad below (a structural stand-in with the same interface and state).  Either way the library keeps the per-stream
+ * score ring and applies the gate: when the largest
  * of the scores pushed 5..7 steps ago (ring[-7:-4]; nothing during the first four steps) is below `threshold`, every label of
  * that stream reads 0 for the step (the 30-deep score ring keeps the ungated value, as in the reference).  threshold <= 0
  * switches the gate off (default).  Call oww_push_vad BEFORE the oww_step / oww_submit of the same frame; vad_scores is

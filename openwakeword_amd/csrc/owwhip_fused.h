@@ -27,6 +27,9 @@ using owr::f32x4;
 #ifndef OWF_B128_STAGE
 #define OWF_B128_STAGE 1   // float staging with two ds_write_b128 per lane (0: scalar stores, paired by the compiler into ds_write2_b32)
 #endif
+#ifndef OWF_COMPACT_TAPS
+#define OWF_COMPACT_TAPS 1 // the sparse mel taps read conflict-free compact power tables (0: the plain power rows, three bins per bank)
+#endif
 #ifndef OWF_WG
 #define OWF_WG 12          // waves per workgroup (one workgroup per CU: 3 waves per SIMD)
 #endif
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         t_tw2[tid] = cs; t_tw2[64 + tid] = sn;
     }
     for (int i = tid; i < 512; i += NT) t_taps[i] = q.mel_taps[(i & 31) * 16 + (i >> 5)];
-    if (tid < 32) s_ms[tid] = q.mel_off[tid];
+    if (tid < 32) s_ms[tid] = OWF_COMPACT_TAPS ? q.mel_off[tid] : q.mel_start[tid] - 2;
     if (tid < 128) reinterpret_cast<unsigned*>(fl + FA_OFF_DST)[tid] = q.mel_dst[tid];
     for (int i = tid; i < FA_WG * FA_MT; i += NT) fl[FA_OFF_MEL + i] = 0.f;      // (hi / lo planes of every wave: zero columns = the mel-axis padding)
     owh::stageA_fill_gather_table(reinterpret_cast<int*>(fl + FA_OFF_GT), tid, NT);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
         // compact power tables of the pass's two frames (256 words each: the words 128..383 of either plane, which the last FFT
         // stage leaves unused): one segment per mel bin, segment starts on 32 different banks -- the tap reads below are conflict-free
         float* pw0 = xr + 128;
-        float* pw1 = xi + 128;
+        float* pw1 = OWF_COMPACT_TAPS ? xi + 128 : xr + 257;
         const unsigned* s_dst = reinterpret_cast<const unsigned*>(fl + FA_OFF_DST + z);
         const float* s_hann = fl + FA_OFF_HANN + z;
         const float* s_tw1 = fl + FA_OFF_TW1 + z;   // [re / im][k 8][lane 64]: exp(-2 pi i lane k / 512)
@@ -243,9 +246,13 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                 const float ar = zr + yr, ai = zi - yi;
                 const float br = zi + yi, bi = zr - yr;
                 const float p0 = 0.25f * (ar * ar + ai * ai), p1 = 0.25f * (br * br + bi * bi);
+#if OWF_COMPACT_TAPS
                 const unsigned d = s_dst[i];                  // every FFT bin feeds at most two (neighbouring) triangular filters
                 pw0[d & 0xffffu] = p0; pw0[d >> 16] = p0;
                 pw1[d & 0xffffu] = p1; pw1[d >> 16] = p1;
+#else
+                pw0[i] = p0; pw1[i] = p1;
+#endif
             }
             wave_sync();
             {

@@ -2,8 +2,9 @@
 
 gpurun boxes have one GPU, so what can be exercised here is a world of ONE: librccl is bound at run time, a communicator is
 created, and the gather runs as a grouped send-to-self / receive-from-self on the handle's stream -- the same code path every
-rank takes at any world size (rank 0 receives from each rank including itself).  A second test forks a 2-rank world onto the
-same device when RCCL accepts that; it is skipped otherwise.  Multi-GPU scaling itself stays unmeasured on this pool."""
+rank takes at any world size (rank 0 receives from each rank including itself).  RCCL refuses two ranks on one device, so a second
+rank cannot be exercised on this pool; bench.py runs the same exchange at N > 1 as its `c_abi_gather` record (under a watchdog) when
+the driver has a multi-GPU node.  Multi-GPU scaling itself stays unmeasured on this pool."""
 import numpy as np
 import pytest
 
@@ -20,6 +21,7 @@ def test_world_of_one_gathers_through_rccl():
     eng = StreamEngine(S, heads, W.synthetic_embedding(1234))
     try:
         eng.comm_init(StreamEngine.comm_id(), 0, 1)
+        assert eng.comm_count() == 1                          # ncclCommCount: what bench.py reports as config.rccl_ranks
         with pytest.raises(Exception):                       # a second communicator on the same handle is refused
             eng.comm_init(StreamEngine.comm_id(), 0, 1)
         pcm = W.synthetic_pcm(S, 1280 * 8, seed=5)
