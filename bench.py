@@ -72,7 +72,7 @@ def pmc_traffic(kernel: str, streams: int, args):
     if args.valu or args.lds_mfma or streams != 131072:
         return None
     key = kernel + ("_rr" if args.fp32 else "_hx")
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
@@ -82,16 +82,22 @@ def pmc_traffic(kernel: str, streams: int, args):
 
 
 def issue_bound(kernel: str, streams: int, avg_ms: float, args):
-    """Composite bound of one launch from the committed PMC pass (profiles/r03_instr.json, tools/pmc.sh on this workload): wave
+    """Composite bound of one launch from the committed PMC pass (profiles/r04_instr.json, tools/pmc.sh on this workload): wave
     instructions per stream-step by pipe and the SIMD cycles they need at issue.  On this part a wave's VALU and MFMA work add up on
     its SIMD (tools/ubench/overlap_ubench.hip: a VALU instruction issues in 4 cycles, v_mfma_f32_16x16x32_f16 in 16, no overlap between
     the waves of a SIMD), so issue cycles = 4 VALU + 16 MFMA per stream-step; LDS and HBM are priced beside it and the largest of the
     fractions names what binds."""
     if args.valu or args.lds_mfma or args.fp32 or streams != 131072:
         return None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r03_instr.json")))[kernel + "_hx"]
-    except Exception:
+    t = src = None
+    for name in ("r04_instr.json", "r03_instr.json"):            # newest committed PMC pass first
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel + "_hx"]
+            src = name
+            break
+        except Exception:
+            continue
+    if t is None:
         return None
     per = lambda c: t[c] / streams
     mfma, valu, lds = per("SQ_INSTS_MFMA"), per("SQ_INSTS_VALU") - per("SQ_INSTS_MFMA"), per("SQ_INSTS_LDS")
@@ -107,8 +113,8 @@ def issue_bound(kernel: str, streams: int, avg_ms: float, args):
             "simd_cycles_per_stream_step": {"available_at_2.4GHz": round(avail, 0), "mfma_issue": round(16 * mfma, 0), "valu_issue": round(4 * valu, 0)},
             "frac_of_available": {k: (round(v, 4) if v is not None else None) for k, v in fr.items()}, "binds": binds,
             "lds_bank_conflict_frac": round(t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0), 4),
-            "source": "profiles/r03_instr.json (rocprofv3 --pmc passes of tools/pmc.sh on this workload); the chip holds ~1.95 GHz of its 2.4 GHz "
-                      "peak in this regime (GRBM_GUI_ACTIVE / duration), so ~0.81 of 'available' is the practical ceiling"}
+            "source": f"profiles/{src} (rocprofv3 --pmc passes of tools/pmc.sh on this workload); the chip sits at its power cap in this regime "
+                      "(profiles/r04_power.jsonl: 1,354 W of 1,400 W, sclk 1.99 of 2.4 GHz), so ~0.83 of 'available' is the practical ceiling"}
 
 
 def make_pcm_pool(torch, dev, S, n_pool, kind, gen, rank):
