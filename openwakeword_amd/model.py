@@ -93,6 +93,11 @@ def resolve_embedding(embedding: Optional[dict], seed: Optional[int]) -> dict:
     path = FEATURE_MODELS["embedding"]["model_path"]
     if os.path.exists(path):
         from . import onnx_ingest
+        # real model files: the log-mel front end of the HIP path is analytic, so the melspectrogram graph that sits next to the
+        # embedding network is VERIFIED to be that recipe (or the construction fails loudly: onnx_ingest.verify_melspectrogram)
+        mel_path = FEATURE_MODELS["melspectrogram"]["model_path"]
+        if os.path.exists(mel_path):
+            onnx_ingest.verify_melspectrogram(mel_path)
         return onnx_ingest.load_embedding(path)
     if seed is not None:
         return W.synthetic_embedding(seed)

@@ -10,7 +10,8 @@ Three graph families are recognised by structure, not by node names:
   Two such chains in one file = the gated form of hey_jarvis (`docs/models/hey_jarvis.md:38`).
 * embedding model (`notebooks/converting_google_speech_embedding_model.ipynb` cell 18): 20 Conv nodes (OIHW weights),
   19 BatchNormalization nodes -- or biases on the Conv nodes where an exporter folded the BatchNorm.
-* melspectrogram: analytic in this package; `check_melspectrogram` compares the file's filterbank with ours.
+* melspectrogram: analytic in this package (the kernel cannot load another recipe); `verify_melspectrogram` checks that the file
+  computes exactly that recipe -- window, hop, DFT, power, filter bank, 10 log10, amin, top_db -- or refuses.
 
 No real model file exists in this environment, so the structural assumptions are pinned by tests/test_onnx_ingest.py:
 two independent writers -- one in the plain idiom, one emitting the idioms tf2onnx (embedding model: NHWC <-> NCHW Transposes, Pad
@@ -720,13 +721,142 @@ def load_embedding(path: str) -> dict:
 
 
 def check_melspectrogram(path: str) -> dict:
-    """Compare the file's mel filterbank ([257, 32] MatMul operand) and DFT kernels with this package's analytic tables."""
+    """Compare the file's mel filterbank ([257, 32] MatMul operand) with this package's analytic table (see verify_melspectrogram
+    for the whole graph)."""
     g = load_graph(path)
     fb = [a for a in g["initializers"].values() if a.shape in ((W.N_BINS, W.N_MELS), (W.N_MELS, W.N_BINS))]
     if not fb:
         raise ValueError(f"{path}: no {W.N_BINS}x{W.N_MELS} filterbank initializer found")
     m = fb[0] if fb[0].shape == (W.N_BINS, W.N_MELS) else fb[0].T
     return {"filterbank_max_abs_diff": float(np.abs(m - W.mel_filterbank()).max()), "filterbank_max": float(np.abs(m).max())}
+
+
+def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
+    """`melspectrogram.onnx` (utils.py:84-87; built by notebooks/converting_google_speech_embedding_model.ipynb cell 15 from
+    torchlibrosa's Spectrogram + LogmelFilterBank with a patched power_to_db) CANNOT be loaded into the HIP front end -- that kernel is
+    analytic (Hann(400) centred in 512-sample frames, hop 160, 512-point DFT, power, Slaney filter bank 60..3800 Hz x 32, 10 log10
+    with amin 1e-10, clamp at the call's maximum - 80 dB).  What can be done is to VERIFY that the file computes exactly that, and to
+    refuse to run next to a file that does not (a different window, hop, filter bank or top_db would score differently in silence):
+
+      * two STFT convolutions with [257, 1, 512] kernels, stride 160, no padding, equal (up to sign) to window x cos / sin;
+      * power 2 (no Sqrt), one MatMul against a [257, 32] matrix equal to weights.mel_filterbank();
+      * a lower clamp of 1e-10 in front of one Log, constant factors behind it that multiply to 10 / ln 10, no reference offset;
+      * a ReduceMax of the result, 80 subtracted from it, and a Max / Clip against that;
+      * nothing else that does arithmetic.
+    Returns the measured differences; raises ValueError naming what differs."""
+    g = load_graph(path)
+    fl = _Flow(g, path)
+    nodes, inits = g["nodes"], g["initializers"]
+    shape_ops = {"Unsqueeze", "Squeeze", "Transpose", "Reshape", "Identity", "Cast", "Shape", "Gather", "Concat", "Slice", "Flatten",
+                 "ConstantOfShape", "Expand"}
+    known = shape_ops | {"Conv", "Mul", "Pow", "Add", "Sub", "Div", "MatMul", "Clip", "Max", "Log", "ReduceMax", "Pad"}
+    odd = sorted({n["op"] for n in nodes} - known)
+    if odd:
+        fl.refuse(f"melspectrogram graph contains {odd} (a Sqrt would mean a magnitude, not a power spectrogram); the HIP front end computes "
+                  "a fixed recipe and cannot follow it")
+    for n in nodes:
+        if n["op"] == "Pad":
+            pads = n["attrs"].get("pads")
+            if pads is None and len(n["inputs"]) > 1 and n["inputs"][1] in inits:
+                pads = inits[n["inputs"][1]].tolist()
+            if pads is None or any(int(v) for v in pads):
+                fl.refuse(f"the waveform is padded ({pads}): the reference frames with center=False")
+    # ---- STFT
+    convs = [n for n in nodes if n["op"] == "Conv"]
+    if len(convs) != 2:
+        fl.refuse(f"{len(convs)} Conv nodes, expected the real and imaginary STFT convolutions")
+    n_ = np.arange(W.N_FFT, dtype=np.float64)
+    win = np.zeros(W.N_FFT)
+    lo = (W.N_FFT - W.WIN) // 2
+    win[lo:lo + W.WIN] = W.hann_window().astype(np.float64)
+    ang = 2.0 * np.pi * np.outer(np.arange(W.N_BINS), n_) / W.N_FFT
+    basis = {"cos": win[None, :] * np.cos(ang), "sin": win[None, :] * np.sin(ang)}
+    found, worst = set(), 0.0
+    for n in convs:
+        w = inits.get(n["inputs"][1]) if len(n["inputs"]) > 1 else None
+        if w is None or w.size != W.N_BINS * W.N_FFT or w.shape[0] != W.N_BINS:
+            fl.refuse(f"STFT kernel of shape {None if w is None else tuple(w.shape)}, expected [{W.N_BINS}, 1, {W.N_FFT}]")
+        k = np.asarray(w, np.float64).reshape(W.N_BINS, W.N_FFT)
+        st = [int(v) for v in (n["attrs"].get("strides") or [1])]
+        if max(st) != W.HOP or any(v not in (1, W.HOP) for v in st):
+            fl.refuse(f"STFT stride {st}, the front end hops {W.HOP} samples")
+        if any(int(v) for v in (n["attrs"].get("pads") or [0])) or (n["attrs"].get("auto_pad", "NOTSET") or "NOTSET") not in ("NOTSET", "VALID"):
+            fl.refuse("the STFT convolutions pad their input (center=False expected)")
+        d = {name: min(np.abs(k - b).max(), np.abs(k + b).max()) for name, b in basis.items()}
+        name = min(d, key=d.get)
+        if d[name] > tol:
+            fl.refuse(f"an STFT kernel differs from Hann({W.WIN}) centred in {W.N_FFT} samples x cos / sin by {min(d.values()):.3g} "
+                      "(another window, window length or FFT size)")
+        found.add(name)
+        worst = max(worst, d[name])
+    if found != {"cos", "sin"}:
+        fl.refuse("the two STFT kernels are not a cos / sin pair")
+    # ---- power -> mel
+    mm = [n for n in nodes if n["op"] == "MatMul"]
+    fbs = [inits[i] for n in mm for i in n["inputs"] if i in inits and inits[i].shape in ((W.N_BINS, W.N_MELS), (W.N_MELS, W.N_BINS))]
+    if len(mm) != 1 or len(fbs) != 1:
+        fl.refuse(f"{len(mm)} MatMul nodes / {len(fbs)} [{W.N_BINS}, {W.N_MELS}] constants, expected one filter bank product")
+    fb = fbs[0] if fbs[0].shape == (W.N_BINS, W.N_MELS) else fbs[0].T
+    fb_diff = float(np.abs(fb.astype(np.float64) - W.mel_filterbank().astype(np.float64)).max())
+    if fb_diff > 1e-6:
+        fl.refuse(f"the mel filter bank differs from the Slaney bank 60..3800 Hz x {W.N_MELS} (slaney norm) by {fb_diff:.3g}")
+    for n in nodes:
+        if n["op"] == "Pow" and abs(_scalar(fl.const(n)) - 2.0) > 0:
+            fl.refuse(f"Pow exponent {_scalar(fl.const(n))}: a power-2 spectrogram is expected")
+    # ---- 10 log10(max(x, 1e-10)), no reference offset
+    logs = [n for n in nodes if n["op"] == "Log"]
+    if len(logs) != 1:
+        fl.refuse(f"{len(logs)} Log nodes, expected one")
+    src = fl.producer.get(logs[0]["inputs"][0])
+    amin = None
+    if src is not None and src["op"] == "Clip":
+        amin = src["attrs"].get("min")
+        if amin is None and len(src["inputs"]) > 1 and src["inputs"][1] in inits:
+            amin = _scalar(inits[src["inputs"][1]])
+    elif src is not None and src["op"] == "Max":
+        amin = _scalar(fl.const(src))
+    if amin is None or abs(float(amin) - 1e-10) > 1e-13:
+        fl.refuse(f"the logarithm's input is clamped at {amin}, expected amin = 1e-10")
+    factor, offset, cur = 1.0, 0.0, logs[0]["outputs"][0]
+    while True:
+        cons = fl.consumers.get(cur, [])
+        arith = [c for c in cons if c["op"] in ("Mul", "Div", "Sub", "Add") and fl.const(c) is not None and np.asarray(fl.const(c)).size == 1]
+        if len(cons) != 1 or not arith:
+            break
+        c, v = arith[0], _scalar(fl.const(arith[0]))
+        if c["op"] == "Mul":
+            factor, offset = factor * v, offset * v
+        elif c["op"] == "Div":
+            if c["inputs"][0] != cur:
+                break
+            factor, offset = factor / v, offset / v
+        elif c["op"] == "Add":
+            offset += v
+        else:
+            if c["inputs"][0] != cur:
+                break
+            offset -= v
+        cur = c["outputs"][0]
+    if abs(factor - 10.0 / np.log(10.0)) > 1e-5 or abs(offset) > 1e-6:
+        fl.refuse(f"the logarithm is scaled by {factor:.6g} and offset by {offset:.3g}; 10 log10 (x {10.0 / np.log(10.0):.6g}) with ref = 1 is expected")
+    # ---- top_db: clamp at (max over the call) - 80
+    rmax = [n for n in nodes if n["op"] == "ReduceMax"]
+    if len(rmax) != 1:
+        fl.refuse(f"{len(rmax)} ReduceMax nodes, expected the one of top_db")
+    if rmax[0]["attrs"].get("axes") not in (None, []):
+        fl.refuse(f"top_db reduces over axes {rmax[0]['attrs'].get('axes')}; the reference's patched power_to_db takes the maximum of the whole call")
+    t = rmax[0]["outputs"][0]
+    cons = fl.consumers.get(t, [])
+    if len(cons) != 1 or cons[0]["op"] not in ("Sub", "Add") or fl.const(cons[0]) is None:
+        fl.refuse("the call's maximum is not lowered by a constant top_db")
+    top_db = _scalar(fl.const(cons[0])) * (1.0 if cons[0]["op"] == "Sub" else -1.0)
+    if abs(top_db - 80.0) > 1e-6:
+        fl.refuse(f"top_db = {top_db:g}; the front end clamps at the call's maximum - 80 dB")
+    floor_t = cons[0]["outputs"][0]
+    clampers = [c for c in fl.consumers.get(floor_t, []) if c["op"] in ("Max", "Clip")]
+    if len(clampers) != 1 or cur not in clampers[0]["inputs"]:
+        fl.refuse("the log-mel values are not clamped from below at (maximum - top_db)")
+    return {"stft_kernel_max_abs_diff": worst, "filterbank_max_abs_diff": fb_diff, "log_factor": factor, "top_db": top_db}
 
 
 # ------------------------------------------------------------------------------------------- voice-activity network

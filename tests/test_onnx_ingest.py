@@ -606,3 +606,66 @@ def test_vad_reader_turns_every_parsing_failure_into_a_refusal(tmp_path):
     open(path, "wb").write(b"\x3a\xff\xff\xff\x0f" + b"\x00" * 10)                     # a length prefix that runs past the end of the file
     with pytest.raises(ValueError):
         onnx_ingest.load_vad(path)
+
+
+# ---- melspectrogram.onnx: the HIP front end is analytic, so the file is VERIFIED, not loaded ---------------------------------------
+def write_melspectrogram(path, win_len=400, n_fft=512, hop=160, top_db=80.0, amin=1e-10, power=2, fb=None, log_factor=None,
+                         reduce_axes=None, pad=0):
+    """torch.onnx.export of torchlibrosa's Spectrogram + LogmelFilterBank as the notebook builds them (cell 15): Unsqueeze -> two
+    Conv1d (window x cos / -sin, stride hop) -> squares -> Add -> MatMul(melW) -> Clip(amin) -> Log -> Div(ln 10) -> Mul(10) ->
+    ReduceMax -> Sub(top_db) -> Max."""
+    g = G2("input", opset=12)
+    n = np.arange(n_fft, dtype=np.float64)
+    win = np.zeros(n_fft)
+    lo = (n_fft - win_len) // 2
+    win[lo:lo + win_len] = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_len) / win_len)
+    ang = 2.0 * np.pi * np.outer(np.arange(n_fft // 2 + 1), n) / n_fft
+    x = g.op("Unsqueeze", ["input"], axes=[1])
+    if pad:
+        x = g.op("Pad", [x, g.const(np.array([0, 0, pad, 0, 0, pad], np.int64), "pads")], mode="reflect")
+    re = g.op("Conv", [x, g.const((win * np.cos(ang))[:, None, :], "conv_real.weight")], strides=[hop], dilations=[1], group=1, kernel_shape=[n_fft], pads=[0, 0])
+    im = g.op("Conv", [x, g.const((-win * np.sin(ang))[:, None, :], "conv_imag.weight")], strides=[hop], dilations=[1], group=1, kernel_shape=[n_fft], pads=[0, 0])
+    two = g.const(np.array(2.0, np.float32), "two")
+    p = g.op("Add", [g.op("Pow", [re, two]), g.op("Pow", [im, two])])
+    if power == 1:
+        p = g.op("Sqrt", [p])
+    p = g.op("Transpose", [g.op("Unsqueeze", [p], axes=[1])], perm=[0, 1, 3, 2])
+    mel = g.op("MatMul", [p, g.const(W.mel_filterbank() if fb is None else fb, "melW")])
+    lg = g.op("Log", [g.op("Clip", [mel, g.const(np.array(amin, np.float32), "amin")])])
+    if log_factor is None:
+        db = g.op("Mul", [g.op("Div", [lg, g.const(np.array(np.log(10.0), np.float32), "ln10")]), g.const(np.array(10.0, np.float32), "ten")])
+    else:
+        db = g.op("Mul", [lg, g.const(np.array(log_factor, np.float32), "k")])
+    mx = g.op("ReduceMax", [db], keepdims=0) if reduce_axes is None else g.op("ReduceMax", [db], axes=reduce_axes, keepdims=1)
+    out = g.op("Max", [db, g.op("Sub", [mx, g.const(np.array(top_db, np.float32), "top_db")])])
+    g.outputs = [out]
+    g.save(path)
+
+
+def test_melspectrogram_file_is_verified_against_the_analytic_front_end(tmp_path):
+    path = os.path.join(tmp_path, "melspectrogram.onnx")
+    write_melspectrogram(path)
+    res = onnx_ingest.verify_melspectrogram(path)
+    assert res["stft_kernel_max_abs_diff"] < 1e-6 and res["filterbank_max_abs_diff"] == 0.0
+    assert abs(res["log_factor"] - 10.0 / np.log(10.0)) < 1e-6 and res["top_db"] == 80.0
+    write_melspectrogram(path, log_factor=10.0 / np.log(10.0))             # the scaling as one constant
+    onnx_ingest.verify_melspectrogram(path)
+    htk = W.mel_filterbank().copy()
+    htk[40:60] *= 1.05
+    for kw, why in ((dict(win_len=512), "another window"), (dict(hop=128), "stride"), (dict(top_db=100.0), "top_db = 100"),
+                    (dict(amin=1e-6), "amin"), (dict(power=1), "Sqrt"), (dict(fb=htk), "filter bank differs"),
+                    (dict(log_factor=1.0), "scaled by 1"), (dict(reduce_axes=[3]), "axes"), (dict(pad=256), "padded")):
+        write_melspectrogram(path, **kw)
+        with pytest.raises(ValueError, match=why):
+            onnx_ingest.verify_melspectrogram(path)
+    # ... and the recipe the file is held to IS the one the oracle (and with it the kernels) compute: evaluate the verified graph's
+    # formula with numpy -- frames by its stride, its two kernels, power, its filter bank, 10 log10, the clamp -- and compare
+    x = (np.random.default_rng(3).normal(0, 3000, 1760)).astype(np.float64)
+    n_ = np.arange(512)
+    win = np.zeros(512); win[56:456] = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(400) / 400)
+    ang = 2.0 * np.pi * np.outer(np.arange(257), n_) / 512
+    frames = np.stack([x[160 * t:160 * t + 512] for t in range((1760 - 512) // 160 + 1)])
+    power = (frames @ (win * np.cos(ang)).T) ** 2 + (frames @ (win * np.sin(ang)).T) ** 2
+    db = 10.0 * np.log10(np.maximum(power @ W.mel_filterbank().astype(np.float64), 1e-10))
+    db = np.maximum(db, db.max() - 80.0)
+    np.testing.assert_allclose(O.mel_stage(x[None].astype(np.float32), np.float64)[0, 0], db, rtol=0, atol=1e-6)

@@ -43,6 +43,7 @@ def both(golden):
                           melspec_model_path=os.path.join(MODELS_DIR, "melspectrogram.onnx"),
                           embedding_model_path=os.path.join(MODELS_DIR, "embedding_model.onnx"))
     assert onnx_ingest.check_melspectrogram(os.path.join(MODELS_DIR, "melspectrogram.onnx"))["filterbank_max_abs_diff"] < 1e-6
+    onnx_ingest.verify_melspectrogram(os.path.join(MODELS_DIR, "melspectrogram.onnx"))       # window, hop, DFT, power, 10 log10, amin, top_db
     weights = {"embedding": onnx_ingest.load_embedding(os.path.join(MODELS_DIR, "embedding_model.onnx")),
                "heads": {os.path.splitext(os.path.basename(p))[0]: onnx_ingest.load_head(p) for p in paths}}
     hip_model = amd.Model(wakeword_models=list(weights["heads"]), weights=weights)
