@@ -96,8 +96,13 @@ def resolve_embedding(embedding: Optional[dict], seed: Optional[int]) -> dict:
         # real model files: the log-mel front end of the HIP path is analytic, so the melspectrogram graph that sits next to the
         # embedding network is VERIFIED to be that recipe (or the construction fails loudly: onnx_ingest.verify_melspectrogram)
         mel_path = FEATURE_MODELS["melspectrogram"]["model_path"]
-        if os.path.exists(mel_path):
-            onnx_ingest.verify_melspectrogram(mel_path)
+        if os.path.exists(mel_path) and os.environ.get("OWW_TRUST_MELSPECTROGRAM") != "1":
+            try:
+                onnx_ingest.verify_melspectrogram(mel_path)
+            except ValueError as e:
+                raise ValueError(f"{e}.  The HIP front end computes the published recipe only; if this graph is known to be equivalent "
+                                 "(an exporter idiom the verifier does not know), set OWW_TRUST_MELSPECTROGRAM=1 and hold the result to "
+                                 "tests/test_real_reference.py") from e
         return onnx_ingest.load_embedding(path)
     if seed is not None:
         return W.synthetic_embedding(seed)
