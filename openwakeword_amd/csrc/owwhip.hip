@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <dlfcn.h>
 #include <string>
 #include <vector>
@@ -51,6 +53,99 @@ int fail(int code, const char* fmt, ...) {
         hipError_t e__ = (expr);                                                             \
         if (e__ != hipSuccess) return fail(OWW_EHIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
+
+// ---- device allocations.  OWW_GUARD_ALLOC=1|2 is a debugging aid: every device buffer of the library then lives in its own
+// virtual range (hipMemAddressReserve / hipMemMap) with an UNMAPPED granule on both sides and the buffer pushed against the upper (1)
+// or the lower (2) end of its mapping, so that a kernel that reads or writes outside a buffer faults on the spot instead of touching
+// whatever hipMalloc happened to place next to it; each allocation prints its address range and the source line that made it.
+struct GuardRange { char* base; size_t reserve, mapped; hipMemGenericAllocationHandle_t hnd; };
+std::mutex g_guard_mu;
+std::unordered_map<void*, GuardRange> g_guard;
+int guard_mode() {
+    static const int mode = [] { const char* e = getenv("OWW_GUARD_ALLOC"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+hipError_t guard_alloc(void** p, size_t n, int line) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    GuardRange g{};
+    g.mapped = (std::max<size_t>(n, 1) + gran - 1) / gran * gran;
+    g.reserve = g.mapped + 2 * gran;
+    void* base = nullptr;
+    if ((e = hipMemAddressReserve(&base, g.reserve, gran, nullptr, 0)) != hipSuccess) return e;
+    g.base = static_cast<char*>(base);
+    if ((e = hipMemCreate(&g.hnd, g.mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(base, g.reserve); return e; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemMap(g.base + gran, g.mapped, 0, g.hnd, 0)) != hipSuccess ||
+        (e = hipMemSetAccess(g.base + gran, g.mapped, &acc, 1)) != hipSuccess) {
+        (void)hipMemRelease(g.hnd); (void)hipMemAddressFree(base, g.reserve); return e;
+    }
+    char* user = guard_mode() == 2 ? g.base + gran : g.base + gran + g.mapped - (n + 15) / 16 * 16;
+    fprintf(stderr, "[owwhip guard] line %d: %zu bytes at [%p, %p), mapped [%p, %p)\n", line, n, (void*)user, (void*)(user + n),
+            (void*)(g.base + gran), (void*)(g.base + gran + g.mapped));
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[user] = g;
+    *p = user;
+    return hipSuccess;
+}
+template <class T>
+hipError_t dev_alloc(T** p, size_t n, int line = __builtin_LINE()) {
+    if (!guard_mode()) return hipMalloc(reinterpret_cast<void**>(p), n);
+    return guard_alloc(reinterpret_cast<void**>(p), n, line);
+}
+hipError_t dev_free(void* p) {
+    if (!guard_mode() || !p) return hipFree(p);
+    GuardRange g;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guard.find(p);
+        if (it == g_guard.end()) return hipFree(p);
+        g = it->second;
+        g_guard.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    const size_t gran = (g.reserve - g.mapped) / 2;
+    (void)hipMemUnmap(g.base + gran, g.mapped);
+    (void)hipMemRelease(g.hnd);
+    return hipMemAddressFree(g.base, g.reserve);
+}
+
+// Copies between host memory and a hipMemMap'ed range: the runtime's path for PAGEABLE host memory drops bytes at some sizes /
+// alignments (tools/experiments/vmm_copy_probe.hip: 5,000,000 bytes from a range that ends at its mapping's end), its pinned path does
+// not -- under OWW_GUARD_ALLOC host <-> device copies therefore go through a page-locked bounce buffer, synchronously.
+hipError_t guard_copy(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t st) {
+    void* pin = nullptr;
+    hipError_t e = hipHostMalloc(&pin, std::max<size_t>(n, 1), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (kind == hipMemcpyHostToDevice) {
+        memcpy(pin, src, n);
+        e = hipMemcpyAsync(dst, pin, n, kind, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    } else {
+        e = hipMemcpyAsync(pin, src, n, kind, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) memcpy(dst, pin, n);
+    }
+    (void)hipHostFree(pin);
+    return e;
+}
+inline hipError_t copy_async(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t st) {
+    if (guard_mode() && n && (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToHost)) return guard_copy(dst, src, n, kind, st);
+    return hipMemcpyAsync(dst, src, n, kind, st);
+}
+inline hipError_t copy_sync(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    if (guard_mode() && n && (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToHost)) return guard_copy(dst, src, n, kind, nullptr);
+    return hipMemcpy(dst, src, n, kind);
+}
 
 struct LayerDef { int kh, kw, cin, cout; };
 constexpr int kSmallLaunchWgs = 2 * 256;      // stage / heads launches of at most two workgroups per CU (MI355X: 256 CUs) use the deep weight rings
@@ -652,10 +747,10 @@ int run_cnn(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
 
 int ensure_scratch(oww_ctx* h, size_t streams) {
     if (streams <= h->scratch_streams) return 0;
-    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    if (h->d_scratch) (void)dev_free(h->d_scratch);
     h->d_scratch = nullptr; h->scratch_streams = 0;
     const size_t n = streams * std::max<size_t>(1, h->nets.size()) * 2 * (size_t)std::max(h->generic_hmax, 1);
-    HIPCHK(hipMalloc(&h->d_scratch, n * sizeof(float)));
+    HIPCHK(dev_alloc(&h->d_scratch, n * sizeof(float)));
     h->scratch_streams = streams;
     return 0;
 }
@@ -779,8 +874,8 @@ int do_reset(oww_ctx* h, const int* d_ids, int n, const float* d_featinit) {
 }
 
 template <class T>
-int dalloc(T** p, size_t n, bool zero = true) {
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
+int dalloc(T** p, size_t n, bool zero = true, int line = __builtin_LINE()) {
+    HIPCHK(dev_alloc(p, std::max<size_t>(n, 1) * sizeof(T), line));
     if (zero) HIPCHK(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
     return 0;
 }
@@ -832,7 +927,7 @@ int rccl_load() {
 void comm_release(oww_ctx* h);
 
 void free_all(oww_ctx* h) {
-    auto fr = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    auto fr = [](auto*& p) { if (p) { (void)dev_free((void*)p); p = nullptr; } };
     fr(h->d_w); fr(h->d_allnets); fr(h->d_generic); fr(h->d_scratch);
     for (auto& g : h->groups) fr(g.d_nets);
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
@@ -840,19 +935,19 @@ void free_all(oww_ctx* h) {
     fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin); fr(h->d_vadx); fr(h->d_vadhc); fr(h->d_vadlast); fr(h->d_verw); fr(h->d_verb); fr(h->d_verthr); fr(h->d_verT);
     fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
     h->save_floats = 0;
-    if (h->d_on) { (void)hipFree(h->d_on); h->d_on = nullptr; }
+    if (h->d_on) { (void)dev_free(h->d_on); h->d_on = nullptr; }
     for (int b = 0; b < 4; ++b) {
         if (h->blk_stream[b]) { (void)hipStreamSynchronize(h->blk_stream[b]); (void)hipStreamDestroy(h->blk_stream[b]); h->blk_stream[b] = nullptr; }
         if (h->blk_done[b]) { (void)hipEventDestroy(h->blk_done[b]); h->blk_done[b] = nullptr; }
     }
     if (h->blk_fork) { (void)hipEventDestroy(h->blk_fork); h->blk_fork = nullptr; }
-    if (h->d_lists) { (void)hipFree(h->d_lists); h->d_lists = nullptr; }
+    if (h->d_lists) { (void)dev_free(h->d_lists); h->d_lists = nullptr; }
     for (int i = 0; i < 2; ++i) {
         if (h->h_lists[i]) { (void)hipHostFree(h->h_lists[i]); h->h_lists[i] = nullptr; }
         if (h->lists_ev[i]) { (void)hipEventDestroy(h->lists_ev[i]); h->lists_ev[i] = nullptr; }
     }
     h->lists_cap = 0;
-    if (h->d_rs) { (void)hipFree(h->d_rs); h->d_rs = nullptr; h->rs_bytes = 0; }
+    if (h->d_rs) { (void)dev_free(h->d_rs); h->d_rs = nullptr; h->rs_bytes = 0; }
     if (h->h_range) { (void)hipHostFree(h->h_range); h->h_range = nullptr; h->d_range = nullptr; }
     for (auto& sl : h->slot) {
         fr(sl.d_pcm); fr(sl.d_scores);
@@ -924,14 +1019,14 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
     if ((long long)n_act * 8 > (long long)S * 7) return -1;
     const size_t need = (size_t)S + S / 2 + S / 4 + S / 8 + S / 16 + 64;       // (regions of the five lists, see below)
     if (need > h->lists_cap) {
-        if (h->d_lists) (void)hipFree(h->d_lists);
+        if (h->d_lists) (void)dev_free(h->d_lists);
         h->d_lists = nullptr;
         for (int i = 0; i < 2; ++i) {
             if (h->lists_ev[i]) (void)hipEventSynchronize(h->lists_ev[i]);
             if (h->h_lists[i]) { (void)hipHostFree(h->h_lists[i]); h->h_lists[i] = nullptr; }
         }
         h->lists_cap = 0;
-        if (hipMalloc(&h->d_lists, need * sizeof(int)) != hipSuccess) return fail(OWW_ENOMEM, "oww_step_masked: out of device memory") - 100;
+        if (dev_alloc(&h->d_lists, need * sizeof(int)) != hipSuccess) return fail(OWW_ENOMEM, "oww_step_masked: out of device memory") - 100;
         for (int i = 0; i < 2; ++i) {
             if (hipHostMalloc((void**)&h->h_lists[i], need * sizeof(int), hipHostMallocDefault) != hipSuccess) return fail(OWW_ENOMEM, "oww_step_masked: out of page-locked memory") - 100;
             if (!h->lists_ev[i] && hipEventCreateWithFlags(&h->lists_ev[i], hipEventDisableTiming) != hipSuccess) return fail(OWW_EHIP, "hipEventCreate failed") - 100;
@@ -978,7 +1073,7 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
         off += (size_t)n[k];
     }
     if (off) {
-        if (hipMemcpyAsync(h->d_lists, out, off * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(OWW_EHIP, "oww_step_masked: list upload failed") - 100;
+        if (copy_async(h->d_lists, out, off * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(OWW_EHIP, "oww_step_masked: list upload failed") - 100;
         (void)hipEventRecord(h->lists_ev[turn], h->stream);
     }
     return n_act;
@@ -1046,15 +1141,15 @@ int park_state(oww_ctx* h, int n_streams, bool save) {
     size_t need = h->Spad + n8 * (size_t)h->TR * 96;
     for (int a = 0; a < N_STATE; ++a) need += n8 * (size_t)h->state_len[a];
     if (save && need > h->save_floats) {
-        if (h->d_save) (void)hipFree(h->d_save);
+        if (h->d_save) (void)dev_free(h->d_save);
         h->d_save = nullptr; h->save_floats = 0;
-        if (hipMalloc(&h->d_save, need * sizeof(float)) != hipSuccess) return fail(OWW_ENOMEM, "out of device memory for %zu parked state bytes", need * sizeof(float));
+        if (dev_alloc(&h->d_save, need * sizeof(float)) != hipSuccess) return fail(OWW_ENOMEM, "out of device memory for %zu parked state bytes", need * sizeof(float));
         h->save_floats = need;
     }
     if (!h->d_save || need > h->save_floats) return fail(OWW_ESTATE, "park_state: nothing parked");
     float* q = h->d_save;
     auto cp = [&](void* live, size_t nfl) -> int {
-        HIPCHK(hipMemcpyAsync(save ? (void*)q : live, save ? live : (void*)q, nfl * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(copy_async(save ? (void*)q : live, save ? live : (void*)q, nfl * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         q += nfl;
         return 0;
     };
@@ -1151,10 +1246,10 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
         cal.NL = t->NL;
         int off[21]; off[0] = 0;
         for (int l = 0; l < 20; ++l) off[l + 1] = off[l] + kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2];
-        if (hipMalloc(&d_max, 20 * sizeof(unsigned)) != hipSuccess || hipMalloc(&d_off, sizeof off) != hipSuccess ||
-            hipMalloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_commit: out of device memory (calibration)"); break; }
+        if (dev_alloc(&d_max, 20 * sizeof(unsigned)) != hipSuccess || dev_alloc(&d_off, sizeof off) != hipSuccess ||
+            dev_alloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_commit: out of device memory (calibration)"); break; }
         if (hipMemsetAsync(d_max, 0, 20 * sizeof(unsigned), t->stream) != hipSuccess ||
-            hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration setup failed"); break; }
+            copy_async(d_off, off, sizeof off, hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration setup failed"); break; }
         auto absmax = [&]() { hipLaunchKernelGGL(layer_absmax_kernel, dim3(20, CAL_NP), dim3(256), 0, t->stream, t->d_dbg, (size_t)DBG_FLOATS, d_off, d_max); };
         // (a) the all-ones mel history every stream starts from (utils.py:165): the handle sits in that steady state after its commit
         hipLaunchKernelGGL(fill_kernel, dim3(CAL_NP), dim3(256), 0, t->stream, t->d_mel, (size_t)CAL_NP * 256, 1.0f);
@@ -1168,15 +1263,15 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
             if (it == 0 && bt > 0 && (rc = do_reset(t, nullptr, CAL_NP, nullptr))) break;
             if (getenv("OWW_DEBUG_CALIB")) { const hipError_t e = hipStreamSynchronize(t->stream); fprintf(stderr, "calibrate: probe step %d of %d (%s)\n", bt, cal.nb * CAL_T, hipGetErrorString(e)); }
             // (the upload waits for the previous step: one staging buffer, stream-ordered copies from pageable memory are synchronous)
-            if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
+            if (copy_async(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
             if ((rc = probe_step(t, d_chunk, true))) break;
             absmax();
-            if (hipMemcpyAsync(&cal.ref_emb[(size_t)bt * CAL_NP * 96], t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
-                (t->NL > 0 && hipMemcpyAsync(&cal.ref_raw[(size_t)bt * CAL_NP * t->NL], t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+            if (copy_async(&cal.ref_emb[(size_t)bt * CAL_NP * 96], t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+                (t->NL > 0 && copy_async(&cal.ref_raw[(size_t)bt * CAL_NP * t->NL], t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
         }
         if (rc) break;
         unsigned mx[20];
-        if (hipMemcpyAsync(mx, d_max, sizeof mx, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration run failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (copy_async(mx, d_max, sizeof mx, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration run failed: %s", hipGetErrorString(hipGetLastError())); break; }
         for (int l = 0; l < 20; ++l) {
             float m; memcpy(&m, &mx[l], 4);
             if (!std::isfinite(m)) { rc = fail(OWW_EINVAL, "oww_commit: layer %d of the embedding network produces non-finite activations in exact fp32 -- the weights are broken", l); break; }
@@ -1215,9 +1310,9 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
             h->hx_xexp[st] = h->hx_ein[nxt] - h->hx_e[last];
         }
     } while (0);
-    if (d_max) (void)hipFree(d_max);
-    if (d_off) (void)hipFree(d_off);
-    if (d_chunk) (void)hipFree(d_chunk);
+    if (d_max) (void)dev_free(d_max);
+    if (d_off) (void)dev_free(d_off);
+    if (d_chunk) (void)dev_free(d_chunk);
     const std::string keep = g_err;
     (void)oww_destroy(t);
     if (rc) g_err = keep;
@@ -1228,21 +1323,21 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
 // replay of the probes on the handle's own (f16-split) kernels; leaves the first CAL_NP streams dirty -- the caller resets all state
 int selftest_hx(oww_ctx* h, const HxCalib& cal) {
     int16_t* d_chunk = nullptr;
-    if (hipMalloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) return fail(OWW_ENOMEM, "oww_commit: out of device memory (self-test)");
+    if (dev_alloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) return fail(OWW_ENOMEM, "oww_commit: out of device memory (self-test)");
     std::vector<float> emb((size_t)cal.nb * CAL_T * CAL_NP * 96), raw((size_t)cal.nb * CAL_T * CAL_NP * std::max(h->NL, 1));
     int rc = 0;
     float* saved_dbg = h->d_dbg; h->d_dbg = nullptr;
     for (int bt = 0; bt < cal.nb * CAL_T && !rc; ++bt) {
         if (bt % CAL_T == 0 && bt > 0 && (rc = do_reset(h, nullptr, CAL_NP, nullptr))) break;
         if (getenv("OWW_DEBUG_CALIB")) { const hipError_t e = hipStreamSynchronize(h->stream); fprintf(stderr, "self-test: probe step %d of %d (%s)\n", bt, cal.nb * CAL_T, hipGetErrorString(e)); }
-        if (hipMemcpyAsync(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
+        if (copy_async(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
         if ((rc = probe_step(h, d_chunk, true))) break;
-        if (hipMemcpyAsync(&emb[(size_t)bt * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            (h->NL > 0 && hipMemcpyAsync(&raw[(size_t)bt * CAL_NP * h->NL], h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+        if (copy_async(&emb[(size_t)bt * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            (h->NL > 0 && copy_async(&raw[(size_t)bt * CAL_NP * h->NL], h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
     }
     h->d_dbg = saved_dbg;
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(OWW_EHIP, "oww_commit: self-test run failed: %s", hipGetErrorString(hipGetLastError()));
-    (void)hipFree(d_chunk);
+    (void)dev_free(d_chunk);
     if (rc) return rc;
     float err = 0.f, ref = 0.f, serr = 0.f;
     bool finite = true;
@@ -1694,8 +1789,8 @@ int oww_commit(oww_ctx* h) {
         o_vwd = hb.add(q, 64); q += 64;
         h->vad_bd = *q;
     }
-    HIPCHK(hipMalloc(&h->d_w, hb.data.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(dev_alloc(&h->d_w, hb.data.size() * sizeof(float)));
+    HIPCHK(copy_sync(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
     h->d_hann = h->d_w + o_hann; h->d_mstart = reinterpret_cast<const int*>(h->d_w + o_start); h->d_taps = h->d_w + o_taps;
     h->d_meloff = reinterpret_cast<const int*>(h->d_w + o_meloff); h->d_meldst = reinterpret_cast<const unsigned*>(h->d_w + o_meldst);
     if (h->vad) {
@@ -1725,15 +1820,15 @@ int oww_commit(oww_ctx* h) {
         std::vector<NetDesc> all;
         for (size_t ni = 0; ni < h->nets.size(); ++ni) all.push_back(make_desc((int)ni, 0));
         h->host_descs = all;
-        HIPCHK(hipMalloc(&h->d_allnets, all.size() * sizeof(NetDesc)));
-        HIPCHK(hipMemcpy(h->d_allnets, all.data(), all.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
+        HIPCHK(dev_alloc(&h->d_allnets, all.size() * sizeof(NetDesc)));
+        HIPCHK(copy_sync(h->d_allnets, all.data(), all.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
     }
     for (size_t gi = 0; gi < h->groups.size(); ++gi) {
         FastGroup& g = h->groups[gi];
         std::vector<NetDesc> ds;
         for (int i = 0; i < g.n_nets; ++i) ds.push_back(make_desc(g.nets[i], 64 * i));
-        HIPCHK(hipMalloc(&g.d_nets, ds.size() * sizeof(NetDesc)));
-        HIPCHK(hipMemcpy(g.d_nets, ds.data(), ds.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
+        HIPCHK(dev_alloc(&g.d_nets, ds.size() * sizeof(NetDesc)));
+        HIPCHK(copy_sync(g.d_nets, ds.data(), ds.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
         g.d_w1pk = h->d_w + goff[gi].w1pk; g.d_b1cat = h->d_w + goff[gi].b1cat;
         if (h->hx) { g.d_w1hx = h->d_w + goff[gi].w1hx; for (size_t o : goff[gi].w2hx) g.d_w2hx.push_back(h->d_w + o); }
         if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
@@ -1783,7 +1878,7 @@ int oww_commit(oww_ctx* h) {
     if (int rc = dalloc(&h->d_threshold, (size_t)std::max(h->NL, 1))) return rc;
     {
         std::vector<float> nanv(std::max(h->NL, 1), NAN);
-        HIPCHK(hipMemcpy(h->d_threshold, nanv.data(), nanv.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(h->d_threshold, nanv.data(), nanv.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (h->cfg.debug_layers) if (int rc = dalloc(&h->d_dbg, SP * DBG_FLOATS)) return rc;
     if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
@@ -1831,7 +1926,7 @@ int oww_commit(oww_ctx* h) {
             if (int rc = run_cnn(h, warm, 256, 0)) return rc;
         h->d_dbg = saved_dbg;
         for (int a = 0; a < N_STATE; ++a)
-            HIPCHK(hipMemcpyAsync(h->d_tmpl[a], h->d_state[a], (size_t)h->state_len[a] * (h->rr ? kStateSpgRr[a] : 1) * sizeof(float),
+            HIPCHK(copy_async(h->d_tmpl[a], h->d_state[a], (size_t)h->state_len[a] * (h->rr ? kStateSpgRr[a] : 1) * sizeof(float),
                                   hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemsetAsync(h->d_mel, 0, SP * 8 * h->kmax * 32 * sizeof(float), h->stream));
         HIPCHK(hipMemsetAsync(h->d_emb, 0, SP * 96 * sizeof(float), h->stream));
@@ -1860,7 +1955,7 @@ int oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* ini
     HIPCHK(hipSetDevice(h->cfg.device));
     const float* d_init = nullptr;
     if (init_features) {
-        HIPCHK(hipMemcpyAsync(h->d_featinit, init_features, (size_t)h->TR * 96 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(h->d_featinit, init_features, (size_t)h->TR * 96 * sizeof(float), hipMemcpyHostToDevice, h->stream));
         d_init = h->d_featinit;
     }
     if (!stream_ids) {
@@ -1870,12 +1965,12 @@ int oww_reset(oww_ctx* h, const int32_t* stream_ids, int32_t n, const float* ini
         for (int i = 0; i < n; ++i)
             if (stream_ids[i] < 0 || stream_ids[i] >= h->S) return fail(OWW_EINVAL, "oww_reset: stream id %d out of range", stream_ids[i]);
         if (n > h->ids_cap) {
-            if (h->d_ids) (void)hipFree(h->d_ids);
+            if (h->d_ids) (void)dev_free(h->d_ids);
             h->d_ids = nullptr; h->ids_cap = 0;
-            HIPCHK(hipMalloc(&h->d_ids, (size_t)n * sizeof(int)));
+            HIPCHK(dev_alloc(&h->d_ids, (size_t)n * sizeof(int)));
             h->ids_cap = n;
         }
-        HIPCHK(hipMemcpyAsync(h->d_ids, stream_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(h->d_ids, stream_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (int rc = do_reset(h, h->d_ids, n, d_init)) return rc;
     }
     HIPCHK(hipStreamSynchronize(h->stream));     // host buffers may be reused by the caller
@@ -1891,8 +1986,8 @@ int oww_set_postproc(oww_ctx* h, const int32_t* patience, const float* threshold
     std::vector<float> thr(std::max(h->NL, 1), NAN);
     if (patience) for (int i = 0; i < h->NL; ++i) pat[i] = patience[i];
     if (threshold) for (int i = 0; i < h->NL; ++i) thr[i] = threshold[i];
-    HIPCHK(hipMemcpyAsync(h->d_patience, pat.data(), pat.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_threshold, thr.data(), thr.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(copy_async(h->d_patience, pat.data(), pat.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(copy_async(h->d_threshold, thr.data(), thr.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->debounce_frames = debounce_frames;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // baked-in scalar changed
@@ -1912,7 +2007,7 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
     const bool graphable = h->want_graph && n_chunks == 1 && !h->timing;
     const int16_t* d_pcm = pcm;
     if (!pcm_on_device || graphable) {
-        HIPCHK(hipMemcpyAsync(h->d_pcm, pcm, n_pcm * sizeof(int16_t), pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(h->d_pcm, pcm, n_pcm * sizeof(int16_t), pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         d_pcm = h->d_pcm;
     }
     if (graphable) {
@@ -1933,7 +2028,7 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
     }
     if (scores) {
         const size_t nb = (size_t)h->S * h->NL * sizeof(float);
-        if (nb) HIPCHK(hipMemcpyAsync(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        if (nb) HIPCHK(copy_async(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
         if (!scores_on_device) {
             HIPCHK(hipStreamSynchronize(h->stream));
             if (int rc = range_check(h, "oww_step")) return rc;
@@ -1955,14 +2050,14 @@ int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uin
     HIPCHK(hipSetDevice(h->cfg.device));
     h->k_last = 1;
     if (!h->d_on) {
-        HIPCHK(hipMalloc(&h->d_on, h->Spad));
+        HIPCHK(dev_alloc(&h->d_on, h->Spad));
         HIPCHK(hipMemsetAsync(h->d_on, 0, h->Spad, h->stream));
     }
     // (always through the handle's own buffer: the kernels index it up to the padded stream count)
-    HIPCHK(hipMemcpyAsync(h->d_on, stream_on, h->S, stream_on_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    HIPCHK(copy_async(h->d_on, stream_on, h->S, stream_on_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     const int16_t* d_pcm = pcm;
     if (!pcm_on_device || (reinterpret_cast<uintptr_t>(pcm) & 15)) {
-        HIPCHK(hipMemcpyAsync(h->d_pcm, pcm, (size_t)h->S * OWW_CHUNK * sizeof(int16_t),
+        HIPCHK(copy_async(h->d_pcm, pcm, (size_t)h->S * OWW_CHUNK * sizeof(int16_t),
                               pcm_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         d_pcm = h->d_pcm;
     }
@@ -1978,7 +2073,7 @@ int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uin
     if (rc) return rc;
     if (scores) {
         const size_t nb = (size_t)h->S * h->NL * sizeof(float);
-        if (nb) HIPCHK(hipMemcpyAsync(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        if (nb) HIPCHK(copy_async(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
         if (!scores_on_device) {
             HIPCHK(hipStreamSynchronize(h->stream));
             if (int rc2 = range_check(h, "oww_step_masked")) return rc2;
@@ -1994,8 +2089,8 @@ static int ensure_ingest(oww_ctx* h) {
     HIPCHK(hipStreamCreateWithFlags(&h->down_stream, hipStreamNonBlocking));
     const size_t nb = (size_t)h->S * std::max(h->NL, 1) * sizeof(float);
     for (auto& sl : h->slot) {
-        HIPCHK(hipMalloc(&sl.d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax * sizeof(int16_t)));
-        HIPCHK(hipMalloc(&sl.d_scores, nb));
+        HIPCHK(dev_alloc(&sl.d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax * sizeof(int16_t)));
+        HIPCHK(dev_alloc(&sl.d_scores, nb));
         HIPCHK(hipHostMalloc((void**)&sl.h_scores, nb, hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&sl.h_on, h->S, hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
@@ -2029,16 +2124,16 @@ static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const u
     auto& sl = h->slot[h->n_submit & 1];
     if (sl.busy) return fail(OWW_ESTATE, "oww_submit: two steps already in flight, call oww_collect first");
     const size_t n_pcm = (size_t)h->S * OWW_CHUNK * n_chunks;
-    HIPCHK(hipMemcpyAsync(sl.d_pcm, pcm, n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, h->up_stream));
+    HIPCHK(copy_async(sl.d_pcm, pcm, n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, h->up_stream));
     HIPCHK(hipEventRecord(sl.up, h->up_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, sl.up, 0));
     if (stream_on) {                                   // (the mask is small: copied on the compute stream, ordered before this step's kernels)
         if (!h->d_on) {
-            HIPCHK(hipMalloc(&h->d_on, h->Spad));
+            HIPCHK(dev_alloc(&h->d_on, h->Spad));
             HIPCHK(hipMemsetAsync(h->d_on, 0, h->Spad, h->stream));
         }
         memcpy(sl.h_on, stream_on, h->S);              // the caller's array is free again when this call returns
-        HIPCHK(hipMemcpyAsync(h->d_on, sl.h_on, h->S, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(h->d_on, sl.h_on, h->S, hipMemcpyHostToDevice, h->stream));
         h->on_now = h->d_on;
     }
     int n_act = -1;
@@ -2051,10 +2146,10 @@ static int submit_impl(oww_ctx* h, const int16_t* pcm, int32_t n_chunks, const u
     h->on_now = nullptr; h->lists_now = false;
     if (rc_step) return rc_step;
     const size_t nb = (size_t)h->S * h->NL * sizeof(float);
-    if (nb) HIPCHK(hipMemcpyAsync(sl.d_scores, h->d_scores, nb, hipMemcpyDeviceToDevice, h->stream));   // d_scores is rewritten by the next step
+    if (nb) HIPCHK(copy_async(sl.d_scores, h->d_scores, nb, hipMemcpyDeviceToDevice, h->stream));   // d_scores is rewritten by the next step
     HIPCHK(hipEventRecord(sl.done, h->stream));
     HIPCHK(hipStreamWaitEvent(h->down_stream, sl.done, 0));
-    if (nb) HIPCHK(hipMemcpyAsync(sl.h_scores, sl.d_scores, nb, hipMemcpyDeviceToHost, h->down_stream));
+    if (nb) HIPCHK(copy_async(sl.h_scores, sl.d_scores, nb, hipMemcpyDeviceToHost, h->down_stream));
     HIPCHK(hipEventRecord(sl.down, h->down_stream));
     sl.busy = true;
     ++h->n_submit;
@@ -2111,12 +2206,12 @@ int oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, flo
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (w) {
-        HIPCHK(hipMemcpy(h->d_verw + (size_t)label * h->ver_stride, w, (size_t)n_w * sizeof(float), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_verb + label, &bias, sizeof(float), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_verthr + label, &threshold, sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(h->d_verw + (size_t)label * h->ver_stride, w, (size_t)n_w * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(h->d_verb + label, &bias, sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(copy_sync(h->d_verthr + label, &threshold, sizeof(float), hipMemcpyHostToDevice));
     }
     h->ver_T[label] = w ? T : 0;
-    HIPCHK(hipMemcpy(h->d_verT, h->ver_T.data(), (size_t)h->NL * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(copy_sync(h->d_verT, h->ver_T.data(), (size_t)h->NL * sizeof(int), hipMemcpyHostToDevice));
     h->n_verifiers = 0;
     for (int t : h->ver_T) h->n_verifiers += t > 0;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }       // the launch list changed
@@ -2142,7 +2237,7 @@ int oww_push_vad(oww_ctx* h, const float* vad_scores, int on_device) {
     HIPCHK(hipSetDevice(h->cfg.device));
     const float* src = vad_scores;
     if (!on_device) {
-        HIPCHK(hipMemcpyAsync(h->d_vadin, vad_scores, (size_t)h->S * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(h->d_vadin, vad_scores, (size_t)h->S * sizeof(float), hipMemcpyHostToDevice, h->stream));
         src = h->d_vadin;
     }
     hipLaunchKernelGGL(push_vad_kernel, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_vadring, h->d_nvad, src, h->S);
@@ -2158,7 +2253,7 @@ int oww_get_vad(oww_ctx* h, float* out) {
     if (!h->vad) return fail(OWW_ESTATE, "oww_get_vad: no voice-activity network loaded (oww_load_vad)");
     if (!out) return fail(OWW_EINVAL, "oww_get_vad: null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpyAsync(out, h->d_vadlast, (size_t)h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(copy_async(out, h->d_vadlast, (size_t)h->S * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
     OWW_GUARD_END
@@ -2175,12 +2270,12 @@ int oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n) {
         for (int i = 0; i < n; ++i)
             if (stream_ids[i] < 0 || stream_ids[i] >= h->S) return fail(OWW_EINVAL, "oww_reset_vad: stream id %d out of range", stream_ids[i]);
         if (n > h->ids_cap) {
-            if (h->d_ids) (void)hipFree(h->d_ids);
+            if (h->d_ids) (void)dev_free(h->d_ids);
             h->d_ids = nullptr; h->ids_cap = 0;
-            HIPCHK(hipMalloc(&h->d_ids, (size_t)n * sizeof(int)));
+            HIPCHK(dev_alloc(&h->d_ids, (size_t)n * sizeof(int)));
             h->ids_cap = n;
         }
-        HIPCHK(hipMemcpyAsync(h->d_ids, stream_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(h->d_ids, stream_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
         d_ids = h->d_ids; count = n;
     }
     if (h->vad) {
@@ -2261,9 +2356,9 @@ int oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, 
     const size_t b_out = out_on_device ? 0 : (size_t)h->S * n_out * sizeof(int16_t);
     if (b_taps + b_in + b_out > h->rs_bytes) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->d_rs) (void)hipFree(h->d_rs);
+        if (h->d_rs) (void)dev_free(h->d_rs);
         h->d_rs = nullptr; h->rs_bytes = 0;
-        if (hipMalloc(&h->d_rs, b_taps + b_in + b_out) != hipSuccess) return fail(OWW_ENOMEM, "oww_resample: out of device memory");
+        if (dev_alloc(&h->d_rs, b_taps + b_in + b_out) != hipSuccess) return fail(OWW_ENOMEM, "oww_resample: out of device memory");
         h->rs_bytes = b_taps + b_in + b_out;
     }
     char* base = (char*)h->d_rs;
@@ -2271,20 +2366,20 @@ int oww_resample(oww_ctx* h, const int16_t* in, int in_on_device, int32_t n_in, 
     HIPCHK(hipStreamSynchronize(h->stream));
     h->rs_taps.assign((size_t)q * ntp, 0.f);
     for (int r = 0; r < q; ++r) memcpy(&h->rs_taps[(size_t)r * ntp], taps + (size_t)r * n_taps, n_taps * sizeof(float));
-    HIPCHK(hipMemcpyAsync(base, h->rs_taps.data(), h->rs_taps.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(copy_async(base, h->rs_taps.data(), h->rs_taps.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     ResampleParams a{};
     a.taps = (const float*)base; a.n_in = n_in; a.n_out = n_out; a.p = p; a.q = q; a.n_taps = n_taps; a.ntp = ntp; a.S = h->S;
     a.span = span; a.taps_in_lds = taps_in_lds; a.opb = opb;
     a.in = in;
     if (!in_on_device) {
-        HIPCHK(hipMemcpyAsync(base + b_taps, in, (size_t)h->S * n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(copy_async(base + b_taps, in, (size_t)h->S * n_in * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
         a.in = (const int16_t*)(base + b_taps);
     }
     a.out = out_on_device ? out : (int16_t*)(base + b_taps + b_in);
     hipLaunchKernelGGL(resample_kernel, dim3((n_out + opb - 1) / opb, h->S), dim3(RS_NT), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     if (!out_on_device) {
-        HIPCHK(hipMemcpyAsync(out, a.out, (size_t)h->S * n_out * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(copy_async(out, a.out, (size_t)h->S * n_out * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return OWW_OK;
@@ -2297,7 +2392,7 @@ int oww_get_raw(oww_ctx* h, float* out) {
     if (!out) return fail(OWW_EINVAL, "oww_get_raw: null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     const size_t nb = (size_t)h->S * h->NL * sizeof(float);
-    if (nb) HIPCHK(hipMemcpyAsync(out, h->d_raw, nb, hipMemcpyDeviceToHost, h->stream));
+    if (nb) HIPCHK(copy_async(out, h->d_raw, nb, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
     OWW_GUARD_END
@@ -2311,25 +2406,25 @@ static int mel_impl(oww_ctx* h, const int16_t* pcm, int32_t B, int32_t n, float*
     int16_t* d_in = nullptr; float* d_out = nullptr; float* d_max = nullptr;
     int rc = 0;
     do {
-        if (hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess || hipMalloc(&d_out, (size_t)B * F * 32 * sizeof(float)) != hipSuccess ||
-            hipMalloc(&d_max, (size_t)B * sizeof(float)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_mel: out of device memory"); break; }
-        if (hipMemcpyAsync(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: H2D failed"); break; }
+        if (dev_alloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess || dev_alloc(&d_out, (size_t)B * F * 32 * sizeof(float)) != hipSuccess ||
+            dev_alloc(&d_max, (size_t)B * sizeof(float)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_mel: out of device memory"); break; }
+        if (copy_async(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: H2D failed"); break; }
         if ((rc = launch_mel(h, d_in, B, n, F, 0, d_out, d_max))) break;
         const size_t tot = (size_t)B * F * 32;
         if (per_clip) {
             hipLaunchKernelGGL(clamp_db_rows_kernel, dim3((F * 32 + 255) / 256, B), dim3(256), 0, h->stream, d_out, F * 32, d_max);
         } else {
             std::vector<float> mx(B);
-            if (hipMemcpyAsync(mx.data(), d_max, B * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            if (copy_async(mx.data(), d_max, B * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
             float gmax = -INFINITY;                       // one clamp floor for the whole call (ipynb cell 15: log_spec.max())
             for (float v : mx) gmax = std::max(gmax, v);
             hipLaunchKernelGGL(clamp_db_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, d_out, tot, gmax - 80.0f);
         }
-        if (hipMemcpyAsync(out_db, d_out, tot * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        if (copy_async(out_db, d_out, tot * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_mel: D2H failed"); break; }
     } while (0);
-    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_max);
+    (void)dev_free(d_in); (void)dev_free(d_out); (void)dev_free(d_max);
     return rc;
 }
 
@@ -2354,10 +2449,10 @@ int oww_embed(oww_ctx* h, const float* mel_rows, int32_t B, int32_t rows, float*
                 if (src < 0) memset(d, 0, 32 * sizeof(float));
                 else memcpy(d, mel_rows + ((size_t)b * rows + src) * 32, 32 * sizeof(float));
             }
-        if (hipMemcpyAsync(h->d_mel, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: H2D failed"); break; }
+        if (copy_async(h->d_mel, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: H2D failed"); break; }
         if ((rc_all = run_cnn(h, B, 256, 0))) break;
         hipLaunchKernelGGL(advance_kernel, dim3((h->Spad + 255) / 256), dim3(256), 0, h->stream, h->d_nfeat, h->Spad, (const uint8_t*)nullptr);
-        if (it >= 9 && hipMemcpyAsync(emb.data(), h->d_emb, emb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: D2H failed"); break; }
+        if (it >= 9 && copy_async(emb.data(), h->d_emb, emb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: D2H failed"); break; }
         if (hipStreamSynchronize(h->stream) != hipSuccess) { rc_all = fail(OWW_EHIP, "oww_embed: device error"); break; }   // slab is reused next iteration
         if (it >= 9)
             for (int b = 0; b < B; ++b) memcpy(out + ((size_t)b * n_out + (it - 9)) * 96, &emb[(size_t)b * 96], 96 * sizeof(float));
@@ -2388,12 +2483,12 @@ int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32
     if (rc) return rc;
     do {
         if (!pcm_on_device) {
-            if (hipMalloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
-            if (hipMemcpyAsync(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: H2D failed"); break; }
+            if (dev_alloc(&d_in, (size_t)B * n * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
+            if (copy_async(d_in, pcm, (size_t)B * n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: H2D failed"); break; }
         }
-        if (hipMalloc(&d_mel, (lead + (size_t)Bp * F * 32) * sizeof(float)) != hipSuccess ||
-            hipMalloc(&d_max, (size_t)B * sizeof(float)) != hipSuccess ||
-            (!out_on_device && hipMalloc(&d_out, (size_t)B * n_out * 96 * sizeof(float)) != hipSuccess)) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
+        if (dev_alloc(&d_mel, (lead + (size_t)Bp * F * 32) * sizeof(float)) != hipSuccess ||
+            dev_alloc(&d_max, (size_t)B * sizeof(float)) != hipSuccess ||
+            (!out_on_device && dev_alloc(&d_out, (size_t)B * n_out * 96 * sizeof(float)) != hipSuccess)) { rc = fail(OWW_ENOMEM, "oww_embed_clips: out of device memory"); break; }
         float* o = out_on_device ? out : d_out;
         if (hipMemsetAsync(d_mel, 0, lead * sizeof(float), h->stream) != hipSuccess ||
             (Bp > B && hipMemsetAsync(d_mel + lead + (size_t)B * F * 32, 0, (size_t)(Bp - B) * F * 32 * sizeof(float), h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_embed_clips: memset failed"); break; }
@@ -2410,13 +2505,13 @@ int oww_embed_clips(oww_ctx* h, const int16_t* pcm, int32_t pcm_on_device, int32
         }
         h->mel_src = nullptr;
         if (rc) break;
-        if (!out_on_device && hipMemcpyAsync(out, d_out, (size_t)B * n_out * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: D2H failed"); break; }
+        if (!out_on_device && copy_async(out, d_out, (size_t)B * n_out * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: D2H failed"); break; }
         if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_embed_clips: device error: %s", hipGetErrorString(hipGetLastError())); break; }
     } while (0);
     h->mel_src = nullptr;
     const int rc_restore = park_state(h, B, false);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(d_in); (void)hipFree(d_mel); (void)hipFree(d_max); (void)hipFree(d_out);
+    (void)dev_free(d_in); (void)dev_free(d_mel); (void)dev_free(d_max); (void)dev_free(d_out);
     if (!rc) rc = rc_restore;
     if (!rc) rc = range_check(h, "oww_embed_clips");
     return rc;
@@ -2433,20 +2528,20 @@ int oww_head(oww_ctx* h, int32_t head, const float* features, int32_t B, float* 
     float* d_f = nullptr; float* d_raw = nullptr;
     int rc = 0;
     do {
-        if (hipMalloc(&d_f, nf * sizeof(float)) != hipSuccess || hipMalloc(&d_raw, (size_t)B * h->NL * sizeof(float)) != hipSuccess) {
+        if (dev_alloc(&d_f, nf * sizeof(float)) != hipSuccess || dev_alloc(&d_raw, (size_t)B * h->NL * sizeof(float)) != hipSuccess) {
             rc = fail(OWW_ENOMEM, "oww_head: out of device memory"); break;
         }
-        if (hipMemcpyAsync(d_f, features, nf * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: H2D failed"); break; }
+        if (copy_async(d_f, features, nf * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: H2D failed"); break; }
         if (hipMemsetAsync(d_raw, 0, (size_t)B * h->NL * sizeof(float), h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: memset failed"); break; }
         if ((rc = run_heads(h, B, false, d_f, head, d_raw, 0))) break;
         std::vector<float> raw((size_t)B * h->NL);
-        if (hipMemcpyAsync(raw.data(), d_raw, raw.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        if (copy_async(raw.data(), d_raw, raw.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_head: D2H failed"); break; }
         for (int b = 0; b < B; ++b)
             for (int o = 0; o < hh.n_out; ++o) out[(size_t)b * hh.n_out + o] = raw[(size_t)b * h->NL + hh.out_col + o];
         rc = range_check(h, "oww_head");
     } while (0);
-    (void)hipFree(d_f); (void)hipFree(d_raw);
+    (void)dev_free(d_f); (void)dev_free(d_raw);
     return rc;
     OWW_GUARD_END
 }
@@ -2458,8 +2553,8 @@ int oww_get_features(oww_ctx* h, int32_t sid, int32_t T, float* out) {
     HIPCHK(hipSetDevice(h->cfg.device));
     std::vector<float> ring((size_t)h->TR * 96);
     uint32_t cnt = 0;
-    HIPCHK(hipMemcpyAsync(ring.data(), h->d_feat + (size_t)sid * h->TR * 96, ring.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&cnt, h->d_nfeat + sid, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(copy_async(ring.data(), h->d_feat + (size_t)sid * h->TR * 96, ring.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(copy_async(&cnt, h->d_nfeat + sid, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     // after the step's advance the newest row sits at slot (cnt-1) % TR; oldest-first order of the last T rows
     for (int t = 0; t < T; ++t) {
@@ -2480,7 +2575,7 @@ int oww_get_mel(oww_ctx* h, int32_t sid, float* out, int32_t n_rows) {
     if (sid < 0 || sid >= h->S || !out || n_rows < 1 || n_rows > rows_last)
         return fail(OWW_EINVAL, "oww_get_mel: bad argument (sid=%d n_rows=%d; the last step produced %d rows per stream)", sid, n_rows, rows_last);
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpyAsync(out, h->d_mel + ((size_t)sid * rows_last + (rows_last - n_rows)) * 32, (size_t)n_rows * 32 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(copy_async(out, h->d_mel + ((size_t)sid * rows_last + (rows_last - n_rows)) * 32, (size_t)n_rows * 32 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return OWW_OK;
     OWW_GUARD_END
@@ -2495,7 +2590,7 @@ int oww_debug_read(oww_ctx* h, int32_t sid, int32_t layer, float* out, int32_t c
     const int n = kLayerOut[layer][0] * kLayerOut[layer][1] * kLayerOut[layer][2];
     if (cap < n) return fail(OWW_EINVAL, "oww_debug_read: need room for %d floats", n);
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemcpyAsync(out, h->d_dbg + (size_t)sid * DBG_FLOATS + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(copy_async(out, h->d_dbg + (size_t)sid * DBG_FLOATS + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return n;
     OWW_GUARD_END
@@ -2507,7 +2602,7 @@ int oww_debug_profile(oww_ctx* h, int64_t* out, int32_t cap) {
     if (!out || cap < 4 * 256) return fail(OWW_EINVAL, "oww_debug_profile: need room for 1024 values");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, h->d_prof, (size_t)4 * 256 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(out, h->d_prof, (size_t)4 * 256 * sizeof(long long), hipMemcpyDeviceToHost));
     return 4 * 256;
     OWW_GUARD_END
 }

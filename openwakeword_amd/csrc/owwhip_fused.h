@@ -24,9 +24,6 @@ namespace owf {
 using owh::lanemask_t;
 using owr::f32x4;
 
-#ifndef OWF_B128_STAGE
-#define OWF_B128_STAGE 1   // float staging with two ds_write_b128 per lane (0: scalar stores, paired by the compiler into ds_write2_b32)
-#endif
 #ifndef OWF_COMPACT_TAPS
 #define OWF_COMPACT_TAPS 1 // the sparse mel taps read conflict-free compact power tables (0: the plain power rows, three bins per bank)
 #endif
@@ -73,10 +70,7 @@ __device__ __forceinline__ void fetch_pass(const int16_t* __restrict__ tail_row,
 }
 
 template <bool DBG>
-#ifndef OWF_MINWAVES
-#define OWF_MINWAVES ((FA_WG + 3) / 4)
-#endif
-__global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAParams q) {
+__global__ __launch_bounds__(64 * FA_WG, (FA_WG + 3) / 4) void hmelA_kernel(MelAParams q) {
     using namespace owr;
     using owk::dft8;
     using owk::wave_sync;
@@ -173,13 +167,8 @@ __global__ __launch_bounds__(64 * FA_WG, OWF_MINWAVES) void hmelA_kernel(MelAPar
                     // ds_write2_b32 at a stride of 8 floats (8-way conflicts: a quarter of this kernel's LDS-active cycles).
                     // (staging the raw int16, or a transposed [8][89] float window, measured slower: round 2)
                     const int16_t* h = reinterpret_cast<const int16_t*>(&raw[u]);
-#if OWF_B128_STAGE
                     *reinterpret_cast<f32x4*>(sx + i) = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                     *reinterpret_cast<f32x4*>(sx + i + 4) = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
-#else
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sx[i + e] = (float)h[e];
-#endif
                 }
             }
             if (f2 < 3) fetch_pass(tail_row, pcm_row, f2 + 1, lane, raw);     // next pass's samples fly during this FFT

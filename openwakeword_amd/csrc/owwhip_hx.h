@@ -73,13 +73,11 @@ struct Op { f16x8 h, l; };
 // (v_cmp_u_f32 + s_or_b64 per tile) and the wave raises the handle's sticky flag (host-mapped word) at kernel end.
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ void nan_guard(lanemask_t& bad, float x) {
-#ifndef OWH_NO_RANGE_GUARD
     // v_cmp_u_f32 + s_or_b64.  The compare is the builtin (not inline asm) so that the compiler's hazard recogniser sees a VALU read of
     // an MFMA result and SCC / VCC stay modelled; the empty asm pins the OR here -- without it every tile's lane mask stays alive
     // until the end of the kernel (+50 SGPRs).
     bad |= __builtin_amdgcn_fcmpf(x, x, 8 /* FCMP_UNO */);
     asm volatile("" : "+s"(bad));
-#endif
 }
 // flag[0] = raised; flag[1] = ONE packed word (first stream << 6 | stream count, count <= 32; -1 = position unknown) of one of the
 // waves that saw it.  Several waves -- of different kernels, reporting 1, 2, 4, 8 or 32 streams -- may write concurrently; a single

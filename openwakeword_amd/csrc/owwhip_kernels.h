@@ -706,18 +706,10 @@ __device__ __forceinline__ void mel_fetch(const MelParams& p, int s, int g, int 
 // the log-mel values (its own LDS regions, no workgroup barrier); the waves only meet once per call for the clamp maximum.
 __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     __shared__ float s_hann[400];
-#ifndef OWK_MEL_NOALIAS
     // a wave's PCM samples are dead once the windowed values are in registers: they share the LDS of the FFT transposes
     // (re and im planes, contiguous per wave) -- 24 KB instead of 35 KB per workgroup, six resident workgroups per CU
     __shared__ float s_z[4][2 * 576];
     static_assert(MEL_WX <= 2 * 576, "sample window fits the transpose planes");
-#else
-    __shared__ float s_x[4][MEL_WX];
-    __shared__ float s_z[4][2 * 576];
-#endif
-#ifdef OWK_MEL_NOALIAS
-    __shared__ float s_pow[8][MEL_PBINS + 8];
-#endif
     __shared__ float s_red[2][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -737,23 +729,14 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     for (int t = 0; t < 16; ++t) taps[t] = p.mel_taps[mbin * 16 + t];
     const int n_groups = (p.n_frames + 7) / 8;
     const int hist = p.streaming ? 480 : 0;
-#ifndef OWK_MEL_NOALIAS
     float* sx = s_z[wave];
-#else
-    float* sx = s_x[wave];
-#endif
     float* xr = s_z[wave];
     float* xi = s_z[wave] + 576;
-#ifndef OWK_MEL_NOALIAS
     // power spectra of the wave's two frames: the last FFT stage leaves xr[128..383] unused (only bins < 128 and >= 384 are
     // written back), exactly 2 x 128 floats -- 20 KB of LDS per workgroup, seven resident workgroups per CU
     static_assert(MEL_PBINS + 8 <= 128, "power rows fit the unused middle of the re plane");
     float* pw0 = xr + 128;
     float* pw1 = xr + 256;
-#else
-    float* pw0 = s_pow[2 * wave];
-    float* pw1 = s_pow[2 * wave + 1];
-#endif
     __syncthreads();                             // s_hann
 
     int it = 0;
@@ -767,9 +750,6 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
         for (int g = 0; g < n_groups; ++g) {
             // ---- this wave's samples (fetched one iteration ahead, see mel_fetch): int16 -> float into the wave's LDS window
             wave_sync();                         // previous group's readers of sx / s_pow (same wave) are done
-#ifdef OWK_MEL_NOPREFETCH
-            mel_fetch(p, s, g, wave, lane, hist, raw);
-#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = lane * 8 + u * 512;
@@ -782,9 +762,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
             {   // the next unit of work of this wave: next group of this stream, else group 0 of the workgroup's next stream
                 const bool same = g + 1 < n_groups;
                 const int sn = same ? s : s + (int)gridDim.x, gn = same ? g + 1 : 0;
-#ifndef OWK_MEL_NOPREFETCH
                 if (sn < p.S) mel_fetch(p, sn, gn, wave, lane, hist, raw);
-#endif
             }
             wave_sync();
             // ---- one complex FFT per wave: z = frame_a + i * frame_b (frames 2*wave and 2*wave + 1 of this group)

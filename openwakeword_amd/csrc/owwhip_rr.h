@@ -41,9 +41,6 @@ __device__ __forceinline__ float leaky_clamp(float x) { return fmaxf(fmaxf(0.2f 
 // VALU instructions were such no-ops.  NaNs are not expected here (they would already have poisoned the convolution).
 // (+inf comes from an opaque scalar move: with a literal the optimiser rewrites the median back into maxNum.)
 __device__ __forceinline__ float fmax_nc(float a, float b) {
-#ifdef OWR_FMAX_IEEE
-    return fmaxf(a, b);
-#endif
     float inf;
     asm("s_mov_b32 %0, 0x7f800000" : "=s"(inf));
     return __builtin_amdgcn_fmed3f(a, b, inf);
@@ -128,9 +125,6 @@ __device__ __forceinline__ f32x4 load_w(const float* __restrict__ w, int oct, in
 #ifndef OWR_WPS
 #define OWR_WPS 2     // waves per SIMD the register budget is sized for
 #endif
-#ifndef OWR_STAGGER
-#define OWR_STAGGER 0 // 1: waves start with a pseudo-random delay so that co-resident waves do not run their epilogues in lockstep
-#endif
 #ifndef OWR_SCHEDBAR
 #define OWR_SCHEDBAR 1
 #endif
@@ -139,12 +133,6 @@ __device__ __forceinline__ f32x4 load_w(const float* __restrict__ w, int oct, in
 #else
 #define OWR_SB() do {} while (0)
 #endif
-__device__ __forceinline__ void stagger(int g) {
-#if OWR_STAGGER
-    const int n = (g * 2654435761u >> 27) & 31;       // 0..31 x 64 clocks... up to ~8k cycles
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
-#endif
-}
 
 // 1x3 (mel axis) layer on NT tiles held in registers
 template <int NCTI, int NCTO, int NT, int F, bool BN>
@@ -537,7 +525,6 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         sbn[l][1][c] = p.shift[l][c];
     }
     const int s_first = g * C::SPT;
-    stagger(g);
 
     float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
     float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
@@ -700,7 +687,6 @@ __global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) { const int k = min(4 * ks + j, 8); goff[ks] = (k / 3) * 34 + (k % 3) + pos; }
 
-    stagger(gw);
     for (int s = gw; s < p.n_streams; s += nw) {
         // an opaque zero per stream: keeps the loop-invariant LDS reads (weights, BatchNorm) from being hoisted out of
         // the stream loop into ~150 live registers
