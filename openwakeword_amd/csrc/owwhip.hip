@@ -144,7 +144,9 @@ inline hipError_t copy_async(void* dst, const void* src, size_t n, hipMemcpyKind
 }
 inline hipError_t copy_sync(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
     if (guard_mode() && n && (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToHost)) return guard_copy(dst, src, n, kind, nullptr);
-    return hipMemcpy(dst, src, n, kind);
+    const hipError_t e = hipMemcpy(dst, src, n, kind);
+    // (set-up time only: the consumers run on non-blocking streams, which nothing orders behind the legacy stream)
+    return e != hipSuccess || kind != hipMemcpyHostToDevice ? e : hipStreamSynchronize(nullptr);
 }
 
 struct LayerDef { int kh, kw, cin, cout; };
@@ -876,7 +878,12 @@ int do_reset(oww_ctx* h, const int* d_ids, int n, const float* d_featinit) {
 template <class T>
 int dalloc(T** p, size_t n, bool zero = true, int line = __builtin_LINE()) {
     HIPCHK(dev_alloc(p, std::max<size_t>(n, 1) * sizeof(T), line));
-    if (zero) HIPCHK(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    if (zero) {
+        // the handle's streams are hipStreamNonBlocking: nothing orders them behind the legacy stream this fill runs on, so it has
+        // finished before the pointer is handed out (a kernel that met garbage frame counters would index out of its buffers)
+        HIPCHK(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+        HIPCHK(hipStreamSynchronize(nullptr));
+    }
     return 0;
 }
 
