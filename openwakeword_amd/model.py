@@ -23,7 +23,7 @@ import pickle
 import wave
 from collections import defaultdict, deque
 from functools import partial
-from typing import DefaultDict, Dict, List, Optional, Sequence, Union
+from typing import Callable, DefaultDict, Dict, List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -168,6 +168,53 @@ class AudioFeatures:
             return np.zeros((0, EMB_DIM), np.float32)
         out = self.engine.embed(spec[None, : 76 + 8 * (n_win - 1)].astype(np.float32))[0]
         return out
+
+    # ---- the reference's stateless helpers (training / data-preparation code calls them directly), same shapes -------------
+    def _get_melspectrogram(self, x, melspec_transform: Callable = lambda x: x / 10 + 2) -> np.ndarray:
+        """utils.py:180-208: int16 samples `[n]` or `[B, n]` -> transformed mel rows `[F, 32]` / `[B, F, 32]`; one clamp floor
+        for the whole call, like one run of the melspectrogram graph."""
+        x = np.array(x).astype(np.int16) if isinstance(x, list) else np.asarray(x)
+        if x.dtype != np.int16:
+            raise ValueError("Input data must be 16-bit integers (i.e., 16-bit PCM audio)."
+                             f"You provided {x.dtype} data.")
+        x = x[None, ] if x.ndim < 2 else x
+        return melspec_transform(np.squeeze(self.engine.mel(x)))
+
+    def _batched(self, fn, x):
+        cap = self.engine.n_streams_padded
+        return np.concatenate([fn(x[o:o + cap]) for o in range(0, x.shape[0], cap)], axis=0)
+
+    def _get_embeddings_from_melspec(self, melspec) -> np.ndarray:
+        """utils.py:210-223: one 76-row window `[76, 32(, 1)]` (or a batch of them) -> its embedding, squeezed."""
+        m = np.asarray(melspec, dtype=np.float32)
+        if m.ndim >= 3 and m.shape[-1] == 1:
+            m = m[..., 0]
+        if m.ndim == 2:
+            m = m[None, ]
+        if m.ndim != 3 or m.shape[1:] != (76, 32):
+            raise ValueError(f"expected melspectrogram windows of shape [76, 32, 1], got {np.asarray(melspec).shape}")
+        return np.squeeze(self._batched(self.engine.embed, m))
+
+    def _get_melspectrogram_batch(self, x, batch_size: int = 128, ncpu: int = 1) -> np.ndarray:
+        """utils.py:243-290 (the CPU path: every clip is its own run of the melspectrogram graph, so every clip has its own
+        clamp floor): int16 `[N, samples]` -> `[N, ceil(samples/160 - 3), 32]`, transformed (x/10 + 2)."""
+        x = np.asarray(x)
+        if x.ndim != 2 or x.dtype != np.int16:
+            raise ValueError("Input data must be 16-bit integers (i.e., 16-bit PCM audio) of shape (N, samples)")
+        return (self._batched(self.engine.mel_clips, x) / 10.0 + 2.0).astype(np.float32)
+
+    def _get_embeddings_batch(self, x, batch_size: int = 128, ncpu: int = 1) -> np.ndarray:
+        """utils.py:292-352: mel rows `[N, frames, 32(, 1)]` -> `[N, (frames - 76)//8 + 1, 96]`: 76-row windows every 8 rows;
+        rows past the last whole window are ignored."""
+        m = np.asarray(x, dtype=np.float32)
+        if m.ndim == 4 and m.shape[-1] == 1:
+            m = m[..., 0]
+        if m.ndim != 3 or m.shape[2] != 32:
+            raise ValueError(f"expected melspectrograms of shape (N, frames, 32), got {np.asarray(x).shape}")
+        if m.shape[1] < 76:
+            raise ValueError("Embedding model requires the input melspectrograms to have at least 76 frames")
+        n_win = (m.shape[1] - 76) // 8 + 1
+        return self._batched(self.engine.embed, np.ascontiguousarray(m[:, : 76 + 8 * (n_win - 1)]))
 
     def get_embedding_shape(self, audio_length: float, sr: int = 16000):
         """Shape of `_get_embeddings` for a clip of `audio_length` seconds (utils.py:238-241), from the frame arithmetic

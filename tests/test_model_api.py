@@ -195,6 +195,60 @@ def test_embed_clips_matches_oracle(golden):
         m.close()
 
 
+@gpu
+def test_stateless_feature_helpers_mirror_the_reference(golden):
+    """The helpers training / data-preparation code calls on AudioFeatures directly (utils.py:180-352): same shapes, same
+    clamp scope (one floor per _get_melspectrogram call, one per clip in _get_melspectrogram_batch), and none of them moves
+    the streaming state."""
+    from openwakeword_amd import Model
+    w = _weights(["alexa"])
+    m = Model(wakeword_models=["alexa"], weights=w)
+    try:
+        F = m.preprocessor
+        oracle = O.OracleAudioFeatures(w["embedding"], init_noise=np.zeros(64000, np.int16))
+        clip = golden["pcm/hey_jane"]
+        x = np.stack([clip[:24123], clip[4000:28123] // 8, np.zeros(24123, np.int16)])
+        # one clip, a list, a batch (ONE floor for the batch: the quiet clip is clamped against the loud one's maximum)
+        one = F._get_melspectrogram(x[0])
+        assert one.shape == (int(np.ceil(24123 / 160 - 3)), 32)
+        np.testing.assert_allclose(one, oracle.melspectrogram(x[0]), rtol=0, atol=2e-4)
+        np.testing.assert_array_equal(F._get_melspectrogram(list(x[0][:4000])), F._get_melspectrogram(x[0][:4000]))
+        both = F._get_melspectrogram(x[:2], melspec_transform=lambda v: v)
+        assert both.shape == (2, 148, 32)
+        np.testing.assert_allclose(both, np.squeeze(oracle.mel_fn(x[:2].astype(np.float32))), rtol=0, atol=2e-3)
+        with pytest.raises(ValueError, match="16-bit integers"):
+            F._get_melspectrogram(x[0].astype(np.float32))
+        # per-clip floors
+        mb = F._get_melspectrogram_batch(x, batch_size=2)
+        assert mb.shape == (3, 148, 32) and mb.dtype == np.float32
+        for i in range(3):
+            np.testing.assert_allclose(mb[i], oracle.melspectrogram(x[i]), rtol=0, atol=2e-4)
+        # windows -> embeddings
+        eb = F._get_embeddings_batch(mb[:, :, :, None])
+        assert eb.shape == (3, (148 - 76) // 8 + 1, 96)
+        want = np.stack([oracle.clip_embeddings(c) for c in x])
+        np.testing.assert_allclose(eb, want, rtol=0, atol=2e-4)
+        np.testing.assert_allclose(F.embed_clips(x[:, :24000]), F._get_embeddings_batch(F._get_melspectrogram_batch(x[:, :24000])), rtol=0, atol=2e-5)
+        one_win = F._get_embeddings_from_melspec(mb[1, 8:84, :, None])
+        assert one_win.shape == (96,)
+        np.testing.assert_allclose(one_win, eb[1, 1], rtol=0, atol=2e-5)
+        with pytest.raises(ValueError, match="at least 76 frames"):
+            F._get_embeddings_batch(mb[:, :70])
+        assert F._get_embeddings(x[0]).shape == F.get_embedding_shape(24123 / 16000)
+    finally:
+        m.close()
+    # (embed_clips re-seeds the object like the reference's constructor does; the others left the ring alone)
+    m = Model(wakeword_models=["alexa"], weights=w)
+    try:
+        F = m.preprocessor
+        m.predict_clip(golden["pcm/hey_jane"][:12800])
+        before = F.get_features(16).copy()
+        F._get_melspectrogram(x[0]); F._get_melspectrogram_batch(x); F._get_embeddings_batch(mb); F._get_embeddings_from_melspec(mb[0, :76])
+        np.testing.assert_array_equal(F.get_features(16), before)
+    finally:
+        m.close()
+
+
 # ----------------------------------------------------------------------------- the rest of the reference's test list
 # (/root/reference/tests/test_models.py: custom verifier 114-128, names with spaces 130-137, label mapping 139-149,
 #  parent lookup 318-321, positive frames 323-330, VAD 259-285)
