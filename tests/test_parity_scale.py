@@ -119,3 +119,34 @@ def test_c4_131072x3_vad_probe_streams_match_gated_oracle():
         eng.close()
     print(f"\nc4: {n_streams} streams x 3 heads + VAD gate: {1024 - skipped} (stream, step) pairs, max |score - oracle| = {worst:.2e}, "
           f"{skipped} decisions within 1e-3 of the threshold skipped, {n_gated} gated / {n_open} open after frame 6")
+
+
+@pytest.mark.gpu
+def test_scores_do_not_depend_on_the_batch_size_the_stream_sits_in():
+    """A size-independent property at the full size: the same audio through stream s gives the same BITS whether s sits in an engine
+    of 131,072 streams (two-slot weight rings, `__syncthreads`), 4,096 (three-slot rings with counted waits and bare barriers, deep
+    heads ring) or 40 (partly filled tiles) -- same arithmetic in the same order in every launch shape."""
+    import torch
+    dev = torch.device("cuda", 0)
+    emb, heads = PS._weights(PS.HEADS3)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    S0, T = 131072, 24
+    pool = [(torch.randn(S0, 1280, device=dev, generator=g) * a).round().clamp(-32768, 32767).to(torch.int16) for a in (3000.0, 150.0, 14000.0)]
+    got = {}
+    for S in (S0, 4096, 40):
+        eng = StreamEngine(S, heads, emb)
+        try:
+            sc = torch.empty(T, S, eng.n_labels, device=dev)
+            pcm = [p[:S].contiguous() for p in pool]
+            torch.cuda.synchronize()                     # (the engine runs on its own stream)
+            for t in range(T):
+                eng.step_device(pcm[t % 3].data_ptr(), 1, sc[t].data_ptr())
+            eng.sync()
+            got[S] = (sc.cpu().numpy(), np.stack([eng.get_features(s, 16) for s in (0, 39)]))
+        finally:
+            eng.close()
+    assert np.isfinite(got[S0][0]).all() and got[S0][0][-1].max() > 0
+    for S in (4096, 40):
+        np.testing.assert_array_equal(got[S][0], got[S0][0][:, :S], err_msg=f"scores, engine of {S} streams")
+        np.testing.assert_array_equal(got[S][1], got[S0][1], err_msg=f"feature rings, engine of {S} streams")

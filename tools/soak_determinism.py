@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Soak: the same 150-frame sequence through two fresh full-size engines must give bit-identical scores and feature rings
-(no data race in the barrier-free wave-local sections, the LDS aliasing of the mel kernel or the double-buffered weight chunks)."""
+"""Soak: the same 150-frame sequence through fresh engines must give bit-identical scores and feature rings -- run against run
+(no data race in the barrier-free wave-local sections, the LDS aliasing of the mel kernel or the weight rings) AND batch size
+against batch size: the first streams of the 131,072-stream engine (two-slot rings, __syncthreads) must equal the same streams in
+engines of 4,096 / 512 / 40 streams (three-slot rings with counted waits and bare barriers, deep heads ring).
+python tools/soak_determinism.py [rounds=2]"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
@@ -8,23 +11,44 @@ from openwakeword_amd import weights as W
 from openwakeword_amd.engine import StreamEngine
 
 dev = torch.device("cuda", 0)
-S, T = 131072, 150
+SIZES, T = (131072, 4096, 512, 40), 150
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 emb = W.synthetic_embedding(1234)
 heads = {n: W.synthetic_head(n, 1234) for n in ("alexa", "hey_mycroft", "hey_jarvis")}
 g = torch.Generator(device=dev); g.manual_seed(99)
-pool = [(torch.randn(S, 1280, device=dev, generator=g) * a).round().clamp(-32768, 32767).to(torch.int16) for a in (3000.0, 200.0, 12000.0, 0.0, 3000.0)]
-outs = []
-for run in range(2):
+S0 = SIZES[0]
+pool = [(torch.randn(S0, 1280, device=dev, generator=g) * a).round().clamp(-32768, 32767).to(torch.int16) for a in (3000.0, 200.0, 12000.0, 0.0, 3000.0)]
+probe = (0, 1, 39)
+
+
+def run(S):
     eng = StreamEngine(S, heads, emb)
     sc = torch.empty(S, eng.n_labels, device=dev)
     acc = torch.zeros(S, eng.n_labels, device=dev, dtype=torch.float64)
+    pcm = [p[:S].contiguous() for p in pool]
     for t in range(T):
-        eng.step_device(pool[(t * 7) % len(pool)].data_ptr(), 1, sc.data_ptr())
+        eng.step_device(pcm[(t * 7) % len(pcm)].data_ptr(), 1, sc.data_ptr())
         eng.sync()
         acc += sc.double() * (1 + t % 5)
-    feats = [eng.get_features(s, 16) for s in (0, 1, 4097, 65535, 131071)]
-    outs.append((acc.clone(), sc.clone(), feats))
+    feats = [eng.get_features(s, 16) for s in probe]
     eng.close()
-same = bool((outs[0][0] == outs[1][0]).all()) and bool((outs[0][1] == outs[1][1]).all()) and all((a == b).all() for a, b in zip(outs[0][2], outs[1][2]))
-print("deterministic:", same, "| finite:", bool(torch.isfinite(outs[0][0]).all()), "| nonzero scores:", int((outs[0][1] > 0).sum()))
-sys.exit(0 if same else 1)
+    return acc, sc.clone(), feats
+
+
+ok = True
+ref = None
+for S in SIZES:
+    outs = [run(S) for _ in range(rounds)]
+    same = all(bool((o[0] == outs[0][0]).all()) and bool((o[1] == outs[0][1]).all()) and all((a == b).all() for a, b in zip(o[2], outs[0][2]))
+               for o in outs[1:])
+    line = f"S={S}: {rounds} runs bit-identical: {same} | finite: {bool(torch.isfinite(outs[0][0]).all())}"
+    if ref is None:
+        ref = outs[0]
+    else:
+        inv = bool((outs[0][0] == ref[0][:S]).all()) and bool((outs[0][1] == ref[1][:S]).all()) and all((a == b).all() for a, b in zip(outs[0][2], ref[2]))
+        line += f" | equals the first {S} streams of the {S0}-stream engine: {inv}"
+        same = same and inv
+    print(line, flush=True)
+    ok = ok and same
+print("deterministic and batch-invariant:", ok)
+sys.exit(0 if ok else 1)
