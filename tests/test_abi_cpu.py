@@ -78,3 +78,50 @@ def test_integration_stubs_compile_and_bind_only_declared_symbols():
             assert sym in names, f"INTEGRATION.md stub calls {sym}, which include/owwhip.h does not declare"
     assert f"lib.oww_abi_version() == {_lib.ABI_VERSION}" in text
     assert f"C ABI version {_lib.ABI_VERSION} " in text
+
+
+def _gcc(args, cwd=None):
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    return subprocess.run([gcc] + args, cwd=cwd, capture_output=True, text=True)
+
+
+def test_header_is_plain_c99_and_the_ctypes_struct_has_its_layout(tmp_path):
+    """include/owwhip.h is what a C / cgo / JNI host compiles against: it must be valid C99 on its own, and the ctypes mirror the
+    Python layer uses must describe the SAME struct (a mismatch would pass every Python test and break every C caller)."""
+    src = tmp_path / "layout.c"
+    fields = [f for f, _ in _lib.Config._fields_]
+    src.write_text('#include <stdio.h>\n#include "owwhip.h"\nint main(void) {\n'
+                   '  printf("sizeof %zu\\n", sizeof(oww_config));\n'
+                   + "".join(f'  printf("{f} %zu\\n", offsetof(oww_config, {f}));\n' for f in fields)
+                   + '  printf("abi %d chunk %d emb %d ring %d comm %d classes %d\\n", OWW_ABI_VERSION, OWW_CHUNK, OWW_EMB_DIM, OWW_SCORE_RING, '
+                     'OWW_COMM_ID_BYTES, OWW_N_KERNEL_CLASSES);\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    r = _gcc(["-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert r.returncode == 0, r.stderr
+    import subprocess
+    out = dict(line.split(" ", 1) for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof"]) == C.sizeof(_lib.Config)
+    for f in fields:
+        assert int(out[f]) == getattr(_lib.Config, f).offset, f
+    assert out["abi"].split() == ["5", "chunk", "1280", "emb", "96", "ring", "30", "comm", "128", "classes", "10"]
+    assert _lib.ABI_VERSION == 5 and engine.CHUNK == 1280 and engine.EMB_DIM == 96
+
+
+def test_c_consumer_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/c/owwhip_demo.c (the ABI driven from plain C) compiles warning-free against the header and links against the
+    library; without a GPU it stops at oww_create with the library's error text, not with a crash or a fallback."""
+    import subprocess
+    import torch
+    exe = tmp_path / "owwhip_demo"
+    libdir = os.path.dirname(_build.lib_path())
+    r = _gcc(["-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+              os.path.join(ROOT, "examples", "c", "owwhip_demo.c"), "-L", libdir, "-lowwhip", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    assert r.returncode == 0, r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_seam_gpu.py runs the program for real")
+    run = subprocess.run([str(exe), str(tmp_path), "4", "2"], capture_output=True, text=True)
+    assert run.returncode == 1 and "oww_create" in run.stderr and "-> -2" in run.stderr

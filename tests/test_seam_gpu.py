@@ -78,3 +78,44 @@ def test_stub_reset_then_second_clip(golden):
     labels = list(golden["c1280/labels"])
     got = np.array([[float(p[k]) for k in labels] for p in preds])
     np.testing.assert_allclose(got, golden["reset/scores"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("family", [3, 1])
+def test_plain_c_host_gets_the_bits_the_python_layer_gets(tmp_path, family):
+    """examples/c/owwhip_demo.c -- create / load / commit / step / destroy from C99, weights and PCM from files -- against the same
+    calls made through ctypes: identical scores, bit for bit (binary, gated and multiclass heads; 40 streams leave a partly filled
+    tile).  What a cgo / JNI / FFI binding of include/owwhip.h would do, minus the language."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    S, T = 40, 12
+    names = ["alexa", "hey_jarvis", "timer"]
+    emb = W.synthetic_embedding(cases.SEED_WEIGHTS)
+    heads = {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in names}
+    E.pack_mel_blob().tofile(tmp_path / "mel.bin")
+    E.pack_embedding_blob(emb).tofile(tmp_path / "embedding.bin")
+    for i, n in enumerate(names):
+        E.pack_head_blob(heads[n]).tofile(tmp_path / f"head_{i}.bin")
+    pcm = (np.random.default_rng(3).standard_normal((T, S, 1280)) * 5000).astype(np.int16)
+    pcm[:, 1] = 0
+    pcm.tofile(tmp_path / "pcm.bin")
+    exe = tmp_path / "owwhip_demo"
+    libdir = os.path.dirname(_build.lib_path())
+    r = subprocess.run([gcc, "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c", "owwhip_demo.c"), "-L", libdir, "-lowwhip", f"-Wl,-rpath,{libdir}", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe), str(tmp_path), str(S), str(T), str(family)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    assert run.stdout.count("step ") == T
+    eng = E.StreamEngine(S, heads, emb, use_mfma=family, calibration_pcm=None)      # (the C program sets no calibration audio either)
+    try:
+        want = np.stack([eng.step(pcm[t]) for t in range(T)])
+    finally:
+        eng.close()
+    got = np.fromfile(tmp_path / "scores.bin", dtype=np.float32).reshape(want.shape)
+    assert want.shape == (T, S, 1 + 1 + 7) or want.shape[2] == eng.n_labels
+    assert np.isfinite(got).all() and got[-1].max() > 0
+    np.testing.assert_array_equal(got, want)
