@@ -669,3 +669,196 @@ def test_melspectrogram_file_is_verified_against_the_analytic_front_end(tmp_path
     db = 10.0 * np.log10(np.maximum(power @ W.mel_filterbank().astype(np.float64), 1e-10))
     db = np.maximum(db, db.max() - 80.0)
     np.testing.assert_allclose(O.mel_stage(x[None].astype(np.float32), np.float64)[0, 0], db, rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# A THIRD writer that is not ours: PyTorch's own TorchScript ONNX exporter -- the one the reference exports its wake-word models
+# with (train.py:144-165: torch.onnx.export(model, rand(input_shape)[None], path, output_names=[...]), multiclass models wrapped in
+# a softmax).  The `onnx` package is not installed here; the exporter only needs it for a post-pass that splices onnx-script
+# functions into the finished ModelProto bytes (none occur in these models), so the test replaces that post-pass by the identity.
+def _torch_export(module, T, path, opset):
+    import io
+    import warnings
+    import torch
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    keep = onnx_proto_utils._add_onnxscript_fn
+    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    try:
+        buf = io.BytesIO()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.onnx.export(module.eval(), torch.rand(T, 96)[None, ], buf, opset_version=opset, output_names=["out"], dynamo=False)
+    finally:
+        onnx_proto_utils._add_onnxscript_fn = keep
+    with open(path, "wb") as f:
+        f.write(buf.getvalue())
+
+
+def _torch_head(net, T, n_out, n_blocks=1):
+    """The architecture of train.py:56-83 (flatten, Linear + LayerNorm + ReLU, blocks of the same, Linear, Sigmoid | ReLU) with the
+    given weights; multiclass models end in ReLU and are exported under a softmax wrapper (train.py:152-165)."""
+    import torch
+    import torch.nn as nn
+
+    class Block(nn.Module):
+        def __init__(self, w, b, ln):
+            super().__init__()
+            self.fc = nn.Linear(w.shape[0], w.shape[1])
+            self.norm = nn.LayerNorm(w.shape[1]) if ln is not None else nn.Identity()      # (the catalogue's multiclass heads have none)
+            self.act = nn.ReLU()
+            with torch.no_grad():
+                self.fc.weight.copy_(torch.from_numpy(w.T.copy())); self.fc.bias.copy_(torch.from_numpy(b))
+                if ln is not None:
+                    self.norm.weight.copy_(torch.from_numpy(ln[0])); self.norm.bias.copy_(torch.from_numpy(ln[1]))
+
+        def forward(self, x):
+            return self.act(self.norm(self.fc(x)))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.flatten = nn.Flatten()
+            self.first = Block(net["w1"], net["b1"], net["ln1"])
+            self.blocks = nn.ModuleList([Block(net["w2"], net["b2"], net["ln2"]) for _ in range(n_blocks)])
+            self.last = nn.Linear(net["w3"].shape[0], n_out)
+            self.last_act = nn.Sigmoid() if n_out == 1 else nn.ReLU()
+            with torch.no_grad():
+                self.last.weight.copy_(torch.from_numpy(net["w3"].T.copy())); self.last.bias.copy_(torch.from_numpy(net["b3"]))
+
+        def forward(self, x):
+            x = self.first(self.flatten(x))
+            for blk in self.blocks:
+                x = blk(x)
+            return self.last_act(self.last(x))
+
+    if n_out == 1:
+        return Net()
+
+    class Wrapped(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Net()
+
+        def forward(self, x):
+            return torch.nn.functional.softmax(self.model(x), dim=1)
+
+    return Wrapped()
+
+
+@pytest.mark.parametrize("name,opset,ln", [("alexa", 17, None), ("alexa", 13, None), ("alexa", 11, None), ("hey_mycroft", 14, None),
+                                           ("timer", 17, None), ("timer", 12, None), ("timer", 17, True), ("weather", 13, True)])
+def test_heads_written_by_pytorchs_own_exporter_load_to_the_same_weights(tmp_path, name, opset, ln):
+    """opset >= 17 emits LayerNormalization, older opsets the decomposed form (ReduceMean / Sub / Pow / Sqrt / Div); Linear becomes
+    Gemm with transB; Flatten, Sigmoid / Relu + Softmax as exported.  Every weight must come back bit for bit, and the oracle must
+    compute with the loaded head exactly what it computes with the source head -- and what torch computed (fp32 round-off)."""
+    torch = pytest.importorskip("torch")
+    head = W.synthetic_head(name, 91, layernorm=ln)
+    assert head["kind"] in ("binary", "multiclass")
+    module = _torch_head(head["net"], head["T"], head["n_out"])
+    path = os.path.join(tmp_path, f"{name}_{opset}.onnx")
+    try:
+        _torch_export(module, head["T"], path, opset)
+    except Exception as e:                                  # noqa: BLE001 -- an exporter that cannot run here is not our failure
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    got = onnx_ingest.load_head(path)
+    assert (got["kind"], got["T"], got["hidden"], got["n_out"]) == (head["kind"], head["T"], head["hidden"], head["n_out"])
+    for k, v in head["net"].items():
+        for x, y in ((v, got["net"][k]),) if not isinstance(v, tuple) else zip(v, got["net"][k]):
+            np.testing.assert_array_equal(x, y, err_msg=k)
+    feats = np.random.default_rng(2).normal(0, 2, (6, head["T"], 96)).astype(np.float32)
+    want = O.head_stage(feats, head, np.float32)
+    np.testing.assert_array_equal(O.head_stage(feats, got, np.float32), want)
+    with torch.no_grad():
+        ref = module.eval()(torch.from_numpy(feats)).numpy()
+    np.testing.assert_allclose(want.reshape(ref.shape), ref, rtol=0, atol=2e-6)
+
+
+def test_a_torch_exported_head_with_two_blocks_is_refused_not_misread(tmp_path):
+    """n_blocks = 2 (train.py:70) is a network the kernels do not implement: the reader must say so instead of dropping a layer."""
+    pytest.importorskip("torch")
+    head = W.synthetic_head("alexa", 92)
+    path = os.path.join(tmp_path, "two_blocks.onnx")
+    try:
+        _torch_export(_torch_head(head["net"], head["T"], 1, n_blocks=2), head["T"], path, 17)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    with pytest.raises(ValueError):
+        onnx_ingest.load_head(path)
+
+
+def _torch_embedding(emb, act="leakyclamp"):
+    """The speech-embedding CNN (notebook cell 18, restated in oracle/oww_oracle.py: CNN_LAYERS) as a torch module in NCHW, input
+    [B, 76, 32, 1] permuted once -- for PyTorch's exporter, which folds eval-mode BatchNorm into a preceding convolution."""
+    import torch
+    import torch.nn as nn
+
+    class Act(nn.Module):
+        def forward(self, x):
+            if act == "leakyclamp":
+                return torch.clamp(torch.nn.functional.leaky_relu(x, 0.2), min=-0.4)
+            return torch.maximum(torch.maximum(x * 0.2, x), torch.tensor(-0.4))
+
+    layers = []
+    for li, (kh, kw, ci, co, relu_first, bn, pool) in enumerate(O.CNN_LAYERS):
+        conv = nn.Conv2d(ci, co, (kh, kw), padding=(0, (kw - 1) // 2), bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(np.ascontiguousarray(emb["conv"][li].transpose(3, 2, 0, 1))))      # HWIO -> OIHW
+        layers.append(conv)
+        if relu_first:
+            layers.append(nn.ReLU())
+        if bn:
+            g, b, m, v = emb["bn"][li]
+            norm = nn.BatchNorm2d(co, eps=1e-3)
+            with torch.no_grad():
+                norm.weight.copy_(torch.from_numpy(g)); norm.bias.copy_(torch.from_numpy(b))
+                norm.running_mean.copy_(torch.from_numpy(m)); norm.running_var.copy_(torch.from_numpy(v))
+            layers += [norm, Act()]
+        if pool:
+            layers.append(nn.MaxPool2d(pool))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = nn.Sequential(*layers)
+
+        def forward(self, x):                                   # [B, 76, 32, 1] -> [B, 1, 1, 96], the reference graph's interface
+            return self.body(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+
+    return Net().eval()
+
+
+@pytest.mark.parametrize("opset,act", [(17, "leakyclamp"), (13, "leakyclamp"), (13, "maxmul")])
+def test_embedding_written_by_pytorchs_own_exporter_loads_to_the_same_network(tmp_path, opset, act):
+    """Not the exporter the real file came from (that was tf2onnx), but a writer that is not ours: Conv with the eval-mode BatchNorm
+    folded in (scaled weights + bias), a standalone BatchNormalization behind conv0's Relu, LeakyRelu + Clip or Mul / Max chains,
+    MaxPool, NCHW with one Transpose either side."""
+    torch = pytest.importorskip("torch")
+    import io
+    import warnings
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    emb = W.synthetic_embedding(56)
+    module = _torch_embedding(emb, act)
+    path = os.path.join(tmp_path, "embedding_torch.onnx")
+    keep = onnx_proto_utils._add_onnxscript_fn
+    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    try:
+        buf = io.BytesIO()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.onnx.export(module, torch.rand(1, 76, 32, 1), buf, opset_version=opset, input_names=["input_1"], dynamo=False)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    finally:
+        onnx_proto_utils._add_onnxscript_fn = keep
+    with open(path, "wb") as f:
+        f.write(buf.getvalue())
+    got = onnx_ingest.load_embedding(path)
+    plain = os.path.join(tmp_path, "plain.onnx")
+    write_embedding(plain, emb)
+    _same_embedding(onnx_ingest.load_embedding(plain), got, atol=5e-7)
+    x = np.random.default_rng(2).normal(10, 1.5, (2, 76, 32, 1)).astype(np.float32)
+    want = O.embedding_stage(x, emb, np.float64)
+    np.testing.assert_allclose(O.embedding_stage(x, got, np.float64), want, rtol=0, atol=2e-5)
+    with torch.no_grad():
+        ref = module(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(ref, want, rtol=0, atol=5e-4 * max(1.0, float(np.abs(want).max())))
