@@ -198,3 +198,30 @@ def test_mel_stage_matches_an_independent_stft(golden):
     assert got.shape == db.shape == ((len(x) - 512) // 160 + 1, 32)
     np.testing.assert_allclose(got, db, rtol=0, atol=1e-6)
     np.testing.assert_allclose(O.mel_stage(x[None], np.float32)[0, 0], db, rtol=0, atol=2e-3)     # fp32 DFT of int16-scale audio
+
+
+def test_cnn_and_head_stages_match_torch_nn_in_float64():
+    """The oracle's embedding CNN and head restatements against an independent implementation of the same published architecture:
+    torch.nn.Conv2d / BatchNorm2d(eps 1e-3) / leaky_relu(0.2) + clamp(-0.4) / MaxPool2d in NCHW, and nn.Linear / LayerNorm / ReLU /
+    Sigmoid (| ReLU + softmax), both in float64 so that only the DEFINITIONS can differ.  The residual is the oracle's fp32 slope
+    and floor constants (0.2, -0.4 as float32: 1.5e-8 relative).  Pins conv orientation and padding, BatchNorm folding, pooling
+    windows, the LayerNorm epsilon and the Gemm orientation of the restatement to library kernels."""
+    torch = pytest.importorskip("torch")
+    import test_onnx_ingest as T
+    for seed in (56, 1234):
+        emb = W.synthetic_embedding(seed)
+        net = T._torch_embedding(emb).double()
+        x = np.random.default_rng(seed).normal(10, 1.5, (3, 76 + 16, 32, 1))          # taller than one window: 3 outputs per item
+        with torch.no_grad():
+            ref = net(torch.from_numpy(x)).numpy()
+        got = O.embedding_stage(x, emb, np.float64)
+        assert got.shape == ref.shape == (3, 3, 1, 96)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7)
+    for name, ln in (("alexa", None), ("timer", None), ("weather", True)):
+        head = W.synthetic_head(name, 7, layernorm=ln)
+        mod = T._torch_head(head["net"], head["T"], head["n_out"]).double()
+        f = np.random.default_rng(5).normal(0, 2, (4, head["T"], 96))
+        with torch.no_grad():
+            ref = mod(torch.from_numpy(f)).numpy()
+        got = O.head_stage(f, head, np.float64)
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=1e-12)
