@@ -862,3 +862,76 @@ def test_embedding_written_by_pytorchs_own_exporter_loads_to_the_same_network(tm
     with torch.no_grad():
         ref = module(torch.from_numpy(x)).numpy()
     np.testing.assert_allclose(ref, want, rtol=0, atol=5e-4 * max(1.0, float(np.abs(want).max())))
+
+
+def _torch_melspectrogram(top_db=80.0, hop=160):
+    """A torch module with the structure of torchlibrosa's Spectrogram + LogmelFilterBank as the notebook patches them (cell 15):
+    two Conv1d with window x cos / -sin kernels (center=False), real^2 + imag^2, matmul with melW, power_to_db with log_spec.max()."""
+    import torch
+    import torch.nn as nn
+    n = np.arange(512, dtype=np.float64)
+    win = np.zeros(512)
+    win[56:456] = W.hann_window().astype(np.float64)
+    ang = 2.0 * np.pi * np.outer(np.arange(257), n) / 512
+
+    class Mel(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv_real = nn.Conv1d(1, 257, 512, stride=hop, bias=False)
+            self.conv_imag = nn.Conv1d(1, 257, 512, stride=hop, bias=False)
+            with torch.no_grad():
+                self.conv_real.weight.copy_(torch.from_numpy((win * np.cos(ang))[:, None, :].astype(np.float32)))
+                self.conv_imag.weight.copy_(torch.from_numpy((-win * np.sin(ang))[:, None, :].astype(np.float32)))
+            self.melW = nn.Parameter(torch.from_numpy(W.mel_filterbank().astype(np.float32)), requires_grad=False)
+
+        def forward(self, x):                                   # [B, samples] -> [B, 1, frames, 32]
+            x = x[:, None, :]
+            real = self.conv_real(x)[:, None, :, :].transpose(2, 3)
+            imag = self.conv_imag(x)[:, None, :, :].transpose(2, 3)
+            spec = real ** 2 + imag ** 2
+            mel = torch.matmul(spec, self.melW)
+            log_spec = 10.0 * torch.log10(torch.clamp(mel, min=1e-10, max=float("inf")))
+            log_spec = log_spec - 10.0 * float(np.log10(max(1e-10, 1.0)))
+            return torch.maximum(log_spec, log_spec.max() - top_db)       # (the patched power_to_db: the call's maximum)
+
+    return Mel().eval()
+
+
+def test_melspectrogram_written_by_pytorchs_own_exporter_is_verified(tmp_path):
+    """The real melspectrogram.onnx came out of torch.onnx.export (notebook cell 15); so does this one.  The verifier must accept the
+    exporter's rendering of the recipe and still refuse another hop or top_db written the same way."""
+    torch = pytest.importorskip("torch")
+    import io
+    import warnings
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+
+    def export(module, path):
+        keep = onnx_proto_utils._add_onnxscript_fn
+        onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+        try:
+            buf = io.BytesIO()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.onnx.export(module, torch.rand(1, 1760) * 1000, buf, opset_version=12, input_names=["input"],
+                                  dynamic_axes={"input": {0: "batch", 1: "samples"}}, dynamo=False)
+        finally:
+            onnx_proto_utils._add_onnxscript_fn = keep
+        with open(path, "wb") as f:
+            f.write(buf.getvalue())
+
+    path = os.path.join(tmp_path, "melspectrogram_torch.onnx")
+    try:
+        export(_torch_melspectrogram(), path)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    res = onnx_ingest.verify_melspectrogram(path)
+    assert res["stft_kernel_max_abs_diff"] < 1e-6 and res["filterbank_max_abs_diff"] == 0.0 and res["top_db"] == 80.0
+    # the module itself computes what the oracle computes
+    x = (np.random.default_rng(4).normal(0, 3000, (2, 1760))).astype(np.float32)
+    with torch.no_grad():
+        ref = _torch_melspectrogram()(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(ref, O.mel_stage(x, np.float32), rtol=0, atol=2e-3)
+    for kw, why in ((dict(top_db=100.0), "top_db"), (dict(hop=128), "stride")):
+        export(_torch_melspectrogram(**kw), path)
+        with pytest.raises(ValueError, match=why):
+            onnx_ingest.verify_melspectrogram(path)
