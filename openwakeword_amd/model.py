@@ -84,18 +84,29 @@ def resolve_weights(weights: Union[str, dict, None]):
     raise ValueError("weights must be 'synthetic', a dict {'embedding':..., 'heads':...} or None")
 
 
-def resolve_embedding(embedding: Optional[dict], seed: Optional[int]) -> dict:
+def resolve_embedding(embedding: Optional[dict], seed: Optional[int], embedding_model_path: str = "",
+                      melspec_model_path: str = "") -> dict:
     """The shared speech-embedding network (utils.py:90-93 loads embedding_model.onnx next to the wake-word models): the
-    caller's weights, else the real file through onnx_ingest, else -- ONLY when synthetic weights were asked for -- the
-    random-init network.  Never silently synthetic: real head files next to a random embedding would score nonsense."""
-    if embedding is not None:
+    caller's weights, else the file the caller names (the reference's `embedding_model_path` / `melspec_model_path` keyword
+    arguments, utils.py:38-44), else the real file in resources/models through onnx_ingest, else -- ONLY when synthetic weights
+    were asked for -- the random-init network.  Never silently synthetic: real head files next to a random embedding would score
+    nonsense."""
+    for given in (embedding_model_path, melspec_model_path):
+        if given and given.endswith(".tflite"):                         # utils.py:75-76, for this backend
+            raise ValueError("The hip inference framework is selected, but tflite models were provided!")
+        if given and not os.path.exists(given):
+            raise ValueError(f"{given} does not exist")
+    if embedding is not None and not embedding_model_path:
+        if melspec_model_path:
+            from . import onnx_ingest
+            onnx_ingest.verify_melspectrogram(melspec_model_path)
         return embedding
-    path = FEATURE_MODELS["embedding"]["model_path"]
+    path = embedding_model_path or FEATURE_MODELS["embedding"]["model_path"]
     if os.path.exists(path):
         from . import onnx_ingest
         # real model files: the log-mel front end of the HIP path is analytic, so the melspectrogram graph that sits next to the
         # embedding network is VERIFIED to be that recipe (or the construction fails loudly: onnx_ingest.verify_melspectrogram)
-        mel_path = FEATURE_MODELS["melspectrogram"]["model_path"]
+        mel_path = melspec_model_path or FEATURE_MODELS["melspectrogram"]["model_path"]
         if os.path.exists(mel_path) and os.environ.get("OWW_TRUST_MELSPECTROGRAM") != "1":
             try:
                 onnx_ingest.verify_melspectrogram(mel_path)
@@ -333,7 +344,8 @@ class Model:
         except Exception as e:                       # ImportError of the package itself or of onnxruntime / tflite inside it
             raise ValueError(f"inference_framework='{framework}' is served by the reference package, which cannot be imported "
                              f"here ({type(e).__name__}: {e}); use inference_framework='hip'") from e
-        passthrough = {k: v for k, v in kwargs.items() if k not in ("weights", "device", "max_chunks", "vad_session", "use_mfma")}
+        passthrough = {k: v for k, v in kwargs.items() if k not in ("weights", "max_chunks", "vad_session", "use_mfma")
+                       and not (k == "device" and not isinstance(v, str))}      # (the reference's own device is "cpu" / "gpu")
         return reference_package.Model(*args, **passthrough)
 
     def __init__(self, wakeword_models: List[str] = [], class_mapping_dicts: List[dict] = [],
@@ -357,7 +369,15 @@ class Model:
             else:
                 name, head = _load_head(m, seed)
                 heads[name] = head
-        embedding = resolve_embedding(embedding, seed)
+        # the keyword arguments the reference hands on to AudioFeatures (model.py:212, utils.py:38-44)
+        unknown = sorted(set(kwargs) - {"melspec_model_path", "embedding_model_path", "sr", "ncpu"})
+        if unknown:
+            raise TypeError(f"AudioFeatures.__init__() got an unexpected keyword argument '{unknown[0]}'")
+        if int(kwargs.get("sr", 16000)) != 16000:
+            raise ValueError("the HIP path runs the reference's 16 kHz models; resample first (openwakeword_amd.resample)")
+        if isinstance(device, str):                     # the reference's device is "cpu" / "gpu" (utils.py:43): this backend has one answer
+            device = 0
+        embedding = resolve_embedding(embedding, seed, kwargs.get("embedding_model_path", "") or "", kwargs.get("melspec_model_path", "") or "")
 
         self.models: Dict[str, dict] = heads
         self.model_inputs = {n: int(h["T"]) for n, h in heads.items()}          # model.py:156

@@ -509,3 +509,81 @@ def test_batched_vad_gate_matches_single_stream_models(golden):
         bm.close()
         for m in singles:
             m.close()
+
+
+@gpu
+def test_models_loaded_by_path_from_files_written_by_pytorchs_exporter(tmp_path, golden):
+    """/root/reference/tests/test_models.py:50-66 (load models by path) with files a user would actually have: wake-word heads,
+    embedding network and melspectrogram graph written by torch.onnx.export (tests/test_onnx_ingest.py: the exporter the reference
+    uses, train.py:144-165), named through the reference's own keyword arguments (wakeword_models=[paths], embedding_model_path,
+    melspec_model_path: model.py:38-60, utils.py:38-44).  Scores must match the oracle on the SOURCE weights."""
+    pytest.importorskip("torch")
+    import test_onnx_ingest as T
+    from openwakeword_amd import Model
+    w = _weights(["alexa", "timer"])
+    paths = {}
+    try:
+        for n in ("alexa", "timer"):
+            paths[n] = str(tmp_path / f"{n}_custom.onnx")
+            T._torch_export(T._torch_head(w["heads"][n]["net"], w["heads"][n]["T"], w["heads"][n]["n_out"]), w["heads"][n]["T"], paths[n], 13)
+        import io, warnings, torch
+        from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+        keep = onnx_proto_utils._add_onnxscript_fn
+        onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+        try:
+            for name, module, x in (("embedding_model", T._torch_embedding(w["embedding"]), torch.rand(1, 76, 32, 1)),
+                                    ("melspectrogram", T._torch_melspectrogram(), torch.rand(1, 1760) * 1000)):
+                buf = io.BytesIO()
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    torch.onnx.export(module, x, buf, opset_version=13, dynamo=False,
+                                      dynamic_axes={"x": {0: "b", 1: "n"}} if name == "melspectrogram" else None,
+                                      input_names=["x"] if name == "melspectrogram" else None)
+                paths[name] = str(tmp_path / f"{name}.onnx")
+                open(paths[name], "wb").write(buf.getvalue())
+        finally:
+            onnx_proto_utils._add_onnxscript_fn = keep
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    m = Model(wakeword_models=[paths["alexa"], paths["timer"]], embedding_model_path=paths["embedding_model"],
+              melspec_model_path=paths["melspectrogram"], ncpu=2, device="gpu")
+    try:
+        assert set(m.models) == {"alexa_custom", "timer_custom"} and m.model_outputs == {"alexa_custom": 1, "timer_custom": 7}
+        clip = golden["pcm/hey_jane"]
+        got = m.predict_clip(clip)
+    finally:
+        m.close()
+    # against a model built from the SOURCE weights (same seed for the random audio that seeds the feature ring, utils.py:169)
+    m2 = Model(wakeword_models=[paths["alexa"], paths["timer"]], embedding_model_path=paths["embedding_model"], melspec_model_path=paths["melspectrogram"])
+    try:
+        src = Model(wakeword_models=["alexa_custom", "timer_custom"],
+                    weights={"embedding": w["embedding"], "heads": {"alexa_custom": w["heads"]["alexa"], "timer_custom": w["heads"]["timer"]}})
+        try:
+            np.random.seed(5); m2.reset(); a = m2.predict_clip(clip)
+            np.random.seed(5); src.reset(); b = src.predict_clip(clip)
+        finally:
+            src.close()
+    finally:
+        m2.close()
+    assert len(a) == len(b) == len(got) and len(a) > 20
+    for fa, fb in zip(a, b):
+        assert set(fa) == set(fb)
+        for k in fa:
+            assert abs(fa[k] - fb[k]) <= 1e-4, (k, fa[k], fb[k])       # (the exporter folded BatchNorm into the convolutions: fp32 round-off)
+    with pytest.raises(ValueError, match="tflite"):
+        Model(wakeword_models=[paths["alexa"]], embedding_model_path=str(tmp_path / "embedding_model.tflite"))
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        Model(wakeword_models=[paths["alexa"]], embedding_model_path=paths["embedding_model"], melspec_path="x")
+    bad = str(tmp_path / "mel_hop128.onnx")
+    T_mod = T._torch_melspectrogram(hop=128)
+    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    try:
+        buf = io.BytesIO()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.onnx.export(T_mod, torch.rand(1, 1760), buf, opset_version=13, dynamo=False)
+        open(bad, "wb").write(buf.getvalue())
+    finally:
+        onnx_proto_utils._add_onnxscript_fn = keep
+    with pytest.raises(ValueError, match="stride"):          # a front end the analytic kernel does not compute is refused, not ignored
+        Model(wakeword_models=[paths["alexa"]], embedding_model_path=paths["embedding_model"], melspec_model_path=bad)
