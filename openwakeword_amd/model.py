@@ -565,7 +565,8 @@ class BatchedModel:
 
     def __init__(self, n_streams: int, wakeword_models: Sequence[str], weights: Union[str, dict, None] = None,
                  device: int = 0, max_chunks: int = 1, hip_stream: int = 0, vad_weights: Optional[dict] = None,
-                 vad_threshold: float = 0.0, use_mfma: Optional[int] = None, calibration_pcm="default"):
+                 vad_threshold: float = 0.0, use_mfma: Optional[int] = None, calibration_pcm="default",
+                 embedding_model_path: str = "", melspec_model_path: str = ""):
         # same weight resolution as Model: real .onnx files (heads AND the shared embedding network) unless synthetic
         # weights are asked for explicitly -- never a random-init embedding under real heads
         seed, emb, given = resolve_weights(weights)
@@ -576,7 +577,7 @@ class BatchedModel:
             else:
                 name, head = _load_head(m, seed)
                 heads[name] = head
-        emb = resolve_embedding(emb, seed)
+        emb = resolve_embedding(emb, seed, embedding_model_path, melspec_model_path)       # (as Model: utils.py:38-44)
         # vad_weights: the on-device voice-activity network (weights.synthetic_vad layout) -- BASELINE configs[4]: network + gate
         # fused into every step.  With a gate asked for and no weights given, a silero_vad.onnx next to the package is ingested
         # when its graph is the architecture the kernels implement (onnx_ingest.load_vad); a graph it refuses, or no file, leaves
