@@ -11,13 +11,19 @@ may.
 PARITY STATUS: the reference's own arithmetic lives in
 un-vendored third-party code (onnxruntime>=1.10,<2 executing melspectrogram.onnx /
 embedding_model.onnx / <wakeword>.onnx, release assets v0.5.1) that is absent from
-/root/reference and from this machine.  The *stage math* below (mel, CNN, heads) is
-therefore "parity unpinned" against the ONNX files -- it restates the published
-recipes cited per function.  The *streaming / control logic* IS pinned: the
-reference's own ``openwakeword.utils.AudioFeatures`` and ``openwakeword.model.Model``
-are executed (tests/golden/make_golden.py) with this file's stage math plugged in at
-the reference's inference-backend seam, and ``OracleAudioFeatures`` / ``OracleModel``
-must reproduce those outputs (tests/test_oracle_golden.py).
+/root/reference and from this machine, so the *stage math* below (mel, CNN, heads) is
+"parity unpinned" against the RELEASED files -- it restates the published recipes cited
+per function.  What IS pinned:
+  * the streaming / control logic: the reference's own ``openwakeword.utils.AudioFeatures``
+    and ``openwakeword.model.Model`` are executed (tests/golden/make_golden.py) with this
+    file's stage math plugged in at the reference's inference-backend seam;
+  * stage math + control logic together on real model FILES: the reference's own Model runs
+    on heads / embedding / melspectrogram graphs written by PyTorch's ONNX exporter (the
+    tool the reference exports with) over a generic ONNX evaluator (oracle/mini_ort.py),
+    with nothing of this file in the loop (tests/golden/make_golden_onnx.py);
+  * the stage math against library kernels in float64 (torch.stft, torch.nn).
+``OracleAudioFeatures`` / ``OracleModel`` must reproduce all of these
+(tests/test_oracle_golden.py).
 
 Reference citations are relative to /root/reference.
 """

@@ -33,3 +33,24 @@ VAD_CASES = [
     ("vad640", ["alexa"], "alexa_test", dict(chunk_size=640), 0.5),
     ("vadnp", ["hey_mycroft"], "hey_mycroft_test", dict(chunk_size=1280, padding=0), 0.5),
 ]
+
+# The reference on real model FILES (tests/golden/make_golden_onnx.py): heads written by PyTorch's exporter under these names and
+# opsets (13 and older: decomposed LayerNorm; 17: the fused operator), loaded BY PATH; multiclass = the catalogue's timer shape.
+ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom"]
+ONNX_HEAD_OPSETS = {"alexa_custom": 13, "mycroft_custom": 17, "timer_custom": 12}
+ONNX_FILE_CASES = [
+    ("f1280", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=1280)),
+    ("f1280j", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=1280)),
+    ("f2560", ["alexa_custom", "mycroft_custom"], "hey_mycroft_test", dict(chunk_size=2560)),
+    ("f1024", ["alexa_custom"], "alexa_test", dict(chunk_size=1024)),
+    ("ftimer", ["timer_custom"], "hey_mycroft_test", dict(chunk_size=1280)),
+    ("fpat", ["alexa_custom", "mycroft_custom"], "hey_jane",
+     dict(chunk_size=1280, patience={"alexa_custom": 2}, threshold={"alexa_custom": 0.4})),
+]
+
+
+def onnx_file_weights():
+    """{"embedding", "heads"}: the synthetic weights behind the exported files (seed SEED_WEIGHTS)."""
+    from openwakeword_amd import weights as W
+    base = {"alexa_custom": "alexa", "mycroft_custom": "hey_mycroft", "timer_custom": "timer"}
+    return {"embedding": W.synthetic_embedding(SEED_WEIGHTS), "heads": {n: W.synthetic_head(b, SEED_WEIGHTS) for n, b in base.items()}}

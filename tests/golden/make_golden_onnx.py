@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/ref_onnx_files.npz: the REFERENCE's own Python (/root/reference/openwakeword: Model.predict_clip ->
+AudioFeatures -> ort.InferenceSession(...).run) running on real model FILES, with nothing of this repository's restatement in the
+loop.  The files are written by PyTorch's own ONNX exporter (tests/torch_export.py: the tool the reference exports its models with,
+train.py:144-165) from the deterministic synthetic weights; `onnxruntime` is oracle/mini_ort.py, a generic numpy evaluator of the ONNX
+operator semantics (held to the torch modules in tests/test_mini_ort.py) that knows nothing about these networks.
+
+Run only in the build container (needs /root/reference):   python tests/golden/make_golden_onnx.py
+Consumers regenerate the same files with the same exporter and compare: the oracle on the source weights (CPU,
+tests/test_oracle_golden.py) and the HIP Model loading the files BY PATH (GPU, tests/test_model_api.py).
+
+What these vectors add to ref_streaming.npz: there the three networks behind the reference's seams were oracle functions; here they
+are graph files evaluated operator by operator -- the reference's file-loading, input / output discovery (model.py:153-159) and its
+whole predict path on what a user would hand it.  What they still cannot pin: the weights and exporter idioms of the RELEASED files.
+"""
+import os
+import sys
+import tempfile
+import wave
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(__file__))
+REF = "/root/reference"
+
+from oracle import mini_ort                           # noqa: E402
+import cases                                          # noqa: E402
+import torch_export as TE                             # noqa: E402
+
+
+def main():
+    sys.modules["onnxruntime"] = mini_ort.as_module()
+    sys.path.insert(0, REF)
+    import openwakeword                               # the real reference package
+    assert os.path.realpath(openwakeword.__file__).startswith(REF)
+
+    clips = {}
+    for c in cases.CLIPS:
+        with wave.open(os.path.join(REF, "tests", "data", c + ".wav"), "rb") as f:
+            clips[c] = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16).copy()
+
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        paths = TE.export_reference_files(d, cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+        for cid, head_names, clip, kw in cases.ONNX_FILE_CASES:
+            np.random.seed(cases.SEED_NP)
+            mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",
+                                     melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+            assert sorted(mdl.models) == sorted(head_names), mdl.models.keys()
+            preds = mdl.predict_clip(clips[clip], **kw)
+            labels = sorted(preds[0].keys())
+            out[f"{cid}/labels"] = np.array(labels)
+            out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
+            out[f"{cid}/features"] = mdl.preprocessor.feature_buffer.astype(np.float32)
+            if cid == "f1280":
+                out["init/model_inputs"] = np.array([mdl.model_inputs[n] for n in sorted(mdl.models)])
+                out["init/model_outputs"] = np.array([mdl.model_outputs[n] for n in sorted(mdl.models)])
+    path = os.path.join(os.path.dirname(__file__), "ref_onnx_files.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+    for cid, *_ in cases.ONNX_FILE_CASES:
+        s = out[f"{cid}/scores"]
+        print(f"  {cid:10s} frames={s.shape[0]:3d} labels={list(out[cid + '/labels'])} max={s.max(axis=0).round(4)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -518,21 +518,21 @@ def test_models_loaded_by_path_from_files_written_by_pytorchs_exporter(tmp_path,
     uses, train.py:144-165), named through the reference's own keyword arguments (wakeword_models=[paths], embedding_model_path,
     melspec_model_path: model.py:38-60, utils.py:38-44).  Scores must match the oracle on the SOURCE weights."""
     pytest.importorskip("torch")
-    import test_onnx_ingest as T
+    import torch_export as T
     from openwakeword_amd import Model
     w = _weights(["alexa", "timer"])
     paths = {}
     try:
         for n in ("alexa", "timer"):
             paths[n] = str(tmp_path / f"{n}_custom.onnx")
-            T._torch_export(T._torch_head(w["heads"][n]["net"], w["heads"][n]["T"], w["heads"][n]["n_out"]), w["heads"][n]["T"], paths[n], 13)
+            T.torch_export_head(T.torch_head(w["heads"][n]["net"], w["heads"][n]["T"], w["heads"][n]["n_out"]), w["heads"][n]["T"], paths[n], 13)
         import io, warnings, torch
         from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
         keep = onnx_proto_utils._add_onnxscript_fn
         onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
         try:
-            for name, module, x in (("embedding_model", T._torch_embedding(w["embedding"]), torch.rand(1, 76, 32, 1)),
-                                    ("melspectrogram", T._torch_melspectrogram(), torch.rand(1, 1760) * 1000)):
+            for name, module, x in (("embedding_model", T.torch_embedding(w["embedding"]), torch.rand(1, 76, 32, 1)),
+                                    ("melspectrogram", T.torch_melspectrogram(), torch.rand(1, 1760) * 1000)):
                 buf = io.BytesIO()
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
@@ -575,7 +575,7 @@ def test_models_loaded_by_path_from_files_written_by_pytorchs_exporter(tmp_path,
     with pytest.raises(TypeError, match="unexpected keyword"):
         Model(wakeword_models=[paths["alexa"]], embedding_model_path=paths["embedding_model"], melspec_path="x")
     bad = str(tmp_path / "mel_hop128.onnx")
-    T_mod = T._torch_melspectrogram(hop=128)
+    T_mod = T.torch_melspectrogram(hop=128)
     onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
     try:
         buf = io.BytesIO()
@@ -587,3 +587,38 @@ def test_models_loaded_by_path_from_files_written_by_pytorchs_exporter(tmp_path,
         onnx_proto_utils._add_onnxscript_fn = keep
     with pytest.raises(ValueError, match="stride"):          # a front end the analytic kernel does not compute is refused, not ignored
         Model(wakeword_models=[paths["alexa"]], embedding_model_path=paths["embedding_model"], melspec_model_path=bad)
+
+
+@gpu
+@pytest.mark.parametrize("case", cases.ONNX_FILE_CASES, ids=[c[0] for c in cases.ONNX_FILE_CASES])
+def test_hip_model_on_exported_files_matches_the_reference_on_the_same_files(tmp_path, golden, case):
+    """The drop-in claim on real FILES: heads, embedding network and melspectrogram graph written by PyTorch's exporter, loaded by path
+    through the reference's own keyword arguments -- against what the reference's own code returned for the same files and clips
+    (tests/golden/make_golden_onnx.py: `openwakeword.Model(..., inference_framework="onnx")` over a generic ONNX evaluator).  1e-4."""
+    pytest.importorskip("torch")
+    import os
+    import torch_export as TE
+    from openwakeword_amd import Model
+    cid, head_names, clip, kw = case
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    try:
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=[paths[n] for n in head_names], melspec_model_path=paths["melspectrogram"],
+              embedding_model_path=paths["embedding_model"])
+    try:
+        assert sorted(m.models) == sorted(head_names)
+        preds = m.predict_clip(golden["pcm/" + clip], **kw)
+        labels = list(ref[f"{cid}/labels"])
+        assert sorted(preds[0].keys()) == labels
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        want = ref[f"{cid}/scores"]
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=TOL_SCORE)
+        feats = ref[f"{cid}/features"]
+        n = min(len(feats), 120)
+        np.testing.assert_allclose(m.preprocessor.get_features(n)[0], feats[-n:], rtol=0, atol=2e-4)
+    finally:
+        m.close()

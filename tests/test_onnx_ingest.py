@@ -671,80 +671,14 @@ def test_melspectrogram_file_is_verified_against_the_analytic_front_end(tmp_path
     np.testing.assert_allclose(O.mel_stage(x[None].astype(np.float32), np.float64)[0, 0], db, rtol=0, atol=1e-6)
 
 
+from torch_export import torch_export_head as _torch_export, torch_head as _torch_head, torch_embedding as _torch_embedding, torch_melspectrogram as _torch_melspectrogram, export as _export  # noqa: E402
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # A THIRD writer that is not ours: PyTorch's own TorchScript ONNX exporter -- the one the reference exports its wake-word models
 # with (train.py:144-165: torch.onnx.export(model, rand(input_shape)[None], path, output_names=[...]), multiclass models wrapped in
 # a softmax).  The `onnx` package is not installed here; the exporter only needs it for a post-pass that splices onnx-script
 # functions into the finished ModelProto bytes (none occur in these models), so the test replaces that post-pass by the identity.
-def _torch_export(module, T, path, opset):
-    import io
-    import warnings
-    import torch
-    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
-    keep = onnx_proto_utils._add_onnxscript_fn
-    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
-    try:
-        buf = io.BytesIO()
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            torch.onnx.export(module.eval(), torch.rand(T, 96)[None, ], buf, opset_version=opset, output_names=["out"], dynamo=False)
-    finally:
-        onnx_proto_utils._add_onnxscript_fn = keep
-    with open(path, "wb") as f:
-        f.write(buf.getvalue())
-
-
-def _torch_head(net, T, n_out, n_blocks=1):
-    """The architecture of train.py:56-83 (flatten, Linear + LayerNorm + ReLU, blocks of the same, Linear, Sigmoid | ReLU) with the
-    given weights; multiclass models end in ReLU and are exported under a softmax wrapper (train.py:152-165)."""
-    import torch
-    import torch.nn as nn
-
-    class Block(nn.Module):
-        def __init__(self, w, b, ln):
-            super().__init__()
-            self.fc = nn.Linear(w.shape[0], w.shape[1])
-            self.norm = nn.LayerNorm(w.shape[1]) if ln is not None else nn.Identity()      # (the catalogue's multiclass heads have none)
-            self.act = nn.ReLU()
-            with torch.no_grad():
-                self.fc.weight.copy_(torch.from_numpy(w.T.copy())); self.fc.bias.copy_(torch.from_numpy(b))
-                if ln is not None:
-                    self.norm.weight.copy_(torch.from_numpy(ln[0])); self.norm.bias.copy_(torch.from_numpy(ln[1]))
-
-        def forward(self, x):
-            return self.act(self.norm(self.fc(x)))
-
-    class Net(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.flatten = nn.Flatten()
-            self.first = Block(net["w1"], net["b1"], net["ln1"])
-            self.blocks = nn.ModuleList([Block(net["w2"], net["b2"], net["ln2"]) for _ in range(n_blocks)])
-            self.last = nn.Linear(net["w3"].shape[0], n_out)
-            self.last_act = nn.Sigmoid() if n_out == 1 else nn.ReLU()
-            with torch.no_grad():
-                self.last.weight.copy_(torch.from_numpy(net["w3"].T.copy())); self.last.bias.copy_(torch.from_numpy(net["b3"]))
-
-        def forward(self, x):
-            x = self.first(self.flatten(x))
-            for blk in self.blocks:
-                x = blk(x)
-            return self.last_act(self.last(x))
-
-    if n_out == 1:
-        return Net()
-
-    class Wrapped(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.model = Net()
-
-        def forward(self, x):
-            return torch.nn.functional.softmax(self.model(x), dim=1)
-
-    return Wrapped()
-
-
 @pytest.mark.parametrize("name,opset,ln", [("alexa", 17, None), ("alexa", 13, None), ("alexa", 11, None), ("hey_mycroft", 14, None),
                                            ("timer", 17, None), ("timer", 12, None), ("timer", 17, True), ("weather", 13, True)])
 def test_heads_written_by_pytorchs_own_exporter_load_to_the_same_weights(tmp_path, name, opset, ln):
@@ -786,72 +720,19 @@ def test_a_torch_exported_head_with_two_blocks_is_refused_not_misread(tmp_path):
         onnx_ingest.load_head(path)
 
 
-def _torch_embedding(emb, act="leakyclamp"):
-    """The speech-embedding CNN (notebook cell 18, restated in oracle/oww_oracle.py: CNN_LAYERS) as a torch module in NCHW, input
-    [B, 76, 32, 1] permuted once -- for PyTorch's exporter, which folds eval-mode BatchNorm into a preceding convolution."""
-    import torch
-    import torch.nn as nn
-
-    class Act(nn.Module):
-        def forward(self, x):
-            if act == "leakyclamp":
-                return torch.clamp(torch.nn.functional.leaky_relu(x, 0.2), min=-0.4)
-            return torch.maximum(torch.maximum(x * 0.2, x), torch.tensor(-0.4))
-
-    layers = []
-    for li, (kh, kw, ci, co, relu_first, bn, pool) in enumerate(O.CNN_LAYERS):
-        conv = nn.Conv2d(ci, co, (kh, kw), padding=(0, (kw - 1) // 2), bias=False)
-        with torch.no_grad():
-            conv.weight.copy_(torch.from_numpy(np.ascontiguousarray(emb["conv"][li].transpose(3, 2, 0, 1))))      # HWIO -> OIHW
-        layers.append(conv)
-        if relu_first:
-            layers.append(nn.ReLU())
-        if bn:
-            g, b, m, v = emb["bn"][li]
-            norm = nn.BatchNorm2d(co, eps=1e-3)
-            with torch.no_grad():
-                norm.weight.copy_(torch.from_numpy(g)); norm.bias.copy_(torch.from_numpy(b))
-                norm.running_mean.copy_(torch.from_numpy(m)); norm.running_var.copy_(torch.from_numpy(v))
-            layers += [norm, Act()]
-        if pool:
-            layers.append(nn.MaxPool2d(pool))
-
-    class Net(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.body = nn.Sequential(*layers)
-
-        def forward(self, x):                                   # [B, 76, 32, 1] -> [B, 1, 1, 96], the reference graph's interface
-            return self.body(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-
-    return Net().eval()
-
-
 @pytest.mark.parametrize("opset,act", [(17, "leakyclamp"), (13, "leakyclamp"), (13, "maxmul")])
 def test_embedding_written_by_pytorchs_own_exporter_loads_to_the_same_network(tmp_path, opset, act):
     """Not the exporter the real file came from (that was tf2onnx), but a writer that is not ours: Conv with the eval-mode BatchNorm
     folded in (scaled weights + bias), a standalone BatchNormalization behind conv0's Relu, LeakyRelu + Clip or Mul / Max chains,
     MaxPool, NCHW with one Transpose either side."""
     torch = pytest.importorskip("torch")
-    import io
-    import warnings
-    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
     emb = W.synthetic_embedding(56)
     module = _torch_embedding(emb, act)
     path = os.path.join(tmp_path, "embedding_torch.onnx")
-    keep = onnx_proto_utils._add_onnxscript_fn
-    onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
     try:
-        buf = io.BytesIO()
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            torch.onnx.export(module, torch.rand(1, 76, 32, 1), buf, opset_version=opset, input_names=["input_1"], dynamo=False)
+        _export(module, torch.rand(1, 76, 32, 1), path, opset, input_names=["input_1"])
     except Exception as e:                                  # noqa: BLE001
         pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
-    finally:
-        onnx_proto_utils._add_onnxscript_fn = keep
-    with open(path, "wb") as f:
-        f.write(buf.getvalue())
     got = onnx_ingest.load_embedding(path)
     plain = os.path.join(tmp_path, "plain.onnx")
     write_embedding(plain, emb)
@@ -864,60 +745,13 @@ def test_embedding_written_by_pytorchs_own_exporter_loads_to_the_same_network(tm
     np.testing.assert_allclose(ref, want, rtol=0, atol=5e-4 * max(1.0, float(np.abs(want).max())))
 
 
-def _torch_melspectrogram(top_db=80.0, hop=160):
-    """A torch module with the structure of torchlibrosa's Spectrogram + LogmelFilterBank as the notebook patches them (cell 15):
-    two Conv1d with window x cos / -sin kernels (center=False), real^2 + imag^2, matmul with melW, power_to_db with log_spec.max()."""
-    import torch
-    import torch.nn as nn
-    n = np.arange(512, dtype=np.float64)
-    win = np.zeros(512)
-    win[56:456] = W.hann_window().astype(np.float64)
-    ang = 2.0 * np.pi * np.outer(np.arange(257), n) / 512
-
-    class Mel(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.conv_real = nn.Conv1d(1, 257, 512, stride=hop, bias=False)
-            self.conv_imag = nn.Conv1d(1, 257, 512, stride=hop, bias=False)
-            with torch.no_grad():
-                self.conv_real.weight.copy_(torch.from_numpy((win * np.cos(ang))[:, None, :].astype(np.float32)))
-                self.conv_imag.weight.copy_(torch.from_numpy((-win * np.sin(ang))[:, None, :].astype(np.float32)))
-            self.melW = nn.Parameter(torch.from_numpy(W.mel_filterbank().astype(np.float32)), requires_grad=False)
-
-        def forward(self, x):                                   # [B, samples] -> [B, 1, frames, 32]
-            x = x[:, None, :]
-            real = self.conv_real(x)[:, None, :, :].transpose(2, 3)
-            imag = self.conv_imag(x)[:, None, :, :].transpose(2, 3)
-            spec = real ** 2 + imag ** 2
-            mel = torch.matmul(spec, self.melW)
-            log_spec = 10.0 * torch.log10(torch.clamp(mel, min=1e-10, max=float("inf")))
-            log_spec = log_spec - 10.0 * float(np.log10(max(1e-10, 1.0)))
-            return torch.maximum(log_spec, log_spec.max() - top_db)       # (the patched power_to_db: the call's maximum)
-
-    return Mel().eval()
-
-
 def test_melspectrogram_written_by_pytorchs_own_exporter_is_verified(tmp_path):
     """The real melspectrogram.onnx came out of torch.onnx.export (notebook cell 15); so does this one.  The verifier must accept the
     exporter's rendering of the recipe and still refuse another hop or top_db written the same way."""
     torch = pytest.importorskip("torch")
-    import io
-    import warnings
-    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
 
     def export(module, path):
-        keep = onnx_proto_utils._add_onnxscript_fn
-        onnx_proto_utils._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
-        try:
-            buf = io.BytesIO()
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                torch.onnx.export(module, torch.rand(1, 1760) * 1000, buf, opset_version=12, input_names=["input"],
-                                  dynamic_axes={"input": {0: "batch", 1: "samples"}}, dynamo=False)
-        finally:
-            onnx_proto_utils._add_onnxscript_fn = keep
-        with open(path, "wb") as f:
-            f.write(buf.getvalue())
+        _export(module, torch.rand(1, 1760) * 1000, path, 12, input_names=["input"], dynamic_axes={"input": {0: "batch", 1: "samples"}})
 
     path = os.path.join(tmp_path, "melspectrogram_torch.onnx")
     try:

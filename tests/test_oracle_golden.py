@@ -207,10 +207,10 @@ def test_cnn_and_head_stages_match_torch_nn_in_float64():
     and floor constants (0.2, -0.4 as float32: 1.5e-8 relative).  Pins conv orientation and padding, BatchNorm folding, pooling
     windows, the LayerNorm epsilon and the Gemm orientation of the restatement to library kernels."""
     torch = pytest.importorskip("torch")
-    import test_onnx_ingest as T
+    import torch_export as TE
     for seed in (56, 1234):
         emb = W.synthetic_embedding(seed)
-        net = T._torch_embedding(emb).double()
+        net = TE.torch_embedding(emb).double()
         x = np.random.default_rng(seed).normal(10, 1.5, (3, 76 + 16, 32, 1))          # taller than one window: 3 outputs per item
         with torch.no_grad():
             ref = net(torch.from_numpy(x)).numpy()
@@ -219,9 +219,36 @@ def test_cnn_and_head_stages_match_torch_nn_in_float64():
         np.testing.assert_allclose(got, ref, rtol=0, atol=3e-7)
     for name, ln in (("alexa", None), ("timer", None), ("weather", True)):
         head = W.synthetic_head(name, 7, layernorm=ln)
-        mod = T._torch_head(head["net"], head["T"], head["n_out"]).double()
+        mod = TE.torch_head(head["net"], head["T"], head["n_out"]).double()
         f = np.random.default_rng(5).normal(0, 2, (4, head["T"], 96))
         with torch.no_grad():
             ref = mod(torch.from_numpy(f)).numpy()
         got = O.head_stage(f, head, np.float64)
         np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=0, atol=1e-12)
+
+
+@pytest.fixture(scope="module")
+def golden_files():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+
+
+@pytest.mark.parametrize("case", cases.ONNX_FILE_CASES, ids=[c[0] for c in cases.ONNX_FILE_CASES])
+def test_oracle_matches_the_reference_run_on_exported_model_files(golden, golden_files, case):
+    """tests/golden/make_golden_onnx.py: the reference's own Model.predict_clip on heads / embedding / melspectrogram FILES written by
+    PyTorch's exporter, evaluated by a generic ONNX interpreter -- no line of this repository's restatement in that loop.  The oracle
+    on the SOURCE weights must give the same scores (the exporter folded BatchNorm into the convolutions in fp32: round-off)."""
+    cid, head_names, clip, kw = case
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    mdl = O.OracleModel({n: w["heads"][n] for n in head_names}, w["embedding"])
+    preds = mdl.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(golden_files[f"{cid}/labels"])
+    assert sorted(preds[0].keys()) == labels
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    want = golden_files[f"{cid}/scores"]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(mdl.preprocessor.features, golden_files[f"{cid}/features"], rtol=0, atol=1e-4)
+    if cid == "f1280":                                      # what the reference read from the files' input / output declarations
+        assert list(golden_files["init/model_inputs"]) == [16, 16] and list(golden_files["init/model_outputs"]) == [1, 1]
