@@ -443,10 +443,28 @@ def load_head(path: str) -> dict:
     return head
 
 
+def _pick_zero(fl: _Flow, n: dict) -> bool:
+    """Gather(x, 0): the element pick a scripted `if score[0, 0] > 0.5:` becomes (one Gather per index)."""
+    if n["op"] != "Gather" or len(n["inputs"]) < 2 or n["inputs"][1] not in fl.inits:
+        return False
+    idx = np.asarray(fl.inits[n["inputs"][1]])
+    return idx.size == 1 and int(idx.reshape(-1)[0]) == 0
+
+
 def _gate_condition(fl: _Flow, s1: str, where: str) -> dict:
     """The comparison node that tests the first network's score against the gate threshold."""
-    t = _shape_only(fl, s1)
-    cmps = [c for c in fl.consumers.get(t, []) + fl.consumers.get(s1, []) if c["op"] in ("Greater", "Less", "GreaterOrEqual", "LessOrEqual")]
+    _CMP = ("Greater", "Less", "GreaterOrEqual", "LessOrEqual")
+    cmps, seen, todo = [], set(), [s1]
+    while todo:                      # through shape-only plumbing and element picks of the [1, 1] score (other consumers: Where / If arms)
+        t = todo.pop()
+        if t in seen:
+            continue
+        seen.add(t)
+        for c in fl.consumers.get(t, []):
+            if c["op"] in _CMP:
+                cmps.append(c)
+            elif c["op"] in ("Squeeze", "Unsqueeze", "Reshape", "Identity", "Flatten") or _pick_zero(fl, c):
+                todo.append(c["outputs"][0])
     if not cmps:
         fl.refuse(f"{where}: two networks but no comparison of the first score with a threshold")
     n = cmps[0]
@@ -478,7 +496,8 @@ def _gate_if(fl: _Flow, node: dict, feats: str, s1: str):
     t = cond
     while t != node["inputs"][0]:                                   # Squeeze / ReduceMax / Reshape between the comparison and the If
         cons = fl.consumers.get(t, [])
-        if len(cons) != 1 or cons[0]["op"] not in ("Squeeze", "Reshape", "ReduceMax", "ReduceMin", "Identity", "Cast"):
+        if len(cons) != 1 or (cons[0]["op"] not in ("Squeeze", "Reshape", "ReduceMax", "ReduceMin", "Identity") and
+                              not (cons[0]["op"] == "Cast" and int(cons[0]["attrs"].get("to", 9)) == 9)):      # (Cast to bool only)
             fl.refuse(f"gate (If): the condition passes through {[c['op'] for c in cons]}")
         t = cons[0]["outputs"][0]
     then_g, else_g = node["attrs"].get("then_branch"), node["attrs"].get("else_branch")
@@ -493,9 +512,16 @@ def _gate_if(fl: _Flow, node: dict, feats: str, s1: str):
         fl.refuse(f"gate (If): the else-branch returns '{src}', not the first network's score")
     # then: the second network applied to the same features (captured from the outer scope)
     tf = _Flow(then_g, fl.path)
-    lin = [c for c in tf.consumers.get(feats, []) if c["op"] in ("Gemm", "MatMul")]
+    inner = feats                    # ... or to its own flattening of the model input (what torch.jit.script + the exporter emit)
+    x_outer = fl.start()
+    own = [c for c in tf.consumers.get(x_outer, []) if c["op"] in ("Flatten", "Reshape")] if x_outer != feats else []
+    if not tf.consumers.get(feats) and len(own) == 1:
+        if own[0]["op"] == "Flatten" and int(own[0]["attrs"].get("axis", 1)) != 1:
+            fl.refuse(f"gate (If): the then-branch flattens the input over axis {own[0]['attrs'].get('axis')}")
+        inner = _shape_only(tf, own[0]["outputs"][0])
+    lin = [c for c in tf.consumers.get(inner, []) if c["op"] in ("Gemm", "MatMul")]
     if len(lin) != 1:
-        fl.refuse(f"gate (If): the then-branch does not apply one network to the features ({[c['op'] for c in tf.consumers.get(feats, [])]})")
+        fl.refuse(f"gate (If): the then-branch does not apply one network to the features ({[c['op'] for c in tf.consumers.get(inner, [])]})")
     net2, tail2, _ = _walk_net(tf, lin[0], "network 1 (then-branch)")
     if tail2 != ["Sigmoid"]:
         fl.refuse(f"gate (If): the then-branch ends in {tail2}")

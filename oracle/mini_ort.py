@@ -394,17 +394,32 @@ def _run_node(n, x: List, opset: int):
         return np.full([int(d) for d in x[0]], v.reshape(-1)[0] if v is not None else np.float32(0))
     if op == "Expand":
         return x[0] * np.ones([int(d) for d in x[1]], dtype=x[0].dtype)
+    if op in ("Greater", "Less", "GreaterOrEqual", "LessOrEqual", "Equal"):
+        f = {"Greater": np.greater, "Less": np.less, "GreaterOrEqual": np.greater_equal, "LessOrEqual": np.less_equal, "Equal": np.equal}[op]
+        return f(x[0], x[1])
+    if op == "Where":
+        return np.where(x[0], x[1], x[2])
+    if op == "Not":
+        return np.logical_not(x[0])
+    if op == "And":
+        return np.logical_and(x[0], x[1])
     raise NotImplementedError(f"mini_ort: operator {op}")
 
 
-def evaluate(graph, feeds: Dict[str, np.ndarray]) -> List[np.ndarray]:
-    env = dict(graph["init"])
+def evaluate(graph, feeds: Dict[str, np.ndarray], outer: Dict[str, np.ndarray] = None, opset: int = None) -> List[np.ndarray]:
+    env = dict(outer or {})          # (a subgraph sees the tensors of the enclosing scopes)
+    env.update(graph["init"])
     env.update(feeds)
+    opset = graph.get("opset", opset) if opset is None else opset
     for n in graph["nodes"]:
         if n["domain"] not in ("", "ai.onnx"):
             raise NotImplementedError(f"mini_ort: operator domain {n['domain']}")
         xs = [env[i] if i else None for i in n["inputs"]]
-        y = _run_node(n, xs, graph["opset"])
+        if n["op"] == "If":
+            cond = bool(np.asarray(xs[0]).reshape(-1)[0])
+            y = tuple(evaluate(n["attrs"]["then_branch" if cond else "else_branch"], {}, env, opset))
+        else:
+            y = _run_node(n, xs, opset)
         ys = y if isinstance(y, tuple) else (y,)
         for name, v in zip(n["outputs"], ys):
             env[name] = np.asarray(v)

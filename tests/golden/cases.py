@@ -36,8 +36,8 @@ VAD_CASES = [
 
 # The reference on real model FILES (tests/golden/make_golden_onnx.py): heads written by PyTorch's exporter under these names and
 # opsets (13 and older: decomposed LayerNorm; 17: the fused operator), loaded BY PATH; multiclass = the catalogue's timer shape.
-ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom"]
-ONNX_HEAD_OPSETS = {"alexa_custom": 13, "mycroft_custom": 17, "timer_custom": 12}
+ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom", "jarvis_custom", "jarvis_custom_if"]
+ONNX_HEAD_OPSETS = {"alexa_custom": 13, "mycroft_custom": 17, "timer_custom": 12, "jarvis_custom": 13, "jarvis_custom_if": 13}
 ONNX_FILE_CASES = [
     ("f1280", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=1280)),
     ("f1280j", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=1280)),
@@ -46,11 +46,15 @@ ONNX_FILE_CASES = [
     ("ftimer", ["timer_custom"], "hey_mycroft_test", dict(chunk_size=1280)),
     ("fpat", ["alexa_custom", "mycroft_custom"], "hey_jane",
      dict(chunk_size=1280, patience={"alexa_custom": 2}, threshold={"alexa_custom": 0.4})),
+    # hey_jarvis-style verifier routing (docs/models/hey_jarvis.md:38) as torch.where and as a scripted branch (an ONNX If)
+    ("fjarvis", ["jarvis_custom", "alexa_custom"], "hey_jane", dict(chunk_size=1280)),
+    ("fjarvisif", ["jarvis_custom_if"], "hey_jane", dict(chunk_size=1280)),
 ]
 
 
 def onnx_file_weights():
     """{"embedding", "heads"}: the synthetic weights behind the exported files (seed SEED_WEIGHTS)."""
     from openwakeword_amd import weights as W
-    base = {"alexa_custom": "alexa", "mycroft_custom": "hey_mycroft", "timer_custom": "timer"}
+    base = {"alexa_custom": "alexa", "mycroft_custom": "hey_mycroft", "timer_custom": "timer", "jarvis_custom": "hey_jarvis",
+            "jarvis_custom_if": "hey_jarvis"}
     return {"embedding": W.synthetic_embedding(SEED_WEIGHTS), "heads": {n: W.synthetic_head(b, SEED_WEIGHTS) for n, b in base.items()}}

@@ -64,6 +64,26 @@ def test_melspectrogram_graph_evaluates_like_its_torch_module(tmp_path):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-3)       # dB of int16-scale audio in fp32
 
 
+@pytest.mark.parametrize("form", ["where", "if"])
+def test_gated_graphs_evaluate_like_their_torch_modules(tmp_path, form):
+    """Greater + Where, and an If whose then-branch is a whole network reading the OUTER graph's input."""
+    head = W.synthetic_head("hey_jarvis", 33)
+    mod = TE.torch_gated(head, form)
+    path = os.path.join(tmp_path, "g.onnx")
+    _export_or_skip(lambda: TE.torch_export_head(mod, head["T"], path, 13))
+    sess = mini_ort.InferenceSession(path)
+    rng = np.random.default_rng(4)
+    arms = set()
+    for _ in range(30):
+        x = rng.normal(0, 2, (1, head["T"], 96)).astype(np.float32)
+        got = sess.run(None, {sess.get_inputs()[0].name: x})[0]
+        with torch.no_grad():
+            want = mod(torch.from_numpy(x)).numpy()
+            arms.add(bool(TE.torch_head(head["net"], head["T"], 1)(torch.from_numpy(x))[0, 0] > 0.5))
+        np.testing.assert_allclose(got.reshape(want.shape), want, rtol=0, atol=2e-6)
+    assert arms == {True, False}
+
+
 def test_unknown_operators_and_wrong_feeds_are_errors(tmp_path):
     head = W.synthetic_head("alexa", 31)
     path = os.path.join(tmp_path, "h.onnx")

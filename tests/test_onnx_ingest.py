@@ -671,7 +671,7 @@ def test_melspectrogram_file_is_verified_against_the_analytic_front_end(tmp_path
     np.testing.assert_allclose(O.mel_stage(x[None].astype(np.float32), np.float64)[0, 0], db, rtol=0, atol=1e-6)
 
 
-from torch_export import torch_export_head as _torch_export, torch_head as _torch_head, torch_embedding as _torch_embedding, torch_melspectrogram as _torch_melspectrogram, export as _export  # noqa: E402
+from torch_export import torch_export_head as _torch_export, torch_head as _torch_head, torch_embedding as _torch_embedding, torch_melspectrogram as _torch_melspectrogram, export as _export, torch_gated as _torch_gated  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -769,3 +769,32 @@ def test_melspectrogram_written_by_pytorchs_own_exporter_is_verified(tmp_path):
         export(_torch_melspectrogram(**kw), path)
         with pytest.raises(ValueError, match=why):
             onnx_ingest.verify_melspectrogram(path)
+
+
+@pytest.mark.parametrize("form,opset", [("where", 13), ("where", 17), ("if", 13)])
+def test_gated_head_written_by_pytorchs_own_exporter(tmp_path, form, opset):
+    """hey_jarvis-style routing as the real exporter renders it (Greater + Where; a scripted branch as an If with one subgraph per
+    arm): kind 'gated', both networks bit for bit, and the oracle on the loaded head == the torch module on either side of 0.5."""
+    torch = pytest.importorskip("torch")
+    head = W.synthetic_head("hey_jarvis", 93)
+    assert head["kind"] == "gated"
+    module = _torch_gated(head, form)
+    path = os.path.join(tmp_path, f"gated_{form}.onnx")
+    try:
+        _torch_export(module, head["T"], path, opset)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    got = onnx_ingest.load_head(path)
+    assert got["kind"] == "gated" and (got["T"], got["hidden"], got["n_out"]) == (head["T"], head["hidden"], 1)
+    for net in ("net", "net2"):
+        for k, v in head[net].items():
+            for x, y in ((v, got[net][k]),) if not isinstance(v, tuple) else zip(v, got[net][k]):
+                np.testing.assert_array_equal(x, y, err_msg=f"{net}.{k}")
+    rng = np.random.default_rng(3)
+    feats = rng.normal(0, 2, (40, head["T"], 96)).astype(np.float32)
+    want = O.head_stage(feats, got, np.float32).reshape(-1)
+    with torch.no_grad():
+        ref = np.array([float(module(torch.from_numpy(f[None]))[0, 0]) for f in feats])
+    first = O.head_stage(feats, {"kind": "binary", "T": head["T"], "hidden": head["hidden"], "n_out": 1, "net": head["net"]}, np.float32).reshape(-1)
+    assert (first > 0.5).any() and (first <= 0.5).any()     # both arms exercised
+    np.testing.assert_allclose(want, ref, rtol=0, atol=2e-6)

@@ -168,17 +168,49 @@ def torch_melspectrogram(top_db=80.0, hop=160):
     return Mel().eval()
 
 
+def torch_gated(head, form="where"):
+    """docs/models/hey_jarvis.md:38: a first network for every frame, a second (verifier) network whose score replaces the first's
+    where the first exceeds 0.5, 'combined together prior to exporting' -- as torch.where, or as a scripted `if` (an ONNX If)."""
+    import torch
+    import torch.nn as nn
+    first, second = torch_head(head["net"], head["T"], 1), torch_head(head["net2"], head["T"], 1)
+    if form == "where":
+        class Gated(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.first, self.second = first, second
+
+            def forward(self, x):
+                a = self.first(x)
+                return torch.where(a > 0.5, self.second(x), a)
+        return Gated().eval()
+
+    class GatedIf(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.first, self.second = first, second
+
+        def forward(self, x):
+            a = self.first(x)
+            if bool(a[0, 0] > 0.5):
+                a = self.second(x)
+            return a
+    return torch.jit.script(GatedIf().eval())
+
+
 def export_reference_files(directory, weights, head_opsets=None, embedding_opset=13, mel_opset=12):
-    """Write melspectrogram.onnx, embedding_model.onnx and one <name>.onnx per head of `weights` = {"embedding", "heads"} (binary and
-    multiclass heads; file name = the head's key) into `directory`; returns {name: path}."""
+    """Write melspectrogram.onnx, embedding_model.onnx and one <name>.onnx per head of `weights` = {"embedding", "heads"} (binary,
+    multiclass and gated heads; file name = the head's key) into `directory`; returns {name: path}."""
     import torch
     head_opsets = head_opsets or {}
     paths = {}
     for name, head in weights["heads"].items():
-        if head["kind"] not in ("binary", "multiclass"):
-            raise ValueError(f"{name}: only binary and multiclass heads have a torch module here")
         paths[name] = os.path.join(directory, f"{name}.onnx")
-        torch_export_head(torch_head(head["net"], head["T"], head["n_out"]), head["T"], paths[name], head_opsets.get(name, 13))
+        if head["kind"] == "gated":                         # hey_jarvis-style routing: "<name>_if" = the scripted branch (an ONNX If)
+            module = torch_gated(head, "if" if name.endswith("_if") else "where")
+        else:
+            module = torch_head(head["net"], head["T"], head["n_out"])
+        torch_export_head(module, head["T"], paths[name], head_opsets.get(name, 13))
     paths["embedding_model"] = os.path.join(directory, "embedding_model.onnx")
     export(torch_embedding(weights["embedding"]), torch.rand(1, 76, 32, 1), paths["embedding_model"], embedding_opset,
            input_names=["input_1"], dynamic_axes={"input_1": {0: "batch"}})
