@@ -34,7 +34,6 @@ import collections
 import json
 import queue
 import threading
-from fractions import Fraction
 from typing import Dict, List, Optional
 
 import numpy as np

@@ -10,7 +10,7 @@ rank 0 (`ScoreGather`), over RCCL/xGMI on GPUs (torch.distributed backend "nccl"
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist

@@ -17,7 +17,7 @@ All arrays are host numpy; `openwakeword_amd.engine` packs and uploads them.
 from __future__ import annotations
 
 import zlib
-from typing import Dict, List, Optional
+from typing import Optional
 
 import numpy as np
 

@@ -8,7 +8,6 @@ time, utils.py:625-673), so here the module skips cleanly; nothing else about th
 
 Where it looks: $OWW_REFERENCE_DIR (default /root/reference) for the package and its `openwakeword/resources/models/*.onnx`,
 or $OWW_MODELS_DIR for the model files alone."""
-import glob
 import os
 import sys
 
