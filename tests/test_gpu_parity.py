@@ -470,3 +470,39 @@ def test_fuzz_kernel_families_agree(emb, seed):
     finally:
         for e in engs:
             e.close()
+
+
+def test_device_pcm_pointer_of_any_alignment():
+    """A device PCM pointer that is only 2-byte aligned (a slice of a larger int16 tensor) cannot feed the fused front end's 16-byte
+    sample loads: such a step takes the separate mel launch (scalar loads) and must give the scores of an aligned copy to fp32
+    round-off -- also with the voice-activity front end, which reads the same buffer."""
+    import torch
+    from openwakeword_amd.engine import StreamEngine
+    dev = torch.device("cuda", 0)
+    S, T = 300, 6
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    pcm = (torch.randn(T, S * 1280 + 8, device=dev, generator=g) * 3000).round().clamp(-32768, 32767).to(torch.int16)
+    heads = {"alexa": W.synthetic_head("alexa", 1)}
+    for vad in (None, W.synthetic_vad(2)):
+        kw = dict(vad=vad, vad_threshold=0.5) if vad is not None else {}
+        for off in (1, 3, 4):
+            out = []
+            for aligned in (True, False):
+                eng = StreamEngine(S, heads, W.synthetic_embedding(1), **kw)
+                sc = torch.empty(S, 1, device=dev)
+                rows = []
+                try:
+                    for t in range(T):
+                        x = pcm[t, off:off + S * 1280]
+                        x = x.clone() if aligned else x
+                        assert (x.data_ptr() % 16 == 0) == aligned
+                        torch.cuda.synchronize()
+                        eng.step_device(x.data_ptr(), 1, sc.data_ptr())
+                        eng.sync()
+                        rows.append(sc.cpu().numpy().copy())
+                finally:
+                    eng.close()
+                out.append(np.stack(rows))
+            assert np.isfinite(out[1]).all()
+            np.testing.assert_allclose(out[1], out[0], rtol=0, atol=1e-5, err_msg=f"offset {off}, vad {vad is not None}")
