@@ -1,0 +1,164 @@
+"""The host shim of the drop-in surface (openwakeword_amd/model.py: Model, AudioFeatures) in the CPU tier: its engine calls are
+served by tests/stub_engine.OracleEngine (the CPU oracle behind the engine interface), everything above them -- buffering in 1280-
+sample units with carry-over, calls shorter / longer than a chunk, the first-five rule, patience and debounce, class mapping, parent
+lookup, reset, argument errors -- is the product's own code, held to the vectors the REFERENCE's code produced
+(tests/golden/make_golden.py).  The same cases run on the HIP engine in tests/test_model_api.py (GPU tier)."""
+import numpy as np
+import pytest
+
+import cases
+from openwakeword_amd import model as M, weights as W
+from stub_engine import OracleEngine
+
+
+@pytest.fixture()
+def stub(monkeypatch):
+    made = []
+
+    def make_engine(n_streams, heads, embedding, use_mfma=None, **kw):
+        made.append(OracleEngine(n_streams, heads, embedding, **kw))
+        return made[-1]
+
+    monkeypatch.setattr(M, "make_engine", make_engine)
+    return made
+
+
+def _weights(names):
+    return {"embedding": W.synthetic_embedding(cases.SEED_WEIGHTS), "heads": {n: W.synthetic_head(n, cases.SEED_WEIGHTS) for n in names}}
+
+
+@pytest.mark.parametrize("case", cases.CLIP_CASES, ids=[c[0] for c in cases.CLIP_CASES])
+def test_host_shim_on_the_oracle_engine_matches_reference_golden(stub, golden, case):
+    cid, head_names, clip, kw = case
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights=_weights(head_names))
+    assert isinstance(m._engine, OracleEngine)
+    if cid == "c1280":
+        np.testing.assert_allclose(m.preprocessor.get_features(41)[0], golden["init/feature_buffer"], rtol=0, atol=2e-5)
+    preds = m.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(golden[cid + "/labels"])
+    assert sorted(preds[0].keys()) == labels
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    want = golden[cid + "/scores"]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    feats = golden[cid + "/features"]
+    n = min(len(feats), 120)
+    np.testing.assert_allclose(m.preprocessor.get_features(n)[0], feats[-n:], rtol=0, atol=2e-5)
+    if cid == "c1280":
+        np.random.seed(cases.SEED_NP + 1)
+        m.reset()
+        preds2 = m.predict_clip(golden["pcm/hey_mycroft_test"], chunk_size=1280)
+        got2 = np.array([[float(p[k]) for k in labels] for p in preds2])
+        np.testing.assert_allclose(got2, golden["reset/scores"], rtol=0, atol=2e-6)
+    m.close()
+    assert stub[-1].closed
+
+
+def test_predict_argument_errors_and_short_calls(stub, golden):
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=["alexa"], weights=_weights(["alexa"]))
+    with pytest.raises(ValueError):                               # model.py:262-263
+        m.predict([0] * 1280)
+    with pytest.raises(ValueError):                               # utils.py:195-197
+        m.predict(np.zeros(1280, np.float32))
+    with pytest.raises(ValueError):                               # model.py:341-343
+        m.predict(np.zeros(1280, np.int16), patience={"alexa": 3})
+    with pytest.raises(ValueError):                               # model.py:344-345
+        m.predict(np.zeros(1280, np.int16), patience={"alexa": 3}, threshold={"alexa": 0.5}, debounce_time=1.0)
+    # calls shorter than a chunk repeat the previous score and lose no sample (model.py:299-307, utils.py:413-430); ragged call
+    # sizes around the chunk size; the first-five rule counts CALLS (model.py:331-333) -- call for call against the oracle's
+    # restatement of the reference (itself golden-pinned for chunk sizes 400 ... 5120)
+    from oracle import oww_oracle as O
+    clip = golden["pcm/hey_jane"]
+    w = _weights(["alexa"])
+    for sizes in ([640] * 24, [400, 1280, 3000, 17, 1263, 2560, 5000, 1], [1279, 1, 1281, 2559]):
+        np.random.seed(cases.SEED_NP)
+        hip_side = M.Model(wakeword_models=["alexa"], weights=w)
+        np.random.seed(cases.SEED_NP)
+        ref = O.OracleModel(w["heads"], w["embedding"])
+        o = 0
+        for n in sizes:
+            got, want = hip_side.predict(clip[o:o + n]), ref.predict(clip[o:o + n])
+            assert set(got) == set(want) == {"alexa"}
+            assert abs(got["alexa"] - want["alexa"]) < 2e-6, (sizes, o, n)
+            o += n
+    assert m.get_parent_model_from_label("alexa") == "alexa"
+    _, clock = m.predict(np.zeros(1280, np.int16), timing=True)
+    assert set(clock["models"]) == {"preprocessor", "alexa"}
+
+
+def test_call_longer_than_max_chunks_is_fed_in_slices(stub, golden):
+    """An 11-chunk call through an engine that takes at most 4 chunks per step: three engine steps, raw scores max-combined like the
+    reference's multi-chunk rule (model.py:287-298); the stream carries on afterwards."""
+    m = M.Model(wakeword_models=["alexa"], weights=_weights(["alexa"]), max_chunks=4)
+    clip = np.resize(golden["pcm/alexa_test"], 1280 * 11)
+    for t in range(6):
+        m.predict(clip[:1280])
+    calls = []
+    real = stub[-1].step_raw
+    stub[-1].step_raw = lambda pcm: (calls.append(pcm.shape[1] // 1280), real(pcm))[1]
+    out = m.predict(clip)
+    assert calls == [4, 4, 3]
+    assert set(out) == {"alexa"} and 0.0 <= out["alexa"] <= 1.0 and m.preprocessor.accumulated_samples == 0
+    again = m.predict(clip[:1280])
+    assert 0.0 <= again["alexa"] <= 1.0 and len(m.prediction_buffer["alexa"]) == 8 and calls[-1] == 1
+
+
+@pytest.mark.parametrize("case", cases.VAD_CASES, ids=[c[0] for c in cases.VAD_CASES])
+def test_vad_gate_of_the_host_shim_matches_reference_golden(stub, golden, case):
+    """model.py:366-381 + vad.py as the host shim carries them (openwakeword_amd/vad.py, Model.predict): gated scores, the VAD ring,
+    the ungated score ring, reset() leaving the VAD alone -- against the reference's own Model (tests/golden/make_golden_vad.py)."""
+    import os
+    from oracle.pseudo_vad import PseudoVadSession
+    gv = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vad.npz")))
+    cid, head_names, clip, kw, thr = case
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights=_weights(head_names), vad_threshold=thr, vad_session=PseudoVadSession())
+    preds = m.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(gv[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    np.testing.assert_allclose(got, gv[f"{cid}/scores"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.array(m.vad.prediction_buffer), gv[f"{cid}/vad"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.array([list(m.prediction_buffer[k]) for k in labels]), gv[f"{cid}/ring"], rtol=0, atol=2e-6)
+    if cid == "vad03":
+        np.random.seed(cases.SEED_NP + 1)
+        m.reset()
+        preds = m.predict_clip(golden["pcm/hey_mycroft_test"], chunk_size=1280)
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, gv["vadreset/scores"], rtol=0, atol=2e-6)
+
+
+def test_custom_verifier_and_label_mapping_on_the_host(stub, golden, tmp_path):
+    """model.py:320-328 (verifier re-scores frames the base model likes), 177-182 (class mapping), 215-224 (parent lookup)."""
+    import pickle
+
+    class Verifier:
+        def predict_proba(self, feats):
+            assert feats.shape == (1, 16, 96)
+            return np.array([[0.75, 0.25]])
+
+    path = tmp_path / "v.pkl"
+    import test_host_logic_cpu as me          # (pickle needs an importable class)
+    me.Verifier = Verifier
+    Verifier.__module__, Verifier.__qualname__ = "test_host_logic_cpu", "Verifier"
+    pickle.dump(Verifier(), open(path, "wb"))
+    w = _weights(["alexa", "timer"])
+    np.random.seed(cases.SEED_NP)
+    plain = M.Model(wakeword_models=["alexa", "timer"], weights=w)
+    np.random.seed(cases.SEED_NP)
+    ver = M.Model(wakeword_models=["alexa", "timer"], weights=w, custom_verifier_models={"alexa": str(path)}, custom_verifier_threshold=0.3)
+    clip = golden["pcm/hey_jane"]
+    hit = False
+    for o in range(0, len(clip) - 1280, 1280):
+        a, b = plain.predict(clip[o:o + 1280]), ver.predict(clip[o:o + 1280])
+        assert set(a) == set(b) and {"alexa", "1_minute_timer", "1_hour_timer"} <= set(a)          # timers through the class mapping
+        if a["alexa"] >= 0.3:
+            assert b["alexa"] == 0.25
+            hit = True
+        else:
+            assert b["alexa"] == a["alexa"]
+    assert hit
+    assert ver.get_parent_model_from_label("1_hour_timer") == "timer" and ver.get_parent_model_from_label("alexa") == "alexa"
+    with pytest.raises(ValueError, match="not matched"):
+        M.Model(wakeword_models=["alexa"], weights=w, custom_verifier_models={"nope": str(path)})
