@@ -58,3 +58,7 @@ def onnx_file_weights():
     base = {"alexa_custom": "alexa", "mycroft_custom": "hey_mycroft", "timer_custom": "timer", "jarvis_custom": "hey_jarvis",
             "jarvis_custom_if": "hey_jarvis"}
     return {"embedding": W.synthetic_embedding(SEED_WEIGHTS), "heads": {n: W.synthetic_head(b, SEED_WEIGHTS) for n, b in base.items()}}
+
+# direct predict() calls of ragged sizes, empty calls included (model.py:232-386 on whatever the caller hands over)
+ONNX_SEQUENCE = ("fseq", ["alexa_custom", "timer_custom"], "hey_jane",
+                 [0, 1280, 0, 640, 0, 640, 400, 3000, 17, 1263, 2560, 5000, 1, 0, 1280, 1279, 1, 1281, 2559, 1280, 1280])

@@ -59,6 +59,18 @@ def main():
             if cid == "f1280":
                 out["init/model_inputs"] = np.array([mdl.model_inputs[n] for n in sorted(mdl.models)])
                 out["init/model_outputs"] = np.array([mdl.model_outputs[n] for n in sorted(mdl.models)])
+        cid, head_names, clip, sizes = cases.ONNX_SEQUENCE
+        np.random.seed(cases.SEED_NP)
+        mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",
+                                 melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+        rows, o = [], 0
+        for n in sizes:
+            p = mdl.predict(clips[clip][o:o + n])
+            o += n
+            labels = sorted(p.keys())
+            rows.append([float(p[k]) for k in labels])
+        out[f"{cid}/labels"] = np.array(labels)
+        out[f"{cid}/scores"] = np.array(rows, dtype=np.float64)
     path = os.path.join(os.path.dirname(__file__), "ref_onnx_files.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

@@ -162,3 +162,22 @@ def test_custom_verifier_and_label_mapping_on_the_host(stub, golden, tmp_path):
     assert ver.get_parent_model_from_label("1_hour_timer") == "timer" and ver.get_parent_model_from_label("alexa") == "alexa"
     with pytest.raises(ValueError, match="not matched"):
         M.Model(wakeword_models=["alexa"], weights=w, custom_verifier_models={"nope": str(path)})
+
+
+def test_host_shim_matches_the_reference_on_ragged_and_empty_calls(stub, golden):
+    """cases.ONNX_SEQUENCE (calls of 0 ... 5000 samples) against what the reference's own code returned on the exporter-written
+    files (tests/golden/make_golden_onnx.py); here the host shim runs on the source weights over the oracle engine."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, sizes = cases.ONNX_SEQUENCE
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights={"embedding": w["embedding"], "heads": {n: w["heads"][n] for n in head_names}})
+    labels = list(ref[f"{cid}/labels"])
+    rows, o = [], 0
+    for n in sizes:
+        p = m.predict(golden["pcm/" + clip][o:o + n])
+        o += n
+        assert sorted(p.keys()) == labels
+        rows.append([float(p[k]) for k in labels])
+    np.testing.assert_allclose(np.array(rows), ref[f"{cid}/scores"], rtol=0, atol=2e-5)

@@ -622,3 +622,32 @@ def test_hip_model_on_exported_files_matches_the_reference_on_the_same_files(tmp
         np.testing.assert_allclose(m.preprocessor.get_features(n)[0], feats[-n:], rtol=0, atol=2e-4)
     finally:
         m.close()
+
+
+@gpu
+def test_hip_model_on_exported_files_ragged_and_empty_calls(tmp_path, golden):
+    """cases.ONNX_SEQUENCE: direct predict() calls of 0 ... 5000 samples, files loaded by path, against the reference's own scores."""
+    pytest.importorskip("torch")
+    import os
+    import torch_export as TE
+    from openwakeword_amd import Model
+    cid, head_names, clip, sizes = cases.ONNX_SEQUENCE
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    try:
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=[paths[n] for n in head_names], melspec_model_path=paths["melspectrogram"],
+              embedding_model_path=paths["embedding_model"])
+    try:
+        labels = list(ref[f"{cid}/labels"])
+        rows, o = [], 0
+        for n in sizes:
+            p = m.predict(golden["pcm/" + clip][o:o + n])
+            o += n
+            assert sorted(p.keys()) == labels
+            rows.append([float(p[k]) for k in labels])
+        np.testing.assert_allclose(np.array(rows), ref[f"{cid}/scores"], rtol=0, atol=TOL_SCORE)
+    finally:
+        m.close()

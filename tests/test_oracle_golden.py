@@ -252,3 +252,20 @@ def test_oracle_matches_the_reference_run_on_exported_model_files(golden, golden
     np.testing.assert_allclose(mdl.preprocessor.features, golden_files[f"{cid}/features"], rtol=0, atol=1e-4)
     if cid == "f1280":                                      # what the reference read from the files' input / output declarations
         assert list(golden_files["init/model_inputs"]) == [16, 16] and list(golden_files["init/model_outputs"]) == [1, 1]
+
+
+def test_oracle_matches_the_reference_on_ragged_and_empty_calls(golden, golden_files):
+    """Direct predict() calls of 0, 1, 17 ... 5000 samples (cases.ONNX_SEQUENCE) through the reference on exported files: calls that
+    complete no chunk repeat the previous binary score and return zeros for a multiclass model (model.py:299-307)."""
+    cid, head_names, clip, sizes = cases.ONNX_SEQUENCE
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    mdl = O.OracleModel({n: w["heads"][n] for n in head_names}, w["embedding"])
+    labels = list(golden_files[f"{cid}/labels"])
+    rows, o = [], 0
+    for n in sizes:
+        p = mdl.predict(golden["pcm/" + clip][o:o + n])
+        o += n
+        assert sorted(p.keys()) == labels
+        rows.append([float(p[k]) for k in labels])
+    np.testing.assert_allclose(np.array(rows), golden_files[f"{cid}/scores"], rtol=0, atol=2e-5)
