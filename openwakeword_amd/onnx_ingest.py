@@ -973,7 +973,13 @@ def _load_vad(path: str) -> dict:
         if n["op"] in ("Gemm", "MatMul", "Conv") and len(n["inputs"]) >= 2 and n["inputs"][1] in inits and inits[n["inputs"][1]].size == H \
                 and n not in enc:
             wd = np.asarray(inits[n["inputs"][1]], np.float32).reshape(H)
-            bd = float(np.asarray(inits[n["inputs"][2]]).reshape(-1)[0]) if len(n["inputs"]) > 2 and n["inputs"][2] in inits else 0.0
+            bd = float(np.asarray(inits[n["inputs"][2]]).reshape(-1)[0]) if len(n["inputs"]) > 2 and n["inputs"][2] in inits else None
+            if bd is None:                                    # nn.Linear as the exporter writes it for a 3-D input: MatMul, then Add(bias)
+                adds = [m for m in nodes if m["op"] == "Add" and n["outputs"][0] in m["inputs"]]
+                consts = [inits[i] for m in adds for i in m["inputs"] if i in inits and inits[i].size == 1]
+                if len(adds) > 1 or len(consts) != len(adds):
+                    refuse(f"the decoder's output feeds {[m['op'] for m in adds]} with non-scalar operands")
+                bd = float(np.asarray(consts[0]).reshape(-1)[0]) if consts else 0.0
             dec = (wd, np.float32(bd))
     if dec is None or "Sigmoid" not in ops:
         refuse("no 64 -> 1 decoder followed by a Sigmoid")

@@ -252,6 +252,32 @@ def _maxpool(x, a):
     return win.max(axis=tuple(range(-nd, 0)))
 
 
+def _lstm(x, a):
+    """ONNX LSTM, forward direction, default activations: X [T, B, in] (layout 0), W [1, 4H, in], R [1, 4H, H], B [1, 8H], gate order
+    i o f c, optional sequence_lens (unsupported), initial_h / initial_c [1, B, H] -> Y [T, 1, B, H], Y_h, Y_c [1, B, H]."""
+    if a.get("direction", "forward") != "forward" or a.get("layout", 0) != 0 or a.get("input_forget", 0):
+        raise NotImplementedError("mini_ort: LSTM direction / layout / input_forget")
+    X, Wm, R = x[0], x[1][0], x[2][0]
+    H = int(a["hidden_size"])
+    Bv = x[3][0] if len(x) > 3 and x[3] is not None else np.zeros(8 * H, X.dtype)
+    if len(x) > 4 and x[4] is not None:
+        raise NotImplementedError("mini_ort: LSTM sequence_lens")
+    h = x[5][0] if len(x) > 5 and x[5] is not None else np.zeros((X.shape[1], H), X.dtype)
+    c = x[6][0] if len(x) > 6 and x[6] is not None else np.zeros((X.shape[1], H), X.dtype)
+    if len(x) > 7 and x[7] is not None:
+        raise NotImplementedError("mini_ort: LSTM peepholes")
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    ys = []
+    for t in range(X.shape[0]):
+        z = X[t] @ Wm.T + h @ R.T + Bv[:4 * H] + Bv[4 * H:]
+        i, o, f, g = (z[:, k * H:(k + 1) * H] for k in range(4))
+        c = sig(f) * c + sig(i) * np.tanh(g)
+        h = sig(o) * np.tanh(c)
+        ys.append(h)
+    Y = np.stack(ys)[:, None].astype(X.dtype)
+    return Y, h[None].astype(X.dtype), c[None].astype(X.dtype)
+
+
 def _axes(node, inputs, opset_from_input: int, opset: int):
     if opset >= opset_from_input and len(inputs) > 1 and inputs[1] is not None:
         return [int(v) for v in np.asarray(inputs[1]).reshape(-1)]
@@ -394,6 +420,8 @@ def _run_node(n, x: List, opset: int):
         return np.full([int(d) for d in x[0]], v.reshape(-1)[0] if v is not None else np.float32(0))
     if op == "Expand":
         return x[0] * np.ones([int(d) for d in x[1]], dtype=x[0].dtype)
+    if op == "LSTM":
+        return _lstm(x, a)
     if op in ("Greater", "Less", "GreaterOrEqual", "LessOrEqual", "Equal"):
         f = {"Greater": np.greater, "Less": np.less, "GreaterOrEqual": np.greater_equal, "LessOrEqual": np.less_equal, "Equal": np.equal}[op]
         return f(x[0], x[1])
@@ -437,8 +465,13 @@ class _IO:
         self.name, self.shape = name, shape
 
 
+REDIRECT: Dict[str, str] = {}       # basename -> actual file, for models the reference resolves inside its own (read-only) package
+
+
 class InferenceSession:
     def __init__(self, path, sess_options=None, providers=None):
+        import os
+        path = REDIRECT.get(os.path.basename(path), path)
         self._g = load(path)
         self._providers = list(providers or ["CPUExecutionProvider"])
         init = self._g["init"]

@@ -62,3 +62,12 @@ def onnx_file_weights():
 # direct predict() calls of ragged sizes, empty calls included (model.py:232-386 on whatever the caller hands over)
 ONNX_SEQUENCE = ("fseq", ["alexa_custom", "timer_custom"], "hey_jane",
                  [0, 1280, 0, 640, 0, 640, 400, 3000, 17, 1263, 2560, 5000, 1, 0, 1280, 1279, 1, 1281, 2559, 1280, 1280])
+
+# the reference's VAD class (vad.py:54-130) on a voice-activity FILE: the stand-in network written by PyTorch's exporter (two ONNX
+# LSTM nodes, state carried through the h / c inputs); (case id, heads, clip, predict_clip kwargs, vad_threshold)
+ONNX_VAD_SEED = 77
+ONNX_VAD_CASES = [
+    ("fvad20", ["alexa_custom"], "hey_jane", dict(chunk_size=1280), 0.2),          # (this network's scores span 0.07 ... 0.36)
+    ("fvad30", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=2560), 0.3),
+    ("fvad12", ["mycroft_custom"], "hey_mycroft_test", dict(chunk_size=1280, padding=0), 0.12),
+]

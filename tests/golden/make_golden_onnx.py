@@ -59,6 +59,22 @@ def main():
             if cid == "f1280":
                 out["init/model_inputs"] = np.array([mdl.model_inputs[n] for n in sorted(mdl.models)])
                 out["init/model_outputs"] = np.array([mdl.model_outputs[n] for n in sorted(mdl.models)])
+        # Model(vad_threshold > 0): the reference opens resources/models/silero_vad.onnx inside its own package (vad.py:60-67);
+        # the evaluator is pointed at the exporter-written stand-in instead (the real file's graph is not available)
+        from openwakeword_amd import weights as W
+        vad_path = os.path.join(d, "silero_vad.onnx")
+        TE.export_vad(W.synthetic_vad(cases.ONNX_VAD_SEED), vad_path)
+        mini_ort.REDIRECT["silero_vad.onnx"] = vad_path
+        for cid, head_names, clip, kw, thr in cases.ONNX_VAD_CASES:
+            np.random.seed(cases.SEED_NP)
+            mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx", vad_threshold=thr,
+                                     melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+            preds = mdl.predict_clip(clips[clip], **kw)
+            labels = sorted(preds[0].keys())
+            out[f"{cid}/labels"] = np.array(labels)
+            out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
+            out[f"{cid}/vad"] = np.array(list(mdl.vad.prediction_buffer), dtype=np.float64)
+            out[f"{cid}/ring"] = np.array([list(mdl.prediction_buffer[k]) for k in labels], dtype=np.float64)
         cid, head_names, clip, sizes = cases.ONNX_SEQUENCE
         np.random.seed(cases.SEED_NP)
         mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",
@@ -74,7 +90,7 @@ def main():
     path = os.path.join(os.path.dirname(__file__), "ref_onnx_files.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
-    for cid, *_ in cases.ONNX_FILE_CASES:
+    for cid, *_ in cases.ONNX_FILE_CASES + cases.ONNX_VAD_CASES:
         s = out[f"{cid}/scores"]
         print(f"  {cid:10s} frames={s.shape[0]:3d} labels={list(out[cid + '/labels'])} max={s.max(axis=0).round(4)}")
 

@@ -181,3 +181,30 @@ def test_host_shim_matches_the_reference_on_ragged_and_empty_calls(stub, golden)
         assert sorted(p.keys()) == labels
         rows.append([float(p[k]) for k in labels])
     np.testing.assert_allclose(np.array(rows), ref[f"{cid}/scores"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", cases.ONNX_VAD_CASES, ids=[c[0] for c in cases.ONNX_VAD_CASES])
+def test_host_vad_wrapper_on_an_exported_file_session(stub, golden, tmp_path, case):
+    """The host VAD wrapper (openwakeword_amd/vad.py) driving a session that evaluates the exporter-written voice-activity FILE
+    (oracle/mini_ort.py), against the reference's own VAD class on the same file (tests/golden/make_golden_onnx.py)."""
+    pytest.importorskip("torch")
+    import os
+    import torch_export as TE
+    from oracle import mini_ort
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, kw, thr = case
+    path = str(tmp_path / "silero_vad.onnx")
+    try:
+        TE.export_vad(W.synthetic_vad(cases.ONNX_VAD_SEED), path)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights={"embedding": w["embedding"], "heads": {n: w["heads"][n] for n in head_names}},
+                vad_threshold=thr, vad_session=mini_ort.InferenceSession(path))
+    preds = m.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(ref[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    np.testing.assert_allclose(np.array(m.vad.prediction_buffer), ref[f"{cid}/vad"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got, ref[f"{cid}/scores"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.array([list(m.prediction_buffer[k]) for k in labels]), ref[f"{cid}/ring"], rtol=0, atol=2e-5)

@@ -95,3 +95,30 @@ def test_unknown_operators_and_wrong_feeds_are_errors(tmp_path):
     g["nodes"][0]["op"] = "Einsum"
     with pytest.raises(NotImplementedError, match="Einsum"):
         mini_ort.evaluate(g, {sess.get_inputs()[0].name: np.zeros((1, 16, 96), np.float32)})
+
+
+def test_vad_standin_graph_evaluates_like_its_torch_module_and_the_oracle(tmp_path):
+    """Two Conv1d STFT branches, Sqrt / Log, four strided Conv1d, two ONNX LSTM nodes with carried state, Gemm / MatMul decoder, mean
+    over time -- the file the reference's VAD class (vad.py:60-130) is pointed at in tests/golden/make_golden_onnx.py."""
+    from oracle import vad_standin as VS
+    vad = W.synthetic_vad(34)
+    mod = TE.torch_vad(vad)
+    path = os.path.join(tmp_path, "silero_vad.onnx")
+    _export_or_skip(lambda: TE.export_vad(vad, path))
+    sess = mini_ort.InferenceSession(path)
+    assert [i.name for i in sess.get_inputs()] == ["input", "sr", "h", "c"]
+    rng = np.random.default_rng(5)
+    h = np.zeros((2, 1, 64), np.float32)
+    c = np.zeros((2, 1, 64), np.float32)
+    ho, co = h.copy(), c.copy()
+    for step in range(6):                                   # the state is carried from call to call (vad.py:121-124)
+        x = (rng.normal(0, 0.05 * (1 + step), (1, 640))).astype(np.float32)
+        out, h, c = sess.run(None, {"input": x, "sr": np.array(16000).astype("int64"), "h": h, "c": c})
+        with torch.no_grad():
+            want, hn, cn = mod(torch.from_numpy(x), torch.tensor(16000), torch.from_numpy(ho), torch.from_numpy(co))
+        y, ho, co = VS.forward(vad, x, ho, co)
+        np.testing.assert_allclose(out, want.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out[:, 0], y, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(h, hn.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(h, ho, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(c, co, rtol=0, atol=2e-5)

@@ -651,3 +651,64 @@ def test_hip_model_on_exported_files_ragged_and_empty_calls(tmp_path, golden):
         np.testing.assert_allclose(np.array(rows), ref[f"{cid}/scores"], rtol=0, atol=TOL_SCORE)
     finally:
         m.close()
+
+
+@gpu
+@pytest.mark.parametrize("case", cases.ONNX_VAD_CASES, ids=[c[0] for c in cases.ONNX_VAD_CASES])
+def test_vad_file_host_session_and_device_network_match_the_reference_vad_class(tmp_path, golden, case):
+    """Row I on a voice-activity FILE (the stand-in network written by PyTorch's exporter; tests/golden/make_golden_onnx.py ran the
+    reference's own VAD class on it): (a) the HIP Model with a host session evaluating the file, (b) for 1280-sample chunks the
+    network ON THE DEVICE -- `onnx_ingest.load_vad(file)` -> oww_load_vad -> vad_front / vad_lstm kernels + the gate inside the step
+    (configs[4]) -- both against the reference's gated scores; decisions whose VAD window maximum lies within 1e-3 of the threshold
+    are not compared for (b)."""
+    pytest.importorskip("torch")
+    import os
+    import torch_export as TE
+    from oracle import mini_ort
+    from openwakeword_amd import Model, BatchedModel, onnx_ingest
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, kw, thr = case
+    path = str(tmp_path / "silero_vad.onnx")
+    try:
+        TE.export_vad(W.synthetic_vad(cases.ONNX_VAD_SEED), path)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    src = cases.onnx_file_weights()
+    w = {"embedding": src["embedding"], "heads": {n: src["heads"][n] for n in head_names}}
+    labels = list(ref[f"{cid}/labels"])
+    want, vad_ring = ref[f"{cid}/scores"], ref[f"{cid}/vad"]
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=list(head_names), weights=w, vad_threshold=thr, vad_session=mini_ort.InferenceSession(path))
+    try:
+        seed_features = m.preprocessor.get_features(120)[0].copy()
+        preds = m.predict_clip(golden["pcm/" + clip], **kw)
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(np.array(m.vad.prediction_buffer), vad_ring, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(got, want, rtol=0, atol=TOL_SCORE)
+    finally:
+        m.close()
+    if kw.get("chunk_size") != 1280:
+        return
+    bm = BatchedModel(3, list(head_names), weights=w, vad_weights=onnx_ingest.load_vad(path), vad_threshold=thr)
+    try:
+        assert bm.labels == labels
+        for s in range(3):
+            bm.reset([s], seed_features[-bm.engine.feature_ring:])
+        data = golden["pcm/" + clip]
+        pad = kw.get("padding", 1)
+        if pad:
+            data = np.concatenate((np.zeros(16000 * pad, np.int16), data, np.zeros(16000 * pad, np.int16)))
+        compared = skipped = 0
+        for t, o in enumerate(range(0, len(data) - 1280, 1280)):
+            x = np.ascontiguousarray(np.tile(data[o:o + 1280], (3, 1)))
+            got = bm.predict_batch(x)
+            np.testing.assert_allclose(bm.engine.get_vad()[0], vad_ring[t], rtol=0, atol=2e-5)       # the device network == the file
+            window = vad_ring[max(0, t + 1 - 7): max(0, t + 1 - 4)]                                  # vad.py / model.py:366-381: ring[-7:-4]
+            if len(window) and abs(window.max() - thr) < 1e-3:
+                skipped += 1
+                continue
+            np.testing.assert_allclose(got[1], want[t], rtol=0, atol=TOL_SCORE, err_msg=f"frame {t}")
+            compared += 1
+        assert compared > 8 and (want > 0).any() and (want == 0).any()
+    finally:
+        bm.close()

@@ -798,3 +798,25 @@ def test_gated_head_written_by_pytorchs_own_exporter(tmp_path, form, opset):
     first = O.head_stage(feats, {"kind": "binary", "T": head["T"], "hidden": head["hidden"], "n_out": 1, "net": head["net"]}, np.float32).reshape(-1)
     assert (first > 0.5).any() and (first <= 0.5).any()     # both arms exercised
     np.testing.assert_allclose(want, ref, rtol=0, atol=2e-6)
+
+
+def test_vad_standin_written_by_pytorchs_own_exporter_loads_to_the_same_weights(tmp_path):
+    """nn.LSTM(num_layers=2) becomes two ONNX LSTM nodes (gate order i o f c, W / R / B split, initial states sliced from h, c), nn.Linear
+    on a 3-D input MatMul + Add, the |STFT| two strided Conv1d: `load_vad` must return the source weights (LSTM biases as b_ih + b_hh)."""
+    pytest.importorskip("torch")
+    import torch_export as TE
+    vad = W.synthetic_vad(35)
+    path = os.path.join(tmp_path, "silero_vad.onnx")
+    try:
+        TE.export_vad(vad, path)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    got = onnx_ingest.load_vad(path)
+    for (w, b), (w2, b2) in zip(vad["enc"], got["enc"]):
+        np.testing.assert_array_equal(w, w2)
+        np.testing.assert_array_equal(b, b2)
+    for (w, b), (w2, b2) in zip(vad["lstm"], got["lstm"]):
+        np.testing.assert_array_equal(w, w2)
+        np.testing.assert_array_equal(b, b2)
+    np.testing.assert_array_equal(vad["dec"][0], got["dec"][0])
+    assert float(got["dec"][1]) == float(vad["dec"][1])

@@ -269,3 +269,24 @@ def test_oracle_matches_the_reference_on_ragged_and_empty_calls(golden, golden_f
         assert sorted(p.keys()) == labels
         rows.append([float(p[k]) for k in labels])
     np.testing.assert_allclose(np.array(rows), golden_files[f"{cid}/scores"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", cases.ONNX_VAD_CASES, ids=[c[0] for c in cases.ONNX_VAD_CASES])
+def test_oracle_vad_matches_the_reference_vad_class_on_an_exported_file(golden, golden_files, case):
+    """tests/golden/make_golden_onnx.py: the reference's Model(vad_threshold=...) whose own VAD class (vad.py:54-130) opens a
+    voice-activity FILE -- the stand-in network written by PyTorch's exporter, evaluated by the generic ONNX interpreter.  The oracle
+    (stand-in restatement + OracleVad + gate) must return the same gated scores, VAD ring and ungated score ring."""
+    from oracle.vad_standin import StandinVadSession
+    cid, head_names, clip, kw, thr = case
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    mdl = O.OracleModel({n: w["heads"][n] for n in head_names}, w["embedding"], vad_threshold=thr,
+                        vad_session=StandinVadSession(W.synthetic_vad(cases.ONNX_VAD_SEED)))
+    preds = mdl.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(golden_files[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    want, vad = golden_files[f"{cid}/scores"], golden_files[f"{cid}/vad"]
+    np.testing.assert_allclose(np.array(mdl.vad.ring), vad, rtol=0, atol=2e-5)
+    assert got.shape == want.shape and (want == 0).any() and (want > 0).any()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.array([list(mdl.prediction_buffer[k]) for k in labels]), golden_files[f"{cid}/ring"], rtol=0, atol=2e-5)

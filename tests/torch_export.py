@@ -198,6 +198,61 @@ def torch_gated(head, form="where"):
     return torch.jit.script(GatedIf().eval())
 
 
+def torch_vad(vad):
+    """The voice-activity STAND-IN (oracle/vad_standin.py; the interface is Silero's, vad.py:92-130) as a torch module with the
+    inputs the reference feeds -- input [B, 640] (samples / 32767), sr (int64), h, c [2, B, 64] -- and outputs (out [B, 1], hn, cn):
+    |STFT| as two strided Conv1d (periodic Hann(256), hop 64, bins 1..128) -> log(1 + 50 |X|) -> four Conv1d(k=3, pad 1) + ReLU ->
+    nn.LSTM(64, 64, num_layers=2) -> ReLU -> Linear(64, 1) -> Sigmoid -> mean over time."""
+    import torch
+    import torch.nn as nn
+    from oracle import vad_standin as VS
+    n = np.arange(VS.N_FFT, dtype=np.float64)
+    ang = 2.0 * np.pi * np.outer(np.arange(1, VS.N_BINS + 1), n) / VS.N_FFT
+    win = VS.hann_periodic()
+
+    class Vad(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.re = nn.Conv1d(1, VS.N_BINS, VS.N_FFT, stride=VS.HOP, bias=False)
+            self.im = nn.Conv1d(1, VS.N_BINS, VS.N_FFT, stride=VS.HOP, bias=False)
+            self.enc = nn.ModuleList([nn.Conv1d(ci, co, 3, stride=st, padding=1) for ci, co, st in VS.ENC])
+            self.lstm = nn.LSTM(VS.HID, VS.HID, num_layers=2, batch_first=True)
+            self.dec = nn.Linear(VS.HID, 1)
+            with torch.no_grad():
+                self.re.weight.copy_(torch.from_numpy((win * np.cos(ang))[:, None, :].astype(np.float32)))
+                self.im.weight.copy_(torch.from_numpy((-win * np.sin(ang))[:, None, :].astype(np.float32)))
+                for conv, (w, b) in zip(self.enc, vad["enc"]):
+                    conv.weight.copy_(torch.from_numpy(np.ascontiguousarray(w.transpose(2, 1, 0))))      # [k, cin, cout] -> [cout, cin, k]
+                    conv.bias.copy_(torch.from_numpy(b))
+                H = VS.HID
+                for layer, (w, b) in enumerate(vad["lstm"]):                  # rows (x ; h), columns i | f | g | o: torch's own order
+                    getattr(self.lstm, f"weight_ih_l{layer}").copy_(torch.from_numpy(np.ascontiguousarray(w[:H].T)))
+                    getattr(self.lstm, f"weight_hh_l{layer}").copy_(torch.from_numpy(np.ascontiguousarray(w[H:].T)))
+                    getattr(self.lstm, f"bias_ih_l{layer}").copy_(torch.from_numpy(b))
+                    getattr(self.lstm, f"bias_hh_l{layer}").zero_()
+                self.dec.weight.copy_(torch.from_numpy(vad["dec"][0][None, :].copy()))
+                self.dec.bias.fill_(float(vad["dec"][1]))
+
+        def forward(self, x, sr, h, c):
+            x = x * (sr == 16000).to(x.dtype)                  # (the rate input stays part of the graph, as in the real file)
+            x = x[:, None, :]
+            re, im = self.re(x), self.im(x)
+            a = torch.log(1.0 + 50.0 * torch.sqrt(re * re + im * im))
+            for conv in self.enc:
+                a = torch.relu(conv(a))
+            y, (hn, cn) = self.lstm(a.transpose(1, 2), (h, c))
+            out = torch.sigmoid(self.dec(torch.relu(y))).mean(dim=1)
+            return out, hn, cn
+
+    return Vad().eval()
+
+
+def export_vad(vad, path, opset=13):
+    import torch
+    export(torch_vad(vad), (torch.rand(1, 640) * 0.1, torch.tensor(16000), torch.zeros(2, 1, 64), torch.zeros(2, 1, 64)), path, opset,
+           input_names=["input", "sr", "h", "c"], output_names=["output", "hn", "cn"])
+
+
 def export_reference_files(directory, weights, head_opsets=None, embedding_opset=13, mel_opset=12):
     """Write melspectrogram.onnx, embedding_model.onnx and one <name>.onnx per head of `weights` = {"embedding", "heads"} (binary,
     multiclass and gated heads; file name = the head's key) into `directory`; returns {name: path}."""
