@@ -39,11 +39,18 @@ def trim_mmap(mmap_path: str, n_rows: Optional[int] = None) -> int:
     return n_rows
 
 
-def _embedding_weights(weights: Optional[str]) -> dict:
-    """The embedding model's parameters: the .onnx file where the reference keeps it, else (opt-in) synthetic ones."""
+def _embedding_weights(weights) -> dict:
+    """The embedding model's parameters: the caller's ({"embedding": ...} as for `Model`, or the path of an embedding_model.onnx),
+    else the .onnx file where the reference keeps it, else (opt-in, weights="synthetic") random-init ones."""
     from . import weights as W
     from .model import FEATURE_MODELS
+    if isinstance(weights, dict):
+        return weights["embedding"] if "embedding" in weights else weights
     path = FEATURE_MODELS["embedding"]["model_path"]
+    if isinstance(weights, str) and weights != "synthetic":
+        if not os.path.exists(weights):
+            raise ValueError(f"{weights} does not exist")
+        path = weights
     if os.path.exists(path):
         from . import onnx_ingest
         return onnx_ingest.load_embedding(path)
@@ -54,14 +61,15 @@ def _embedding_weights(weights: Optional[str]) -> dict:
 
 def compute_features_from_generator(generator: Iterator[np.ndarray], n_total: int, clip_duration: int, output_file: str,
                                     device: str = "gpu", ncpu: int = 1, engine: Optional[StreamEngine] = None,
-                                    weights: Optional[str] = None) -> int:
+                                    weights=None) -> int:
     """utils.py:542-601 with the embedding work on the MI355X.
 
     `generator` yields int16 arrays [batch, clip_duration]; the first batch fixes the batch size (ValueError when it
     exceeds `n_total`, utils.py:581-583); rows beyond `n_total` are dropped; the file is trimmed to the rows written.
     `device` / `ncpu` exist for signature compatibility (there is no CPU path here).  `engine`: an existing
-    `StreamEngine` to run on; otherwise one is created with as many streams as the batch (`weights='synthetic'` opts
-    into random-init embedding weights when the model file is absent, like `Model`).  Returns the rows written."""
+    `StreamEngine` to run on; otherwise one is created with as many streams as the batch.  `weights`: None = the embedding model
+    file where the reference keeps it; the path of an embedding_model.onnx; a weight dict as for `Model`; 'synthetic' opts into
+    random-init weights when the file is absent.  Returns the rows written."""
     n_cols = AudioFeatures.get_embedding_shape(None, clip_duration / 16000)
     if n_cols[0] < 1:
         raise ValueError("clips are shorter than one 76-frame embedding window (12512 samples, 782 ms)")

@@ -75,6 +75,18 @@ def main():
             out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
             out[f"{cid}/vad"] = np.array(list(mdl.vad.prediction_buffer), dtype=np.float64)
             out[f"{cid}/ring"] = np.array([list(mdl.prediction_buffer[k]) for k in labels], dtype=np.float64)
+        # the bulk feature path (utils.py:243-385, what compute_features_from_generator / the training scripts call)
+        from openwakeword.utils import AudioFeatures
+        F = AudioFeatures(melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"],
+                          inference_framework="onnx", ncpu=2)
+        j = clips["hey_jane"]
+        x = np.stack([j[:32000], j[5000:37000] // 4, np.zeros(32000, np.int16), np.resize(clips["alexa_test"], 32000)])
+        out["embed/pcm"] = x
+        out["embed/embed_clips"] = F.embed_clips(x, batch_size=3, ncpu=2).astype(np.float32)
+        out["embed/melspec_batch"] = F._get_melspectrogram_batch(x, batch_size=2, ncpu=1).astype(np.float32)
+        out["embed/get_embeddings"] = np.asarray(F._get_embeddings(x[1]), np.float32)
+        out["embed/melspectrogram"] = np.asarray(F._get_melspectrogram(x[0][:12345]), np.float32)
+        out["embed/shape_2s"] = np.array(F.get_embedding_shape(2.0))
         cid, head_names, clip, sizes = cases.ONNX_SEQUENCE
         np.random.seed(cases.SEED_NP)
         mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",

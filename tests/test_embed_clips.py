@@ -200,3 +200,38 @@ def test_bulk_predict_matches_predict_clip_per_file(tmp_path):
     np.random.seed(11)
     other = bulk_predict(files[:1], names, weights=w, chunk_size=1024)
     assert len(other[files[0]]) == len(range(0, len(z["pcm/alexa_test"]) + 32000 - 1024, 1024))
+
+
+@gpu
+def test_bulk_feature_path_matches_the_reference_audiofeatures_on_exported_files(tmp_path):
+    """The (f)1 row against the REFERENCE's own AudioFeatures (utils.py:180-385) run on melspectrogram / embedding FILES written by
+    PyTorch's exporter (tests/golden/make_golden_onnx.py): the HIP side loads the same files by path and must return the reference's
+    embed_clips / _get_melspectrogram_batch / _get_embeddings / _get_melspectrogram / get_embedding_shape results, and
+    compute_features_from_generator must write the same rows."""
+    pytest.importorskip("torch")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    import torch_export as TE
+    from openwakeword_amd import Model
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    try:
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    m = Model(wakeword_models=[paths["alexa_custom"]], melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+    try:
+        F = m.preprocessor
+        x = ref["embed/pcm"]
+        np.testing.assert_allclose(F.embed_clips(x, batch_size=3, ncpu=2), ref["embed/embed_clips"], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(F._get_melspectrogram_batch(x, batch_size=2), ref["embed/melspec_batch"], rtol=0, atol=5e-4)
+        np.testing.assert_allclose(F._get_embeddings(x[1]), ref["embed/get_embeddings"], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(F._get_melspectrogram(x[0][:12345]), ref["embed/melspectrogram"], rtol=0, atol=5e-4)
+        assert tuple(F.get_embedding_shape(2.0)) == tuple(ref["embed/shape_2s"])
+    finally:
+        m.close()
+    from openwakeword_amd.utils import compute_features_from_generator
+    out = str(tmp_path / "features.npy")
+    assert compute_features_from_generator(iter([x[:2], x[2:]]), 4, 32000, out, weights=paths["embedding_model"]) == 4
+    np.testing.assert_allclose(np.load(out), ref["embed/embed_clips"], rtol=0, atol=2e-4)

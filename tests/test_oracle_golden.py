@@ -290,3 +290,18 @@ def test_oracle_vad_matches_the_reference_vad_class_on_an_exported_file(golden, 
     assert got.shape == want.shape and (want == 0).any() and (want > 0).any()
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
     np.testing.assert_allclose(np.array([list(mdl.prediction_buffer[k]) for k in labels]), golden_files[f"{cid}/ring"], rtol=0, atol=2e-5)
+
+
+def test_oracle_bulk_features_match_the_reference_audiofeatures_on_exported_files(golden_files):
+    """utils.py:180-385 as the reference itself ran them on the exporter-written melspectrogram / embedding files: embed_clips,
+    _get_melspectrogram_batch (a floor per clip on the CPU path), _get_embeddings, _get_melspectrogram, get_embedding_shape."""
+    w = cases.onnx_file_weights()
+    F = O.OracleAudioFeatures(w["embedding"], init_noise=np.zeros(64000, np.int16))
+    x = golden_files["embed/pcm"]
+    want = golden_files["embed/embed_clips"]
+    got = np.stack([F.clip_embeddings(c) for c in x])
+    assert got.shape == want.shape == (4, 16, 96) and tuple(golden_files["embed/shape_2s"]) == (16, 96)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(np.stack([F.melspectrogram(c) for c in x]), golden_files["embed/melspec_batch"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(F.clip_embeddings(x[1]), golden_files["embed/get_embeddings"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(F.melspectrogram(x[0][:12345]), golden_files["embed/melspectrogram"], rtol=0, atol=2e-4)
