@@ -71,3 +71,6 @@ ONNX_VAD_CASES = [
     ("fvad30", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=2560), 0.3),
     ("fvad12", ["mycroft_custom"], "hey_mycroft_test", dict(chunk_size=1280, padding=0), 0.12),
 ]
+
+# Model(custom_verifier_models={name: pickle}) (model.py:183-195, 320-328): the pickled scikit-learn pipeline of tests/verifier_fixture.py
+ONNX_VERIFIER = ("fver", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=1280), "alexa_custom", 0.3)

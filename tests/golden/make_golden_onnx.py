@@ -75,6 +75,18 @@ def main():
             out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
             out[f"{cid}/vad"] = np.array(list(mdl.vad.prediction_buffer), dtype=np.float64)
             out[f"{cid}/ring"] = np.array([list(mdl.prediction_buffer[k]) for k in labels], dtype=np.float64)
+        # a custom verifier model re-scoring the frames the base model likes (model.py:320-328)
+        import verifier_fixture
+        cid, head_names, clip, kw, target, vthr = cases.ONNX_VERIFIER
+        pkl = verifier_fixture.write(os.path.join(d, "verifier.pkl"))
+        np.random.seed(cases.SEED_NP)
+        mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",
+                                 custom_verifier_models={target: pkl}, custom_verifier_threshold=vthr,
+                                 melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+        preds = mdl.predict_clip(clips[clip], **kw)
+        labels = sorted(preds[0].keys())
+        out[f"{cid}/labels"] = np.array(labels)
+        out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
         # the bulk feature path (utils.py:243-385, what compute_features_from_generator / the training scripts call)
         from openwakeword.utils import AudioFeatures
         F = AudioFeatures(melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"],

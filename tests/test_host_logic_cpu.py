@@ -208,3 +208,24 @@ def test_host_vad_wrapper_on_an_exported_file_session(stub, golden, tmp_path, ca
     np.testing.assert_allclose(np.array(m.vad.prediction_buffer), ref[f"{cid}/vad"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(got, ref[f"{cid}/scores"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(np.array([list(m.prediction_buffer[k]) for k in labels]), ref[f"{cid}/ring"], rtol=0, atol=2e-5)
+
+
+def test_custom_verifier_pickle_matches_the_reference_on_exported_files(stub, golden, tmp_path):
+    """model.py:183-195 (loading) + 320-328 (re-scoring) with the pickled scikit-learn pipeline of tests/verifier_fixture.py, against
+    the reference's own Model run with the same pickle on the exporter-written files (cases.ONNX_VERIFIER)."""
+    pytest.importorskip("sklearn")
+    import os
+    import verifier_fixture
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, kw, target, vthr = cases.ONNX_VERIFIER
+    pkl = verifier_fixture.write(str(tmp_path / "verifier.pkl"))
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights={"embedding": w["embedding"], "heads": {n: w["heads"][n] for n in head_names}},
+                custom_verifier_models={target: pkl}, custom_verifier_threshold=vthr)
+    preds = m.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(ref[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    want = ref[f"{cid}/scores"]
+    assert (np.abs(want[:, 0] - ref["f1280j/scores"][:, 0]) > 1e-6).sum() > 10          # the verifier did re-score frames
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)

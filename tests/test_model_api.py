@@ -712,3 +712,47 @@ def test_vad_file_host_session_and_device_network_match_the_reference_vad_class(
         assert compared > 8 and (want > 0).any() and (want == 0).any()
     finally:
         bm.close()
+
+
+@gpu
+def test_custom_verifier_on_exported_files_host_hook_and_device_dot_product(tmp_path, golden):
+    """(f)4 against the reference's own code: `Model(custom_verifier_models={name: pickle})` on the exporter-written files
+    (cases.ONNX_VERIFIER, tests/golden/make_golden_onnx.py) -- (a) the HIP Model with the pickled pipeline as host hook, files by
+    path; (b) BatchedModel with the pipeline folded into one dot product per stream on the device (oww_set_verifier)."""
+    pytest.importorskip("torch")
+    pytest.importorskip("sklearn")
+    import os
+    import torch_export as TE
+    import verifier_fixture
+    from openwakeword_amd import Model, BatchedModel
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, kw, target, vthr = cases.ONNX_VERIFIER
+    try:
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    pkl = verifier_fixture.write(str(tmp_path / "verifier.pkl"))
+    labels = list(ref[f"{cid}/labels"])
+    want = ref[f"{cid}/scores"]
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=[paths[n] for n in head_names], melspec_model_path=paths["melspectrogram"],
+              embedding_model_path=paths["embedding_model"], custom_verifier_models={target: pkl}, custom_verifier_threshold=vthr)
+    try:
+        seed_features = m.preprocessor.get_features(120)[0].copy()
+        preds = m.predict_clip(golden["pcm/" + clip], **kw)
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, want, rtol=0, atol=TOL_SCORE)
+    finally:
+        m.close()
+    src = cases.onnx_file_weights()
+    bm = BatchedModel(2, list(head_names), weights={"embedding": src["embedding"], "heads": {n: src["heads"][n] for n in head_names}})
+    try:
+        assert bm.labels == labels
+        bm.set_custom_verifier(target, verifier_fixture.trained_verifier(), threshold=vthr)
+        bm.reset(None, seed_features[-bm.engine.feature_ring:])
+        data = np.concatenate((np.zeros(16000, np.int16), golden["pcm/" + clip], np.zeros(16000, np.int16)))
+        for t, o in enumerate(range(0, len(data) - 1280, 1280)):
+            got = bm.predict_batch(np.ascontiguousarray(np.tile(data[o:o + 1280], (2, 1))))
+            np.testing.assert_allclose(got[1], want[t], rtol=0, atol=TOL_SCORE, err_msg=f"frame {t}")
+    finally:
+        bm.close()
