@@ -74,3 +74,8 @@ ONNX_VAD_CASES = [
 
 # Model(custom_verifier_models={name: pickle}) (model.py:183-195, 320-328): the pickled scikit-learn pipeline of tests/verifier_fixture.py
 ONNX_VERIFIER = ("fver", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=1280), "alexa_custom", 0.3)
+
+# class_mapping_dicts as the reference's own test passes them (tests/test_models.py:139-149; model.py:176-177 stores the OUTER dict, so
+# the argument only ever matters for single-output models, whose mapping predict() never reads), parent lookup (215-224) and
+# false-positive mining from a WAV file (428-479) on exported files
+ONNX_MAPPING = ("fmap", ["timer_custom", "alexa_custom"], "hey_jane", [{}, {"alexa_custom": {"0": "positive"}}], 0.25)

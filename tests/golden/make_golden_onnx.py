@@ -87,6 +87,27 @@ def main():
         labels = sorted(preds[0].keys())
         out[f"{cid}/labels"] = np.array(labels)
         out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
+        # label mapping given by the caller, parent lookup, false-positive mining from a WAV file
+        cid, head_names, clip, mapping, fthr = cases.ONNX_MAPPING
+        wav = os.path.join(d, "clip.wav")
+        with wave.open(wav, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes(clips[clip].tobytes())
+        np.random.seed(cases.SEED_NP)
+        mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",
+                                 class_mapping_dicts=mapping,
+                                 melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+        preds = mdl.predict_clip(clips[clip], chunk_size=1280)
+        labels = sorted(preds[0].keys())
+        out[f"{cid}/labels"] = np.array(labels)
+        out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
+        out[f"{cid}/parents"] = np.array([mdl.get_parent_model_from_label(k) for k in labels])
+        np.random.seed(cases.SEED_NP)
+        mdl.reset()
+        pos = mdl._get_positive_prediction_frames(wav, threshold=fthr, return_type="features")
+        out[f"{cid}/positive_labels"] = np.array(sorted(pos.keys()))
+        for k, v in pos.items():
+            out[f"{cid}/positive/{k}"] = np.asarray(v, np.float32)
         # the bulk feature path (utils.py:243-385, what compute_features_from_generator / the training scripts call)
         from openwakeword.utils import AudioFeatures
         F = AudioFeatures(melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"],

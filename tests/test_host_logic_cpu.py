@@ -229,3 +229,40 @@ def test_custom_verifier_pickle_matches_the_reference_on_exported_files(stub, go
     want = ref[f"{cid}/scores"]
     assert (np.abs(want[:, 0] - ref["f1280j/scores"][:, 0]) > 1e-6).sum() > 10          # the verifier did re-score frames
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_mapping_parent_lookup_and_positive_frames_match_the_reference(stub, golden, tmp_path):
+    """class_mapping_dicts, get_parent_model_from_label and _get_positive_prediction_frames (model.py:176-182, 215-224, 428-479)
+    against the reference's own run on exported files (cases.ONNX_MAPPING); here the host shim on the oracle engine."""
+
+    import os
+    import wave
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, mapping, fthr = cases.ONNX_MAPPING
+    wav = str(tmp_path / "clip.wav")
+    with wave.open(wav, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(golden["pcm/" + clip].tobytes())
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), class_mapping_dicts=mapping,
+                weights={"embedding": cases.onnx_file_weights()["embedding"], "heads": {n: cases.onnx_file_weights()["heads"][n] for n in head_names}})
+    try:
+        assert m.class_mapping["alexa_custom"] == {"alexa_custom": {"0": "positive"}}     # the reference stores the outer dict (model.py:176-177)
+        preds = m.predict_clip(golden["pcm/" + clip], chunk_size=1280)
+        labels = list(ref[f"{cid}/labels"])
+        assert sorted(preds[0].keys()) == labels
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, ref[f"{cid}/scores"], rtol=0, atol=2e-5)
+        assert [m.get_parent_model_from_label(k) for k in labels] == list(ref[f"{cid}/parents"])
+        np.random.seed(cases.SEED_NP)
+        m.reset()
+        pos = m._get_positive_prediction_frames(wav, threshold=fthr, return_type="features")
+        assert sorted(pos.keys()) == list(ref[f"{cid}/positive_labels"])
+        for k, v in pos.items():
+            want = ref[f"{cid}/positive/{k}"]
+            assert v.shape == want.shape, k
+            np.testing.assert_allclose(v, want, rtol=0, atol=1e-4)
+        audio = m._get_positive_prediction_frames(wav, threshold=fthr, return_type="audio")
+        assert all(a.shape[1] == 64000 for a in audio.values())
+    finally:
+        m.close()

@@ -756,3 +756,48 @@ def test_custom_verifier_on_exported_files_host_hook_and_device_dot_product(tmp_
             np.testing.assert_allclose(got[1], want[t], rtol=0, atol=TOL_SCORE, err_msg=f"frame {t}")
     finally:
         bm.close()
+
+
+@gpu
+def test_mapping_parent_lookup_and_positive_frames_on_exported_files(tmp_path, golden):
+    """class_mapping_dicts, get_parent_model_from_label and _get_positive_prediction_frames (model.py:176-182, 215-224, 428-479): the
+    HIP Model on exporter-written files by path against the reference's own run on the same files (cases.ONNX_MAPPING)."""
+    pytest.importorskip("torch")
+    import torch_export as TE
+    from openwakeword_amd import Model
+    try:
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+
+    import os
+    import wave
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, mapping, fthr = cases.ONNX_MAPPING
+    wav = str(tmp_path / "clip.wav")
+    with wave.open(wav, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(golden["pcm/" + clip].tobytes())
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=[paths[n] for n in head_names], class_mapping_dicts=mapping,
+              melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+    try:
+        assert m.class_mapping["alexa_custom"] == {"alexa_custom": {"0": "positive"}}     # the reference stores the outer dict (model.py:176-177)
+        preds = m.predict_clip(golden["pcm/" + clip], chunk_size=1280)
+        labels = list(ref[f"{cid}/labels"])
+        assert sorted(preds[0].keys()) == labels
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, ref[f"{cid}/scores"], rtol=0, atol=TOL_SCORE)
+        assert [m.get_parent_model_from_label(k) for k in labels] == list(ref[f"{cid}/parents"])
+        np.random.seed(cases.SEED_NP)
+        m.reset()
+        pos = m._get_positive_prediction_frames(wav, threshold=fthr, return_type="features")
+        assert sorted(pos.keys()) == list(ref[f"{cid}/positive_labels"])
+        for k, v in pos.items():
+            want = ref[f"{cid}/positive/{k}"]
+            assert v.shape == want.shape, k
+            np.testing.assert_allclose(v, want, rtol=0, atol=2e-4)
+        audio = m._get_positive_prediction_frames(wav, threshold=fthr, return_type="audio")
+        assert all(a.shape[1] == 64000 for a in audio.values())
+    finally:
+        m.close()
