@@ -31,4 +31,4 @@ def test_reference_on_exported_files_vectors_are_reproducible(tmp_path):
         if old[k].dtype.kind in "US":
             assert list(new[k]) == list(old[k]), k
         else:
-            np.testing.assert_allclose(new[k], old[k], rtol=0, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(new[k], old[k], rtol=0, atol=1e-4, err_msg=k)     # (fp32 BLAS summation order varies with the thread count)
