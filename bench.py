@@ -19,7 +19,7 @@ The JSON line carries, next to the contract fields:
   parity       64 probe streams x 16 frames placed at random ids of the SAME full-size engine, compared with the CPU
                oracle before the timed region (oracle/parity_sample.py; the timed configuration carries its own parity evidence)
   roofline     dominant kernel, from hipEvents on the library's stream during the timed steps
-  cpu_baseline the reference's algorithm on the host cores (torch-CPU port), N = 1 only
+  cpu_baseline the reference's algorithm on the host cores (torch-CPU port), timed by rank 0 before it joins the process group (every N)
   sustained    100 warm-up + 250 timed steps of the same configuration (N = 1 only)
   fp32_exact   the same workload on the exact-fp32 kernel family (use_mfma = 1), the reference's arithmetic type
   resident_1m  1,048,576 streams resident in ONE handle on one GPU (run in a child process): ms per step must stay < 80
@@ -66,37 +66,61 @@ def head_flops(heads) -> int:
     return n
 
 
+_PROFILE_CACHE = {}
+
+
+def loaded_build() -> str:
+    """The source hash compiled into the libowwhip.so this process runs (oww_build_info: "src=<sha16> arch=...")."""
+    from openwakeword_amd import _lib
+    info = _lib.load().oww_build_info().decode()
+    return dict(kv.split("=", 1) for kv in info.split()).get("src", "unknown")
+
+
+def committed_profile(kind: str):
+    """(table, file name, None) of the newest committed rocprofv3 counter summary profiles/rNN_<kind>.json that was taken ON THE BUILD
+    THIS PROCESS RUNS -- tools/pmc.sh stores the library's source hash with every summary ("_csrc_sha16") -- else (None, None, why).
+    A kernel change without a fresh PMC pass must not price new times with old instruction counts."""
+    if kind in _PROFILE_CACHE:
+        return _PROFILE_CACHE[kind]
+    import glob
+    have = loaded_build()
+    res = (None, None, f"no profiles/r*_{kind}.json was taken on the loaded build (src={have}): run tools/pmc.sh on it")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get("_csrc_sha16") == have:
+            res = (t, os.path.basename(path), None)
+            break
+    _PROFILE_CACHE[kind] = res
+    return res
+
+
 def pmc_traffic(kernel: str, streams: int, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, produced by
-    tools/pmc.sh on the same workload; newest round first); None when no pass matches this configuration."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass of THIS build (FETCH_SIZE x2 + WRITE_SIZE, produced by
+    tools/pmc.sh on the same workload); None when no pass matches this configuration or this build."""
     if args.valu or args.lds_mfma or streams != 131072:
         return None
     key = kernel + ("_rr" if args.fp32 else "_hx")
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
-        except Exception:
-            continue
-    return None
+    t, name, _why = committed_profile("traffic")
+    if t is None or key not in t:
+        return None
+    return {"hbm_bytes_per_launch": t[key]["hbm_bytes"], "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, build src={t['_csrc_sha16']})"}
 
 
 def issue_bound(kernel: str, streams: int, avg_ms: float, args):
-    """Composite bound of one launch from the committed PMC pass (profiles/r04_instr.json, tools/pmc.sh on this workload): wave
+    """Composite bound of one launch from the committed PMC pass of the loaded build (profiles/rNN_instr.json, tools/pmc.sh on this workload): wave
     instructions per stream-step by pipe and the SIMD cycles they need at issue.  On this part a wave's VALU and MFMA work add up on
     its SIMD (tools/ubench/overlap_ubench.hip: a VALU instruction issues in 4 cycles, v_mfma_f32_16x16x32_f16 in 16, no overlap between
     the waves of a SIMD), so issue cycles = 4 VALU + 16 MFMA per stream-step; LDS and HBM are priced beside it and the largest of the
     fractions names what binds."""
     if args.valu or args.lds_mfma or args.fp32 or streams != 131072:
         return None
-    t = src = None
-    for name in ("r04_instr.json", "r03_instr.json"):            # newest committed PMC pass first
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel + "_hx"]
-            src = name
-            break
-        except Exception:
-            continue
+    tab, src, why = committed_profile("instr")
+    if tab is None:
+        return {"unavailable": why}
+    t = tab.get(kernel + "_hx")
     if t is None:
         return None
     per = lambda c: t[c] / streams
@@ -113,7 +137,7 @@ def issue_bound(kernel: str, streams: int, avg_ms: float, args):
             "simd_cycles_per_stream_step": {"available_at_2.4GHz": round(avail, 0), "mfma_issue": round(16 * mfma, 0), "valu_issue": round(4 * valu, 0)},
             "frac_of_available": {k: (round(v, 4) if v is not None else None) for k, v in fr.items()}, "binds": binds,
             "lds_bank_conflict_frac": round(t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0), 4),
-            "source": f"profiles/{src} (rocprofv3 --pmc passes of tools/pmc.sh on this workload); the chip sits at its power cap in this regime "
+            "source": f"profiles/{src} (rocprofv3 --pmc passes of tools/pmc.sh on this workload and this build, src={tab['_csrc_sha16']}); the chip sits at its power cap in this regime "
                       "(profiles/r04_power.jsonl: 1,354 W of 1,400 W, sclk 1.99 of 2.4 GHz), so ~0.83 of 'available' is the practical ceiling"}
 
 
@@ -512,8 +536,10 @@ def main():
     rank0 = rank == 0
     head_names = [n for n in args.heads.split(",") if n]
     cpu_base = None
-    if rank0 and args.gpus == 1 and not args.no_cpu_baseline:
-        # forked single-threaded workers: must run before this process touches HIP
+    t_pre = time.perf_counter()
+    if rank0 and not args.no_cpu_baseline:
+        # forked single-threaded workers: must run before this process touches HIP.  Rank 0 times it at EVERY N (the other ranks sit
+        # in the rendezvous below meanwhile, so the host cores are free): an N > 1 line without it would read "unmeasured".
         from oracle import cpu_baseline
         cpu_base = cpu_baseline.run(head_names, budget_s=args.cpu_seconds)
     parity_ref = None
@@ -527,6 +553,7 @@ def main():
         if world == 1 and not args.no_extras and not args.vad and set(head_names) == set(PS.HEADS3):
             vad_parity_ref = PS.oracle_reference(vad=True)     # for the vad_fused record (BASELINE configs[4])
 
+    t_pre_done = time.perf_counter()
     import torch
     import torch.distributed as dist
     from openwakeword_amd import weights as W
@@ -543,10 +570,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rank 0 arrives late by design: it has timed the CPU baseline (--cpu-seconds) and computed the oracle reference of the parity
+        # sample (a child interpreter, 20-60 s on a loaded host) before it joins, so the rendezvous and the first collective get an
+        # explicit, generous timeout instead of whatever the backend defaults to
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=max(1800.0, 20.0 * args.cpu_seconds + 600.0))
         if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         if want_parity:
             dist.barrier()                               # rank 0 wrote the cache file before it joined
             if not rank0:
@@ -807,6 +839,7 @@ def main():
             out["roofline"] = None
         out.update(extras)
         out["cpu_baseline"] = cpu_base
+        out["pre_rendezvous_s"] = round(t_pre_done - t_pre, 1)      # rank 0: CPU baseline + oracle reference, before HIP / the process group
     else:
         out = None
     if world > 1 and args.gather == "dist" and backend == "nccl" and not one_gpu and not args.no_extras and not host and eng is not None:

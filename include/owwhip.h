@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OWW_ABI_VERSION 5
+#define OWW_ABI_VERSION 6
 
 #define OWW_OK            0
 #define OWW_EINVAL       -1   /* bad argument */
@@ -62,6 +62,9 @@ typedef struct oww_config {
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
 int  oww_abi_version(void);
+/* "src=<16 hex digits> arch=gfx950": the hash of the sources this binary was built from (openwakeword_amd/_build.py: source_hash).
+ * Profiles committed under profiles/ carry the same hash, so a measurement can be tied to the kernels it was taken on. */
+const char* oww_build_info(void);
 const char* oww_last_error(void);
 int  oww_create(const oww_config* cfg, oww_ctx** out);
 int  oww_destroy(oww_ctx* h);
@@ -167,7 +170,10 @@ int  oww_sync(oww_ctx* h);
  * Cost: with a HOST mask of which at most half the streams take part, only the stage groups (1 / 2 / 4 / 8 streams of a wave) that
  * hold a participating stream are launched and the heads run on the participants alone, so the step costs roughly in proportion to
  * the participation (streams sharing a group with a participant are computed and not stored); a device-resident mask, or more than
- * half of the streams, runs the full launches.  Default kernel family only (use_mfma = 3 with the fused front end); OWW_EINVAL otherwise. */
+ * half of the streams, runs the full launches.  Both register-resident kernel families take masked steps (use_mfma = 3 and the exact
+ * fp32 family 1, so weights the fp16 split refuses at commit can still be served; heads of any form); the proportional cost is the
+ * default family's (fused front end, heads of the [T,96] -> 64 -> 64 -> 1 form) -- every other combination runs full launches whose
+ * stores skip the streams that sit out.  The LDS-tiled families (use_mfma = 2, 0) return OWW_EINVAL. */
 int  oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uint8_t* stream_on, int stream_on_on_device,
                      float* scores, int scores_on_device);
 /* Range guard of the default kernel family (use_mfma = 3 evaluates every fp32 product as three f16 MFMAs on hi/lo-split

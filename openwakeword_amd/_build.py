@@ -19,6 +19,18 @@ def lib_path() -> str:
     return os.environ.get("OWW_LIB") or LIB
 
 
+def source_hash() -> str:
+    """First 16 hex digits of the SHA-256 over the library's sources (csrc/ + include/owwhip.h): compiled into the library
+    (oww_build_info) and stored with every rocprofv3 counter summary under profiles/, so that bench.py can tell whether a committed
+    PMC pass belongs to the kernels it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def is_fresh() -> bool:
     return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 
@@ -31,6 +43,7 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, de
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC,
            "-I" + os.path.join(ROOT, "include"), "-o", target + ".tmp", "-Wall", "-Wno-unused-function"]
     cmd += ["-D" + d for d in defines]
+    cmd += ['-DOWW_SRC_SHA16="' + source_hash() + '"']
     cmd += os.environ.get("OWW_HIPCC_FLAGS", "").split()          # (diagnostic builds only, e.g. -mllvm -amdgpu-waitcnt-forcezero)
     if verbose:
         print(" ".join(cmd))

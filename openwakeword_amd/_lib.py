@@ -8,7 +8,7 @@ import os
 from . import _build
 
 _lib = None
-ABI_VERSION = 5          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
+ABI_VERSION = 6          # OWW_ABI_VERSION of include/owwhip.h this binding was written against
 ERANGE = -5
 
 
@@ -26,6 +26,7 @@ class Config(C.Structure):
 _P = C.c_void_p
 SYMBOLS = {
     "oww_abi_version": (C.c_int, []),
+    "oww_build_info": (C.c_char_p, []),
     "oww_last_error": (C.c_char_p, []),
     "oww_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "oww_destroy": (C.c_int, [_P]),

@@ -766,6 +766,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
     HeadParams base{};
     base.feat = ext ? ext : h->d_feat; base.ext = ext ? 1 : 0; base.TR = h->TR; base.nfeat = h->d_nfeat;
     base.raw = raw_out; base.NL = h->NL; base.S = n_active; base.accumulate_max = accumulate_max ? 1 : 0;
+    base.stream_on = ext ? nullptr : h->on_now;
     const bool fast_ok = h->mfma && !force_generic;
     if (fast_ok) {
         for (auto& g : h->groups) {
@@ -849,6 +850,7 @@ int launch_mel(oww_ctx* h, const int16_t* d_pcm, int n_streams, int n_samples, i
     p.pcm = d_pcm; p.n_samples = n_samples; p.n_frames = n_frames; p.streaming = streaming;
     p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.out = out; p.smax = smax;
     p.hann = h->d_hann; p.mel_start = h->d_mstart; p.mel_taps = h->d_taps; p.S = n_streams;
+    p.stream_on = streaming ? h->on_now : nullptr;
 #ifndef OWK_MEL_WGS
 #define OWK_MEL_WGS 6      // mel workgroups per CU in the persistent grid (20 KB LDS, 68 VGPRs each; 7 and 8 measured slower: 0.85 / 0.77 vs 0.73 ms)
 #endif
@@ -934,6 +936,12 @@ int rccl_load() {
 void comm_release(oww_ctx* h);
 
 void free_all(oww_ctx* h) {
+    // Nothing of this handle may still be queued when its buffers go: every stream the handle ever launched on is drained first
+    // (hipFree would wait for the whole device as well, but the page-locked words -- h_range, which the f16-split kernels write at
+    // exit, h_lists, the ingest slots -- and the streams and events themselves are released by calls that promise no such wait).
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t st : {h->up_stream, h->down_stream, h->blk_stream[0], h->blk_stream[1], h->blk_stream[2], h->blk_stream[3]})
+        if (st) (void)hipStreamSynchronize(st);
     auto fr = [](auto*& p) { if (p) { (void)dev_free((void*)p); p = nullptr; } };
     fr(h->d_w); fr(h->d_allnets); fr(h->d_generic); fr(h->d_scratch);
     for (auto& g : h->groups) fr(g.d_nets);
@@ -1023,6 +1031,8 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
     const int S = h->S;
     int n_act = 0;
     for (int s = 0; s < S; ++s) n_act += on[s] != 0;          // (vectorised by the compiler)
+    if (n_act == 0) return 0;
+    if (!h->hx || !h->fuse || !h->generic_nets.empty()) return -1;       // the group lists are read by the default family's launches only
     if ((long long)n_act * 8 > (long long)S * 7) return -1;
     const size_t need = (size_t)S + S / 2 + S / 4 + S / 8 + S / 16 + 64;       // (regions of the five lists, see below)
     if (need > h->lists_cap) {
@@ -1228,6 +1238,7 @@ int probe_step(oww_ctx* t, const int16_t* d_chunk, bool heads) {
 }
 
 int calibrate_hx(oww_ctx* h, HxCalib& cal) {
+    (void)hipGetLastError();                 // (a stale error of the caller's thread is not this function's to report)
     make_probe_pcm(cal.pcm, h->cal_user);
     cal.nb = (int)(cal.pcm.size() / ((size_t)CAL_T * CAL_NP * OWW_CHUNK));
     oww_config c2 = h->cfg;
@@ -1321,9 +1332,14 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
     if (d_off) (void)dev_free(d_off);
     if (d_chunk) (void)dev_free(d_chunk);
     const std::string keep = g_err;
+    // the scratch handle's whole life -- launches whose status nobody looked at, its frees -- must have left no HIP error behind
+    const hipError_t e_run = hipStreamSynchronize(t->stream);
     (void)oww_destroy(t);
+    const hipError_t e_last = hipGetLastError();
     if (rc) g_err = keep;
     (void)hipSetDevice(h->cfg.device);
+    if (!rc && (e_run != hipSuccess || e_last != hipSuccess))
+        rc = fail(OWW_EHIP, "oww_commit: the calibration handle left a HIP error behind (run: %s, last: %s)", hipGetErrorString(e_run), hipGetErrorString(e_last));
     return rc;
 }
 
@@ -1377,6 +1393,10 @@ void comm_release(oww_ctx* h) {
 extern "C" {
 
 int oww_abi_version(void) { return OWW_ABI_VERSION; }
+#ifndef OWW_SRC_SHA16
+#define OWW_SRC_SHA16 "unknown"            /* (set by openwakeword_amd/_build.py: hash of csrc/ + include/owwhip.h) */
+#endif
+const char* oww_build_info(void) { return "src=" OWW_SRC_SHA16 " arch=gfx950"; }
 const char* oww_last_error(void) { return g_err.c_str(); }
 
 int oww_create(const oww_config* cfg, oww_ctx** out) {
@@ -2050,9 +2070,7 @@ int oww_step_masked(oww_ctx* h, const int16_t* pcm, int pcm_on_device, const uin
     OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step_masked: handle not committed");
     if (!pcm || !stream_on) return fail(OWW_EINVAL, "oww_step_masked: null argument");
-    if (!h->hx || !h->fuse || !h->generic_nets.empty())
-        return fail(OWW_EINVAL, "oww_step_masked: needs the fp16-split kernels with the fused front end (use_mfma = 3, OWW_NO_FUSE unset) and "
-                    "heads of the fast [T,96] -> 128/64/32 form");
+    if (!h->rr) return fail(OWW_EINVAL, "oww_step_masked: needs the register-resident kernel families (use_mfma = 3 or 1)");
     if (int rc = range_check(h, "oww_step_masked")) return rc;
     HIPCHK(hipSetDevice(h->cfg.device));
     h->k_last = 1;
@@ -2114,8 +2132,8 @@ int oww_submit(oww_ctx* h, const int16_t* pcm, int32_t n_chunks) { OWW_GUARD_BEG
 int oww_submit_masked(oww_ctx* h, const int16_t* pcm, const uint8_t* stream_on) {
     OWW_GUARD_BEGIN
     if (!stream_on) return fail(OWW_EINVAL, "oww_submit_masked: stream_on is null");
-    if (h && h->committed && (!h->hx || !h->fuse || !h->generic_nets.empty()))
-        return fail(OWW_EINVAL, "oww_submit_masked: needs the fp16-split kernels with the fused front end (see oww_step_masked)");
+    if (h && h->committed && !h->rr)
+        return fail(OWW_EINVAL, "oww_submit_masked: needs the register-resident kernel families (use_mfma = 3 or 1; see oww_step_masked)");
     return submit_impl(h, pcm, 1, stream_on);
     OWW_GUARD_END
 }

@@ -809,6 +809,9 @@ __global__ __launch_bounds__(64 * WG, (NS == 3 && C::WPS > 2 ? 2 : C::WPS)) void
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
+    // every pass starts at ring phase CH0 = 0 (conv a) and advances the ring by 4 * NCT chunks: with more than one pass the slot the
+    // chunk prefetched by conv d lands in is the one conv a of the next pass reads only if that advance is a multiple of the ring length
+    static_assert(NS == 2 || C::NPASS == 1 || (4 * NCT) % NS == 0, "multi-pass stages need a ring phase that returns to 0 after each pass");
     constexpr int KSA = (NCTI + 1) / 2, KS = (NCT + 1) / 2;          // k-steps per tap: first layer / other layers
     constexpr int NBA = 3 * KSA * 2, NB = 3 * KS * 2;                // 1 KB blocks per chunk
     using TK = TimeK<NCT, C::HOUT>;

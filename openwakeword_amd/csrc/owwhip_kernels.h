@@ -628,6 +628,7 @@ struct MelParams {
     const int* mel_start;   // [32]
     const float* mel_taps;  // [32][16]
     int S;
+    const uint8_t* stream_on;   // oww_step_masked (streaming mode): a stream with stream_on[s] == 0 keeps its sample tail; nullptr = all take part
 };
 
 // dB value and host transform of the mel front end (ipynb cell 15: 10 log10(max(p, 1e-10)); utils.py:180,206: x / 10 + 2) with the two
@@ -856,8 +857,10 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 const float db = (n_groups > 1) ? *o : last_db;
                 *o = (db == INFINITY) ? 1.0f : mel_units(db, floor_db);
             }
-            // new 480-sample tail = last 480 samples of [tail ; pcm]
-            if (p.n_samples >= 480) {
+            // new 480-sample tail = last 480 samples of [tail ; pcm] (a stream that sits a masked step out keeps its tail: the rows
+            // computed above from its stale samples are scratch nobody stores from)
+            if (p.stream_on && !p.stream_on[s]) {
+            } else if (p.n_samples >= 480) {
                 for (int i = tid; i < 480; i += MEL_NT) p.tail[(size_t)s * 480 + i] = pcm[p.n_samples - 480 + i];
             } else {
                 // shorter call: the tail shifts; read everything before anyone overwrites it
@@ -921,6 +924,7 @@ struct HeadParams {
     int NL;
     int S;
     int accumulate_max;     // 1: raw = max(raw, new)  (multi-chunk calls, model.py:298)
+    const uint8_t* stream_on;   // oww_step_masked: [S] 1 = the stream takes part in this step (its raw scores are stored); nullptr = all do
 };
 
 __device__ __forceinline__ const float* feat_row(const HeadParams& p, int s, int T, int t) {
@@ -930,6 +934,7 @@ __device__ __forceinline__ const float* feat_row(const HeadParams& p, int s, int
 }
 
 __device__ __forceinline__ void store_raw(const HeadParams& p, int s, int col, float v) {
+    if (p.stream_on && !p.ext && !p.stream_on[s]) return;
     float* o = p.raw + (size_t)s * p.NL + col;
     *o = p.accumulate_max ? fmaxf(*o, v) : v;
 }

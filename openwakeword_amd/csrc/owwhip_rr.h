@@ -470,7 +470,7 @@ struct RStageParams {
     float xmul;            // f16-split family: factor of the pooled hand-over (K of the next stage's input / K of this stage's last layer)
     float emb_mul;         // f16-split family, last stage: 1 / K of conv19 (embeddings are stored in true units)
     int* range_flag;       // f16-split family: sticky out-of-range flag of the handle (owwhip_hx.h nan_guard); nullptr otherwise
-    const uint8_t* stream_on;  // f16-split family, oww_step_masked: [S] 1 = the stream takes part in this step; nullptr = all do
+    const uint8_t* stream_on;  // oww_step_masked (register-resident families): [S] 1 = the stream takes part in this step; nullptr = all do
     const int* glist;          // f16-split family, oww_step_masked with few participants: the n_groups groups (of this stage's SPT streams)
                                // that hold at least one participating stream; nullptr = groups g_base .. g_base + n_groups-1
     int g_base;                // f16-split family: first group of the block this launch covers (block-pipelined step; 0 otherwise)
@@ -525,6 +525,9 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         sbn[l][1][c] = p.shift[l][c];
     }
     const int s_first = g * C::SPT;
+    // masked steps (oww_step_masked): a stream that sits the step out is computed like any other and stores none of its state;
+    // per lane, because a tile holds SPT streams (position p of a tile belongs to stream p / F in this family)
+    const bool lane_on = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (lane & 15) / F, p.S - 1)] != 0);
 
     float* hb = p.hist_b + (size_t)g * C::HIST_FLOATS;
     float* hd = p.hist_d + (size_t)g * C::HIST_FLOATS;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     load_tile<NCT>(H1, hb + NCT * 4 * 64, lane);
     f32x4 Yb[RP][NCT];
     conv_time_lds<NCT, NCT, RP, true, NCT, NB, C::HOUT, C::HOUT>(H0, H1, Ya, Yb, wbuf, p.w[1], p.w[2], sbn[1][0], sbn[1][1], wave, lane, wbuf1);
-    if (active) {
+    if (lane_on) {
         store_tile<NCT>(Ya[RP - 2], hb, lane);
         store_tile<NCT>(Ya[RP - 1], hb + NCT * 4 * 64, lane);
     }
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
     load_tile<NCT>(H0, hd, lane);
     load_tile<NCT>(H1, hd + NCT * 4 * 64, lane);
     conv_time_lds<NCT, NCT, RP, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBA : 0)), C::HOUT, C::HOUT>(H0, H1, Yc, Yd, wbuf, p.w[3], LAST ? p.w19 : p.w[0], sbn[3][0], sbn[3][1], wave, lane, wbuf1);
-    if (active) {
+    if (lane_on) {
         store_tile<NCT>(Yc[RP - 2], hd, lane);
         store_tile<NCT>(Yc[RP - 1], hd + NCT * 4 * 64, lane);
     }
@@ -605,12 +608,13 @@ __global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
         load_tile<NCT>(H1, h19 + NCT * 4 * 64, lane);
         f32x4 E[1][NCT];
         conv_time_lds<NCT, NCT, 1, false, 4 * NCT, 0>(H0, H1, Pl, E, wbuf, p.w19, nullptr, nullptr, nullptr, wave, lane, wbuf1);
-        if (active) {
+        const bool on19 = active && (p.stream_on == nullptr || p.stream_on[min(s_first + (pos & 7), p.S - 1)] != 0);   // lanes 8..15 mirror 0..7
+        if (on19) {
             store_tile<NCT>(H1, h19, lane);
             store_tile<NCT>(Pl[0], h19 + NCT * 4 * 64, lane);
         }
         const int s = s_first + pos;
-        if (active && pos < C::SPT && s < p.S) {
+        if (on19 && pos < C::SPT && s < p.S) {
             const uint32_t slot = p.nfeat[s] % (uint32_t)p.TR;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -838,7 +842,8 @@ __global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
                         if ((pos & 1) == 0) xo[(ct * 4 + e) * 64 + j * 16 + h * 8 + (pos >> 1)] = m;
                     }
         }
-        // new histories: conv1 rows 6,7 (packed) and mel rows 6,7
+        // new histories: conv1 rows 6,7 (packed) and mel rows 6,7 (not for a stream that sits a masked step out)
+        if (p.stream_on && !p.stream_on[s]) continue;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll

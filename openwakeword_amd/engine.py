@@ -158,6 +158,9 @@ class StreamEngine:
             if isinstance(calibration_pcm, str):
                 calibration_pcm = default_calibration_pcm() if calibration_pcm == "default" else None
             if calibration_pcm is not None and int(use_mfma) == 3:
+                if np.asarray(calibration_pcm).dtype != np.int16:
+                    # (float audio in [-1, 1] would be truncated to silence and the scale ladder calibrated on nothing)
+                    raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {np.asarray(calibration_pcm).dtype} data.")
                 cal = np.ascontiguousarray(calibration_pcm, dtype=np.int16)
                 if cal.ndim != 2 or cal.shape[1] < CHUNK:
                     raise ValueError("calibration_pcm must be int16 [n_streams, n_frames * 1280]")

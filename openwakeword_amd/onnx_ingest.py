@@ -212,6 +212,11 @@ def _fold_constants(g: dict) -> None:
     g["nodes"] = keep
 
 
+class GraphIdiomUnknown(ValueError):
+    """A graph walker met a structure it does not know -- as opposed to a parameter it FOUND and that differs from what the kernels
+    compute (a plain ValueError).  `verify_melspectrogram` callers may downgrade this one to a warning (model.resolve_embedding)."""
+
+
 class _Flow:
     """Dataflow view of a graph: who consumes a tensor, who produced it.  The loaders walk the DATAFLOW (never node order or node
     names), interpret every operator they pass and refuse -- naming the operator and where it sits -- what they cannot interpret."""
@@ -227,9 +232,11 @@ class _Flow:
             for o in n["outputs"]:
                 self.producer[o] = n
 
-    def refuse(self, why: str):
+    def refuse(self, why: str, unknown: bool = False):
+        """unknown = the walker lost the thread (a structure it does not know) as opposed to having FOUND a value that differs."""
         from collections import Counter
-        raise ValueError(f"{self.path}: {why}; operators in the file: {dict(Counter(n['op'] for n in self.g['nodes']))}")
+        raise (GraphIdiomUnknown if unknown else ValueError)(
+            f"{self.path}: {why}; operators in the file: {dict(Counter(n['op'] for n in self.g['nodes']))}")
 
     def const(self, n: dict, skip: str = None):
         """The constant operand of a binary node (the input that is an initializer), or None."""
@@ -373,6 +380,12 @@ def _walk_net(fl: _Flow, first: dict, where: str):
             tail.append(cons[0]["op"])
             cur = cons[0]["outputs"][0]
         else:
+            # a fourth linear layer (or the LayerNorm in front of it) behind the third: train.py's Net built with n_blocks != 1
+            # (train.py:56-83 accepts any number of hidden blocks) -- name the real cause instead of an odd "output activation"
+            deeper = [c["op"] for c in cons if c["op"] in ("Gemm", "MatMul", "LayerNormalization", "ReduceMean")]
+            if deeper:
+                fl.refuse(f"{where}: the third linear layer is followed by {deeper}: a network with more than two hidden layers (train.py's "
+                          "Net with n_blocks != 1) is not supported by the head kernels (Linear -> [LN] -> ReLU twice, then the output layer)")
             return net, tail, cur
 
 
@@ -769,7 +782,9 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
       * a lower clamp of 1e-10 in front of one Log, constant factors behind it that multiply to 10 / ln 10, no reference offset;
       * a ReduceMax of the result, 80 subtracted from it, and a Max / Clip against that;
       * nothing else that does arithmetic.
-    Returns the measured differences; raises ValueError naming what differs."""
+    Returns the measured differences; raises ValueError naming what differs -- and its subclass GraphIdiomUnknown when nothing was found
+    to differ but the walker met a structure it does not know (an unfolded constant, a second Log for a reference offset, a merged
+    real / imaginary convolution ...): the caller may then go on under a warning, see model.resolve_embedding."""
     g = load_graph(path)
     fl = _Flow(g, path)
     nodes, inits = g["nodes"], g["initializers"]
@@ -779,7 +794,7 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     odd = sorted({n["op"] for n in nodes} - known)
     if odd:
         fl.refuse(f"melspectrogram graph contains {odd} (a Sqrt would mean a magnitude, not a power spectrogram); the HIP front end computes "
-                  "a fixed recipe and cannot follow it")
+                  "a fixed recipe and cannot follow it", unknown="Sqrt" not in odd)
     for n in nodes:
         if n["op"] == "Pad":
             pads = n["attrs"].get("pads")
@@ -790,7 +805,7 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     # ---- STFT
     convs = [n for n in nodes if n["op"] == "Conv"]
     if len(convs) != 2:
-        fl.refuse(f"{len(convs)} Conv nodes, expected the real and imaginary STFT convolutions")
+        fl.refuse(f"{len(convs)} Conv nodes, expected the real and imaginary STFT convolutions", unknown=True)
     n_ = np.arange(W.N_FFT, dtype=np.float64)
     win = np.zeros(W.N_FFT)
     lo = (W.N_FFT - W.WIN) // 2
@@ -801,7 +816,7 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     for n in convs:
         w = inits.get(n["inputs"][1]) if len(n["inputs"]) > 1 else None
         if w is None or w.size != W.N_BINS * W.N_FFT or w.shape[0] != W.N_BINS:
-            fl.refuse(f"STFT kernel of shape {None if w is None else tuple(w.shape)}, expected [{W.N_BINS}, 1, {W.N_FFT}]")
+            fl.refuse(f"STFT kernel of shape {None if w is None else tuple(w.shape)}, expected [{W.N_BINS}, 1, {W.N_FFT}]", unknown=w is None)
         k = np.asarray(w, np.float64).reshape(W.N_BINS, W.N_FFT)
         st = [int(v) for v in (n["attrs"].get("strides") or [1])]
         if max(st) != W.HOP or any(v not in (1, W.HOP) for v in st):
@@ -816,12 +831,12 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
         found.add(name)
         worst = max(worst, d[name])
     if found != {"cos", "sin"}:
-        fl.refuse("the two STFT kernels are not a cos / sin pair")
+        fl.refuse("the two STFT kernels are not a cos / sin pair", unknown=True)
     # ---- power -> mel
     mm = [n for n in nodes if n["op"] == "MatMul"]
     fbs = [inits[i] for n in mm for i in n["inputs"] if i in inits and inits[i].shape in ((W.N_BINS, W.N_MELS), (W.N_MELS, W.N_BINS))]
     if len(mm) != 1 or len(fbs) != 1:
-        fl.refuse(f"{len(mm)} MatMul nodes / {len(fbs)} [{W.N_BINS}, {W.N_MELS}] constants, expected one filter bank product")
+        fl.refuse(f"{len(mm)} MatMul nodes / {len(fbs)} [{W.N_BINS}, {W.N_MELS}] constants, expected one filter bank product", unknown=True)
     fb = fbs[0] if fbs[0].shape == (W.N_BINS, W.N_MELS) else fbs[0].T
     fb_diff = float(np.abs(fb.astype(np.float64) - W.mel_filterbank().astype(np.float64)).max())
     if fb_diff > 1e-6:
@@ -832,7 +847,7 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     # ---- 10 log10(max(x, 1e-10)), no reference offset
     logs = [n for n in nodes if n["op"] == "Log"]
     if len(logs) != 1:
-        fl.refuse(f"{len(logs)} Log nodes, expected one")
+        fl.refuse(f"{len(logs)} Log nodes, expected one", unknown=True)
     src = fl.producer.get(logs[0]["inputs"][0])
     amin = None
     if src is not None and src["op"] == "Clip":
@@ -842,7 +857,7 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     elif src is not None and src["op"] == "Max":
         amin = _scalar(fl.const(src))
     if amin is None or abs(float(amin) - 1e-10) > 1e-13:
-        fl.refuse(f"the logarithm's input is clamped at {amin}, expected amin = 1e-10")
+        fl.refuse(f"the logarithm's input is clamped at {amin}, expected amin = 1e-10", unknown=amin is None)
     factor, offset, cur = 1.0, 0.0, logs[0]["outputs"][0]
     while True:
         cons = fl.consumers.get(cur, [])
@@ -868,20 +883,20 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     # ---- top_db: clamp at (max over the call) - 80
     rmax = [n for n in nodes if n["op"] == "ReduceMax"]
     if len(rmax) != 1:
-        fl.refuse(f"{len(rmax)} ReduceMax nodes, expected the one of top_db")
+        fl.refuse(f"{len(rmax)} ReduceMax nodes, expected the one of top_db", unknown=True)
     if rmax[0]["attrs"].get("axes") not in (None, []):
         fl.refuse(f"top_db reduces over axes {rmax[0]['attrs'].get('axes')}; the reference's patched power_to_db takes the maximum of the whole call")
     t = rmax[0]["outputs"][0]
     cons = fl.consumers.get(t, [])
     if len(cons) != 1 or cons[0]["op"] not in ("Sub", "Add") or fl.const(cons[0]) is None:
-        fl.refuse("the call's maximum is not lowered by a constant top_db")
+        fl.refuse("the call's maximum is not lowered by a constant top_db", unknown=True)
     top_db = _scalar(fl.const(cons[0])) * (1.0 if cons[0]["op"] == "Sub" else -1.0)
     if abs(top_db - 80.0) > 1e-6:
         fl.refuse(f"top_db = {top_db:g}; the front end clamps at the call's maximum - 80 dB")
     floor_t = cons[0]["outputs"][0]
     clampers = [c for c in fl.consumers.get(floor_t, []) if c["op"] in ("Max", "Clip")]
     if len(clampers) != 1 or cur not in clampers[0]["inputs"]:
-        fl.refuse("the log-mel values are not clamped from below at (maximum - top_db)")
+        fl.refuse("the log-mel values are not clamped from below at (maximum - top_db)", unknown=True)
     return {"stft_kernel_max_abs_diff": worst, "filterbank_max_abs_diff": fb_diff, "log_factor": factor, "top_db": top_db}
 
 

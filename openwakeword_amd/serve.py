@@ -248,6 +248,7 @@ class FanInServer:
             b[:] = 0
         self.n_steps = 0              # batched steps taken
         self.n_stream_steps = 0       # sum over steps of the streams that took part
+        self.n_dropped_messages = 0   # activation messages lost to clients that stopped reading (such clients are closed, see _post)
         self.n_range_recoveries = 0   # OWW_ERANGE events the pump recovered from (see _recover_range)
         self._last_recovery_step = -10**9
         self.send_timeout_s = 2.0     # deadline of one activation message / close handshake
@@ -339,7 +340,20 @@ class FanInServer:
         """Queue one activation message for a client.  Each client has ONE sender task that writes its queue in order (messages of
         consecutive steps cannot overtake each other) with a deadline per message, so a stalled socket never holds up the pump and
         never accumulates more than its own bounded queue; the task set keeps the tasks alive until they finish."""
-        if c.closed or len(c.outbox) >= 64:
+        if c.closed:
+            return
+        if len(c.outbox) >= 64:
+            # a client that does not read its socket: detections must not vanish in silence while the connection keeps a stream slot --
+            # count, log once and drop the connection (the pump returns its slot to the pool)
+            self.n_dropped_messages += len(c.outbox) + 1
+            import logging
+            logging.getLogger(__name__).warning("client %s does not read its activation messages (%d queued): closing it", c.cid, len(c.outbox))
+            c.closed = True
+            c.outbox.clear()
+            task = asyncio.get_running_loop().create_task(c.ws.close(code=1008, message=b"activation messages not read"))
+            self._tasks.add(task)
+            task.add_done_callback(self._tasks.discard)
+            self._have_chunk.set()
             return
         c.outbox.append(text)
         if c.sender is None or c.sender.done():
@@ -451,9 +465,9 @@ def main(argv=None) -> None:
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--port", type=int, default=9000)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--use-mfma", type=int, default=3, choices=(3,),
-                    help="kernel family; the fan-in server steps through oww_submit_masked, which the fp16-split family (3) provides -- "
-                         "weights that family refuses at commit (OWW_ERANGE) cannot be served batched-and-masked")
+    ap.add_argument("--use-mfma", type=int, default=None, choices=(3, 1),
+                    help="kernel family (default: the fp16-split family 3, and the exact-fp32 family 1 for weights family 3 refuses at "
+                         "commit); the fan-in server steps through oww_submit_masked, which both provide")
     a = ap.parse_args(argv)
     from .model import BatchedModel
     model = BatchedModel(a.streams, a.models, weights=a.weights, device=a.device, use_mfma=a.use_mfma)

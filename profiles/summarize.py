@@ -87,7 +87,16 @@ def traffic_json(paths, out_path):
             f = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 1024 * 2
             w = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) * 1024
             out[k] = {"fetch_bytes": round(f), "write_bytes": round(w), "hbm_bytes": round(f + w), "grid": grid[k]}
+    out["_csrc_sha16"] = build_hash()
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+
+
+def build_hash():
+    """Source hash of the library the counters were taken on (bench.py prices its composite bound only from a pass of the build it runs)."""
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from openwakeword_amd import _build
+    return os.environ.get("OWW_SRC_SHA16") or _build.source_hash()
 
 
 def instr_json(paths, out_path):
@@ -111,6 +120,7 @@ def instr_json(paths, out_path):
         if k.startswith(("stage", "heads_hx", "mel", "vad_")) and "SQ_INSTS_VALU" in v:
             out[k] = {c: sum(x) / len(x) for c, x in v.items()}
             out[k]["grid"] = grid[k]
+    out["_csrc_sha16"] = build_hash()
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
 
 

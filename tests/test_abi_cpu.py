@@ -26,7 +26,7 @@ def test_library_is_built_and_exports_the_header():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/owwhip.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.oww_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.oww_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_blob_layouts():
@@ -107,8 +107,8 @@ def test_header_is_plain_c99_and_the_ctypes_struct_has_its_layout(tmp_path):
     assert int(out["sizeof"]) == C.sizeof(_lib.Config)
     for f in fields:
         assert int(out[f]) == getattr(_lib.Config, f).offset, f
-    assert out["abi"].split() == ["5", "chunk", "1280", "emb", "96", "ring", "30", "comm", "128", "classes", "10"]
-    assert _lib.ABI_VERSION == 5 and engine.CHUNK == 1280 and engine.EMB_DIM == 96
+    assert out["abi"].split() == ["6", "chunk", "1280", "emb", "96", "ring", "30", "comm", "128", "classes", "10"]
+    assert _lib.ABI_VERSION == 6 and engine.CHUNK == 1280 and engine.EMB_DIM == 96
 
 
 def test_c_consumer_builds_and_fails_loudly_without_a_gpu(tmp_path):

@@ -42,12 +42,17 @@ def test_bare_two_rank_invocation_launches_itself():
     env = dict(os.environ, OWW_BENCH_ONE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--streams", "4096", "--no-cpu-baseline"]
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--streams", "4096", "--cpu-seconds", "2"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                             # ONE JSON line, from rank 0
     out = json.loads(lines[0])
+    # the N > 1 line is complete: rank 0 timed the CPU baseline before it joined the process group, and the
+    # roofline comes from rank 0's per-kernel pass
+    assert out["cpu_baseline"] is not None and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] in ("port", "reference")
+    assert out["roofline"] is not None and out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert out["pre_rendezvous_s"] >= 0
     assert out["n_gpus"] == 2 and out["config"]["sharding"] == "stream-range x2" and out["config"]["rccl_ranks"] == 0
     assert out["config"]["gather"] == "dist" and out["parity"]["n_pairs"] == 2048 and out["parity"]["ok"]
     assert abs(out["value"] - 2 * 4096 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-3

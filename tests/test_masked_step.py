@@ -14,24 +14,29 @@ pytestmark = pytest.mark.gpu
 HEADS = ["alexa", "hey_mycroft", "hey_jarvis"]
 
 
-def _engine(S, heads=HEADS, vad=None, vad_threshold=0.0):
+def _engine(S, heads=HEADS, vad=None, vad_threshold=0.0, family=3):
     from openwakeword_amd.engine import StreamEngine
     hs = {n: W.synthetic_head(n, seed=11 + i) for i, n in enumerate(heads)}
-    return StreamEngine(S, hs, W.synthetic_embedding(seed=3), vad=vad, vad_threshold=vad_threshold)
+    return StreamEngine(S, hs, W.synthetic_embedding(seed=3), vad=vad, vad_threshold=vad_threshold, use_mfma=family)
 
 
 def _pcm(rng, S, T):
     return (rng.standard_normal((T, S, 1280)) * 4000).astype(np.int16)
 
 
-@pytest.mark.parametrize("S,with_vad,frac", [(40, False, 0.6), (200, False, 0.6), (72, True, 0.6),
-                                             (200, False, 0.12), (330, True, 0.1), (1000, False, 0.03)])
-def test_masked_step_equals_private_sequences(S, with_vad, frac):
+@pytest.mark.parametrize("S,with_vad,frac,family,heads", [
+    (40, False, 0.6, 3, HEADS), (200, False, 0.6, 3, HEADS), (72, True, 0.6, 3, HEADS),
+    (200, False, 0.12, 3, HEADS), (330, True, 0.1, 3, HEADS), (1000, False, 0.03, 3, HEADS),
+    # the exact-fp32 family (what a network the fp16 split refuses is served by: VERDICT r04 next 4) and heads outside the fast
+    # [T,96] -> 64 -> 64 -> 1 form (the multiclass `timer`, generic head kernel): full launches, participant-only stores
+    (40, False, 0.6, 1, HEADS), (200, False, 0.12, 1, HEADS), (72, True, 0.5, 1, HEADS), (330, False, 0.3, 1, ["alexa", "timer"]),
+    (200, False, 0.4, 3, ["timer", "hey_jarvis"]), (90, False, 0.1, 3, ["alexa", "timer"])])
+def test_masked_step_equals_private_sequences(S, with_vad, frac, family, heads):
     """Random participation masks over 40 steps; every stream's k-th active step must equal, BIT FOR BIT, the k-th step of an
     unmasked engine that is fed the stream's active chunks back to back (S chosen to leave partly filled position tiles).
     frac <= 0.5: the library launches only the groups that hold a participating stream (build_active_lists): same results."""
     rng = np.random.default_rng(5)
-    T = 40
+    T = 40 if family == 3 else 24
     pcm = _pcm(rng, S, T)
     on = rng.random((T, S)) < frac
     on[:, 0] = True                      # one stream in every step
@@ -40,10 +45,10 @@ def test_masked_step_equals_private_sequences(S, with_vad, frac):
     on[1::2, 2] = False
     vad = W.synthetic_vad(seed=9) if with_vad else None
     thr = 0.5 if with_vad else 0.0
-    a, b = _engine(S, vad=vad, vad_threshold=thr), _engine(S, vad=vad, vad_threshold=thr)
+    a, b = _engine(S, heads, vad, thr, family), _engine(S, heads, vad, thr, family)
     first = a.step(np.zeros((S, 1280), np.int16)).copy()       # a plain step first, so that "previous scores" exist
     b.step(np.zeros((S, 1280), np.int16))
-    masked = np.empty((T, S, len(HEADS)), np.float32)
+    masked = np.empty((T, S, a.n_labels), np.float32)
     for t in range(T):
         junk = pcm[t].copy()
         junk[~on[t]] = 12345                                    # samples of a stream sitting out must not be read
@@ -105,9 +110,9 @@ def test_masked_step_argument_errors():
         e.step_masked(np.zeros((8, 1280), np.int16), np.ones(7))
     e.close()
     hs = {"alexa": W.synthetic_head("alexa", seed=1)}
-    f = StreamEngine(8, hs, W.synthetic_embedding(seed=3), use_mfma=1)          # exact-fp32 family: not supported, loudly
+    f = StreamEngine(8, hs, W.synthetic_embedding(seed=3), use_mfma=2)          # LDS-tiled families: not supported, loudly
     from openwakeword_amd._lib import OwwError
-    with pytest.raises(OwwError):
+    with pytest.raises(OwwError, match="register-resident"):
         f.step_masked(np.zeros((8, 1280), np.int16), np.ones(8))
     f.close()
 
@@ -265,13 +270,14 @@ def test_fan_in_server_slot_reuse_and_refusal():
     assert (np.stack(tap[2][:5]) == 0).all()                           # model.py:331-333 for the new owner of the slot
 
 
-def test_masked_submit_pipeline_equals_masked_steps():
+@pytest.mark.parametrize("family", [3, 1])
+def test_masked_submit_pipeline_equals_masked_steps(family):
     """oww_submit_masked with two steps in flight gives what blocking oww_step_masked calls give."""
     rng = np.random.default_rng(31)
     S, T = 96, 14
     pcm = _pcm(rng, S, T)
     on = rng.random((T, S)) < 0.7
-    a, b = _engine(S), _engine(S)
+    a, b = _engine(S, family=family), _engine(S, family=family)
     want = np.stack([a.step_masked(pcm[t], on[t]) for t in range(T)])
     bufs = [b.pinned_empty((S, 1280)) for _ in range(2)]
     got = []

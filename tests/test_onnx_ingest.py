@@ -610,7 +610,7 @@ def test_vad_reader_turns_every_parsing_failure_into_a_refusal(tmp_path):
 
 # ---- melspectrogram.onnx: the HIP front end is analytic, so the file is VERIFIED, not loaded ---------------------------------------
 def write_melspectrogram(path, win_len=400, n_fft=512, hop=160, top_db=80.0, amin=1e-10, power=2, fb=None, log_factor=None,
-                         reduce_axes=None, pad=0):
+                         reduce_axes=None, pad=0, idiom=None):
     """torch.onnx.export of torchlibrosa's Spectrogram + LogmelFilterBank as the notebook builds them (cell 15): Unsqueeze -> two
     Conv1d (window x cos / -sin, stride hop) -> squares -> Add -> MatMul(melW) -> Clip(amin) -> Log -> Div(ln 10) -> Mul(10) ->
     ReduceMax -> Sub(top_db) -> Max."""
@@ -629,6 +629,8 @@ def write_melspectrogram(path, win_len=400, n_fft=512, hop=160, top_db=80.0, ami
     p = g.op("Add", [g.op("Pow", [re, two]), g.op("Pow", [im, two])])
     if power == 1:
         p = g.op("Sqrt", [p])
+    if idiom == "abs":                       # a harmless operator the verifier's whitelist does not hold (|power| = power)
+        p = g.op("Abs", [p])
     p = g.op("Transpose", [g.op("Unsqueeze", [p], axes=[1])], perm=[0, 1, 3, 2])
     mel = g.op("MatMul", [p, g.const(W.mel_filterbank() if fb is None else fb, "melW")])
     lg = g.op("Log", [g.op("Clip", [mel, g.const(np.array(amin, np.float32), "amin")])])
@@ -640,6 +642,28 @@ def write_melspectrogram(path, win_len=400, n_fft=512, hop=160, top_db=80.0, ami
     out = g.op("Max", [db, g.op("Sub", [mx, g.const(np.array(top_db, np.float32), "top_db")])])
     g.outputs = [out]
     g.save(path)
+
+
+def test_unknown_melspectrogram_idiom_warns_and_a_found_difference_refuses(tmp_path):
+    """a rendering of the recipe the verifier cannot follow must not make the default real-weights path unloadable -- a
+    GraphIdiomUnknown becomes a RuntimeWarning in model.resolve_embedding -- while a parameter that was FOUND to differ (hop, top_db,
+    filter bank ...) still refuses."""
+    from openwakeword_amd.model import resolve_embedding
+    path = os.path.join(tmp_path, "melspectrogram.onnx")
+    emb = W.synthetic_embedding(5)
+    write_melspectrogram(path, idiom="abs")
+    with pytest.raises(onnx_ingest.GraphIdiomUnknown, match="Abs"):
+        onnx_ingest.verify_melspectrogram(path)
+    with pytest.warns(RuntimeWarning, match="could not be verified"):
+        assert resolve_embedding(emb, None, melspec_model_path=path) is emb
+    write_melspectrogram(path, hop=128)
+    with pytest.raises(ValueError, match="stride") as ei:
+        resolve_embedding(emb, None, melspec_model_path=path)
+    assert not isinstance(ei.value, onnx_ingest.GraphIdiomUnknown)
+    write_melspectrogram(path, power=1)                       # a Sqrt is a different quantity, not an idiom
+    with pytest.raises(ValueError, match="Sqrt") as ei:
+        onnx_ingest.verify_melspectrogram(path)
+    assert not isinstance(ei.value, onnx_ingest.GraphIdiomUnknown)
 
 
 def test_melspectrogram_file_is_verified_against_the_analytic_front_end(tmp_path):
