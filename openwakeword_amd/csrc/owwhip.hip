@@ -802,8 +802,6 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 // a launch that leaves workgroups alone on their CUs runs the deep weight ring (owwhip_hx.h: HX_NBUF_DEEP); same results
                 const bool deep = (int)grid.x <= h->small_wgs_heads;
                 const int nn = std::min(g.n_nets, 4);
-                const int nbuf = deep ? (nn <= 2 ? owh::HeadsDeep<1>::NBUF : owh::HeadsDeep<4>::NBUF) : owh::HX_NBUF;
-                (void)nbuf;
                 const int lds = 0;                                  // (the ring slots are static LDS objects: owwhip_hx.h hslot)
                 switch (nn * 2 + (deep ? 1 : 0)) {
                     case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;

@@ -1563,8 +1563,11 @@ __device__ __forceinline__ float* hslot_at(int i) {         // slot i of 0..I (i
     if constexpr (I == 0) return hslot<FLOATS, 0>();
     else return i == I ? hslot<FLOATS, I>() : hslot_at<FLOATS, I - 1>(i);
 }
-template <int NN, int NBUF = HX_NBUF>
-__global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(HeadHxParams p) {
+// WG = waves per workgroup (32 streams each).  Round 5 A/B at 4,096 streams x hey_jarvis (same box, per-launch hipEvents): one wave per
+// workgroup (128 workgroups instead of 32 on the 256 CUs) 79 us against 71 us for WG = 4 -- every workgroup then streams the weights
+// itself and the launch is bound by exactly that stream; two-wave workgroups in stages D / E: 36.6 / 39.3 against 35.2 / 38.6 us.
+template <int NN, int NBUF = HX_NBUF, int WG = HX_WG>
+__global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(HeadHxParams p) {
     using namespace owr;
     constexpr int NCT = NN * 4;                 // hidden tiles of 16
     constexpr int NBLK = NCT * 2;               // 1 KB blocks per k-step chunk
@@ -1573,7 +1576,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KST = p.T * 3;
-    issue_chunk<NBLK, HX_WG>(p.w1hx, hslot<CHUNK, 0>(), wave, lane);      // chunk 0 flies while the stream addresses are set up
+    issue_chunk<NBLK, WG>(p.w1hx, hslot<CHUNK, 0>(), wave, lane);      // chunk 0 flies while the stream addresses are set up
 
     // this lane's streams (two tiles of 16) and the address of ring row t
     int s[2];
@@ -1581,7 +1584,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
     uint32_t slot0[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int idx = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
+        const int idx = (blockIdx.x * WG + wave) * 32 + t * 16 + pos;
         s[t] = p.ids ? p.ids[min(idx, p.n_ids - 1)] : min(idx + p.s_base, p.S - 1);
         if (p.ext) { frow[t] = p.feat + (size_t)s[t] * p.T * 96; slot0[t] = 0; }
         else { frow[t] = p.feat + (size_t)s[t] * p.TR * 96; slot0[t] = p.nfeat[s[t]] + (uint32_t)(2 * p.TR - p.T + 1); }
@@ -1605,7 +1608,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
 #pragma unroll
     for (int c = 0; c < D; ++c)
         if (c < KST) {
-            if (c > 0) issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)c * CHUNK, hslot_at<CHUNK, NBUF - 1>(c), wave, lane);     // (chunk 0: issued at kernel start)
+            if (c > 0) issue_chunk<NBLK, WG>(p.w1hx + (size_t)c * CHUNK, hslot_at<CHUNK, NBUF - 1>(c), wave, lane);     // (chunk 0: issued at kernel start)
             asm volatile("" ::: "memory");      // program order = issue order: chunk c, then the features of k-step c
             load_raw(c, raw[c]);
         }
@@ -1621,7 +1624,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
         const float* cur = hslot_at<CHUNK, NBUF - 1>(u);
         if (ALWAYS || ks + D < KST) {                           // slot of k-step ks-1: every wave passed the last barrier, its features are split
             constexpr int un = (u + D) % NBUF;
-            issue_chunk<NBLK, HX_WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hslot_at<CHUNK, NBUF - 1>(un), wave, lane);
+            issue_chunk<NBLK, WG>(p.w1hx + (size_t)(ks + D) * CHUNK, hslot_at<CHUNK, NBUF - 1>(un), wave, lane);
             asm volatile("" ::: "memory");
             load_raw(ks + D, raw[un]);
         }
@@ -1711,7 +1714,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
     if (j == 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int idx = (blockIdx.x * HX_WG + wave) * 32 + t * 16 + pos;
+            const int idx = (blockIdx.x * WG + wave) * 32 + t * 16 + pos;
             if (idx >= (p.ids ? p.n_ids : p.S - p.s_base)) continue;
             const int st = p.ids ? p.ids[idx] : idx + p.s_base;
             if (p.stream_on && !p.stream_on[st]) continue;          // sits this step out: scores, rings and counters stay as they are
@@ -1771,7 +1774,7 @@ __global__ __launch_bounds__(64 * HX_WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kerne
     }
     // (which streams: the wave's 32 positions; with a participant list they are not contiguous -- reported as unknown)
     if (p.ids) raise_range_flag(bad, p.range_flag);
-    else raise_range_flag(bad, p.range_flag, (blockIdx.x * HX_WG + wave) * 32 + p.s_base, 32);
+    else raise_range_flag(bad, p.range_flag, (blockIdx.x * WG + wave) * 32 + p.s_base, 32);
 }
 
 }  // namespace owh

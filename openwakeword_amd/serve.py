@@ -145,7 +145,8 @@ def cohort_distance(a, b) -> float:
 
 
 class _Client:
-    __slots__ = ("cid", "slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed", "in_flight", "outbox", "sender")
+    __slots__ = ("cid", "slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed", "in_flight", "outbox", "sender", "arrivals",
+                 "n_arrived")
 
     def __init__(self, slot: Optional[int], ws, cid: int = -1):
         self.cid, self.slot, self.ws, self.rate = cid, slot, ws, 16000
@@ -156,11 +157,17 @@ class _Client:
         self.in_flight = 0            # submitted steps whose scores for this client have not been dispatched yet
         self.outbox: "collections.deque" = collections.deque()     # activation messages not yet written to the socket, in step order
         self.sender: Optional[asyncio.Task] = None                  # the one task that drains `outbox`
+        self.arrivals: "collections.deque" = collections.deque()   # when each complete, not yet scored chunk became available (metrics)
+        self.n_arrived = 0                                          # samples received so far
 
-    def push(self, x: np.ndarray) -> None:
+    def push(self, x: np.ndarray, now: float = 0.0) -> None:
         if x.size:
             self.pending.append(x)
             self.n_pending += x.size
+            done = (self.n_arrived + x.size) // CHUNK - self.n_arrived // CHUNK      # chunks this message completes
+            self.n_arrived += x.size
+            for _ in range(done):
+                self.arrivals.append(now)
 
     def pop_chunk(self, out: np.ndarray) -> None:
         """Move the oldest 1280 samples into `out`."""
@@ -219,23 +226,30 @@ def _settle(fut, res, err) -> None:
 
 class FanInServer:
     """`model`: a BatchedModel; its n_streams is the number of clients that can be connected at once (further connections are
-    refused with close code 1013).  `window_s`: how long the pump waits after the first chunk of a round becomes available for other
-    connections' chunks to arrive before it steps (0 = step at once; real-time clients deliver one chunk per 80 ms, so a few ms
-    gathers nearly everyone into the same step).  `on_scores(connection_id, step_index, scores_row)`: optional tap, called for every
-    stream-step (used by the tests; connection ids count accepted connections from 0).
+    refused with close code 1013).  `window_s`: the pump's round period -- it gathers whatever complete chunks have arrived and
+    steps at most once per window (real-time clients deliver one chunk per 80 ms, so a few ms gather a whole phase bin of them into
+    one step; 0 = step as soon as anything is there).  `on_scores(connection_id, step_index, scores_row)`: optional tap, called for
+    every stream-step (used by the tests; connection ids count accepted connections from 0).
 
     A connection gets its stream slot with its first audio message -- until then it has no device state to keep -- from a
     `SlotAllocator` keyed by the message's duration and arrival phase (`cohort_key`), see the module docstring.
 
-    Steps go through the host-fed pipeline (`oww_submit_masked` / `oww_collect`): while the kernels of step t run, the pump already
-    gathers and uploads step t+1 from page-locked buffers; at most two steps are in flight, scores are dispatched in step order."""
+    Data path.  The websocket handler of a connection moves each complete 1280-sample chunk straight into the connection's row of the
+    page-locked batch buffer that is currently being FILLED and flags the row; the pump never walks the connections -- a round is a
+    buffer swap, one `oww_submit_masked` and, when the scores are back, array operations over the participating rows (only rows with an
+    activation, or a tap, cost Python time).  Three buffers: one filling, up to two in flight.  A step is collected as soon as it has
+    been submitted while the GPU step is short against the window; when it is not (tens of thousands of streams: the upload of step t+1
+    should overlap the kernels of step t) the collect is left to the next round -- two steps in flight, scores in step order."""
+
+    N_BUF = 3
 
     def __init__(self, model, threshold: float = 0.5, window_s: float = 0.01, on_scores=None):
         self.model = model
         self.threshold = float(threshold)
         self.window_s = float(window_s)
         self.on_scores = on_scores
-        self.slots = SlotAllocator(model.n_streams, group=32, distance=cohort_distance)
+        S = model.n_streams
+        self.slots = SlotAllocator(S, group=32, distance=cohort_distance)
         self.clients: Dict[int, _Client] = {}          # by stream slot: the connections that have sent audio
         self.conns: Dict[int, _Client] = {}            # by connection id: every accepted connection
         self._next_cid = 0
@@ -243,15 +257,29 @@ class FanInServer:
         self._have_chunk: Optional[asyncio.Event] = None
         self._pump_task: Optional[asyncio.Task] = None
         self._gpu: Optional[_GpuWorker] = None
-        self._pcm = [model.engine.pinned_empty((model.n_streams, CHUNK)) for _ in range(2)]
+        self._pcm = [model.engine.pinned_empty((S, CHUNK)) for _ in range(self.N_BUF)]
         for b in self._pcm:
             b[:] = 0
+        self._on = [np.zeros(S, dtype=np.uint8) for _ in range(self.N_BUF)]        # rows of the buffer that carry a chunk
+        self._t_arr = [np.zeros(S, dtype=np.float64) for _ in range(self.N_BUF)]   # when that chunk became complete (metrics)
+        self._fill = 0                                 # the buffer the handlers are filling
+        self._n_fill = 0                               # rows flagged in it
+        self._more: set = set()                        # connections with a further complete chunk whose row of the filling buffer is taken
+        self._closing: set = set()                     # closed connections whose slot is still to be returned
+        self._inflight = np.zeros(S, dtype=np.int32)   # submitted, not yet dispatched steps per slot
+        self._k = np.zeros(S, dtype=np.int64)          # stream-steps dispatched per slot since it was handed out (the tap's step index)
+        self._step_s = 0.0                             # smoothed submit -> scores time of a step
         self.n_steps = 0              # batched steps taken
         self.n_stream_steps = 0       # sum over steps of the streams that took part
         self.n_dropped_messages = 0   # activation messages lost to clients that stopped reading (such clients are closed, see _post)
         self.n_range_recoveries = 0   # OWW_ERANGE events the pump recovered from (see _recover_range)
         self._last_recovery_step = -10**9
         self.send_timeout_s = 2.0     # deadline of one activation message / close handshake
+        # metrics (tools/serve_load.py): per stream-step, the time from the arrival of the message that completed the chunk to the
+        # dispatch of its scores; per batched step, [participants, submit start, submit returned, scores dispatched]
+        self.keep_metrics = False
+        self.latencies_s: List[np.ndarray] = []
+        self.step_log: List[list] = []
         self.failed: Optional[BaseException] = None      # set when the pump died of anything it cannot recover from
 
     # ---- aiohttp plumbing
@@ -279,6 +307,23 @@ class FanInServer:
         if self._gpu:
             self._gpu.stop()
 
+    def _stage(self, c: "_Client") -> None:
+        """Move the connection's oldest complete chunk into its row of the buffer being filled -- if that row is free; else the
+        connection waits in `_more` for the next buffer (one chunk per stream and step, in order)."""
+        if c.n_pending < CHUNK or c.slot is None:
+            return
+        f = self._fill
+        if self._on[f][c.slot]:
+            self._more.add(c)
+            return
+        c.pop_chunk(self._pcm[f][c.slot])
+        self._on[f][c.slot] = 1
+        self._t_arr[f][c.slot] = c.arrivals.popleft() if c.arrivals else 0.0
+        self._n_fill += 1
+        if c.n_pending >= CHUNK:
+            self._more.add(c)
+        self._have_chunk.set()
+
     async def handle(self, request):
         ws = web.WebSocketResponse()
         await ws.prepare(request)
@@ -291,6 +336,7 @@ class FanInServer:
         c = _Client(None, ws, cid=self._next_cid)
         self._next_cid += 1
         self.conns[c.cid] = c
+        loop = asyncio.get_running_loop()
         try:
             await ws.send_str(json.dumps({"loaded_models": list(self.model.labels)}))
             async for msg in ws:
@@ -311,26 +357,33 @@ class FanInServer:
                         # the first audio: place the connection next to the ones whose chunks fall due in the same rounds.  A slot
                         # handed to a new caller starts from Model()'s initial state, VAD history included; the job queue orders
                         # the reset after every step already submitted
-                        loop = asyncio.get_running_loop()
                         c.slot = self.slots.alloc(cohort_key(n / c.rate, loop.time()))
                         self.clients[c.slot] = c
+                        self._k[c.slot] = 0
                         await self._gpu.call(self.model.reset, [c.slot], reset_vad=bool(self.model.engine.has_vad))
                     x = np.frombuffer(msg.data, dtype="<i2", count=n)
                     if c.rate != 16000:                     # filtering runs on the default executor, not on the event loop
-                        x = await asyncio.get_running_loop().run_in_executor(None, to_16k, x, c.rate)
-                    c.push(x)
-                    if c.n_pending >= CHUNK:
-                        self._have_chunk.set()
+                        x = await loop.run_in_executor(None, to_16k, x, c.rate)
+                    c.push(x, loop.time())
+                    self._stage(c)
                 elif msg.type == WSMsgType.ERROR:
                     break
         finally:
             c.closed = True          # the pump scores what the client still delivered, then returns the slot to the pool
+            self._closing.add(c)
             self._have_chunk.set()
         return ws
 
     def _reap(self) -> None:
-        for c in [c for c in self.conns.values() if c.closed and c.n_pending < CHUNK and c.in_flight == 0]:
-            del self.conns[c.cid]
+        """Return the slots of closed connections once nothing of theirs is pending, staged or in flight."""
+        if not self._closing:
+            return
+        for c in list(self._closing):
+            if c.slot is not None and (c.n_pending >= CHUNK or self._inflight[c.slot] or self._on[self._fill][c.slot]):
+                continue
+            self._closing.discard(c)
+            self._more.discard(c)
+            self.conns.pop(c.cid, None)
             if c.slot is not None:
                 del self.clients[c.slot]
                 self.slots.release(c.slot)
@@ -350,6 +403,7 @@ class FanInServer:
             logging.getLogger(__name__).warning("client %s does not read its activation messages (%d queued): closing it", c.cid, len(c.outbox))
             c.closed = True
             c.outbox.clear()
+            self._closing.add(c)
             task = asyncio.get_running_loop().create_task(c.ws.close(code=1008, message=b"activation messages not read"))
             self._tasks.add(task)
             task.add_done_callback(self._tasks.discard)
@@ -368,7 +422,22 @@ class FanInServer:
                 await asyncio.wait_for(c.ws.send_str(text), timeout=self.send_timeout_s)
             except (ConnectionError, RuntimeError, asyncio.TimeoutError):
                 c.closed = True
+                self._closing.add(c)
                 c.outbox.clear()
+
+    def _step_now(self, pcm: np.ndarray, on: np.ndarray):
+        """(GPU thread) one whole step; also returns what it took THERE -- the event loop's own delays must not enter the decision
+        whether steps are long enough to be worth pipelining."""
+        import time
+        t0 = time.perf_counter()
+        self.model.engine.submit(pcm, on)
+        scores = self.model.engine.collect()
+        return scores, time.perf_counter() - t0
+
+    def _release_buffer(self, g: int) -> None:
+        idx = np.nonzero(self._on[g])[0]
+        self._inflight[idx] -= 1
+        self._on[g][:] = 0
 
     async def _recover_range(self, flying) -> None:
         """OWW_ERANGE is sticky per handle: one stream whose activations left the f16 range would stop scoring for everybody.  The
@@ -380,9 +449,11 @@ class FanInServer:
         self.n_range_recoveries += 1
         again = self.n_steps - self._last_recovery_step <= 8
         self._last_recovery_step = self.n_steps
+        n_flying = len(flying)
+
         def recover():
             eng = self.model.engine
-            for _ in range(len(flying)):
+            for _ in range(n_flying):
                 try:
                     eng.collect()
                 except Exception:
@@ -393,52 +464,99 @@ class FanInServer:
             self.model.reset(ids, reset_vad=bool(eng.has_vad))
             eng.range_status(clear=True)
         await self._gpu.call(recover)
-        for ready in flying:
-            for c in ready:
-                c.in_flight -= 1
+        for g in flying:
+            self._release_buffer(g)
         flying.clear()
+
+    def _dispatch(self, g: int, scores: np.ndarray, now: float) -> None:
+        """Scores of the step that was gathered in buffer g: taps, activation messages, counters -- array work except for the rows
+        that have something to say."""
+        on = self._on[g]
+        idx = np.nonzero(on)[0]
+        if self.keep_metrics:
+            self.latencies_s.append(now - self._t_arr[g][idx])
+        rows = scores[idx]
+        if self.on_scores is not None:
+            for s_, row in zip(idx.tolist(), rows):
+                c = self.clients.get(s_)
+                if c is not None:
+                    self.on_scores(c.cid, int(self._k[s_]), row)
+        hit = rows >= self.threshold
+        for j in np.nonzero(hit.any(axis=1))[0].tolist():
+            c = self.clients.get(int(idx[j]))
+            if c is not None and not c.closed:
+                self._post(c, json.dumps({"activations": [self.model.labels[l] for l in np.nonzero(hit[j])[0]]}))
+        self._k[idx] += 1
+        self._inflight[idx] -= 1
+        on[:] = 0                                      # the buffer may be filled again
 
     async def _pump(self) -> None:
         from ._lib import OwwRangeError
         keep = self.model._keep
-        flying: "collections.deque" = collections.deque()        # ready lists of the submitted, not yet collected steps
+        flying: "collections.deque" = collections.deque()        # buffers of the submitted, not yet collected steps
+        t_sub: "collections.deque" = collections.deque()
         try:
+            loop = asyncio.get_running_loop()
+            t_round = loop.time() - self.window_s
             while True:
                 if not flying:
                     await self._have_chunk.wait()
-                    if self.window_s > 0:
-                        await asyncio.sleep(self.window_s)
+                # rounds are paced: at least window_s between the starts of two gathers, whether or not a step is in flight -- without
+                # the pacing a busy server degenerates into thousands of tiny steps per second
+                wait = t_round + self.window_s - loop.time()
+                if wait > 0:
+                    await asyncio.sleep(wait)
+                t_round = loop.time()
                 self._have_chunk.clear()
                 self._reap()
-                ready = [c for c in self.clients.values() if c.n_pending >= CHUNK]
                 try:
-                    if ready:
-                        buf = self._pcm[self.n_steps % 2]                  # (its previous step, n_steps - 2, has been collected)
-                        on = np.zeros(self.model.n_streams, dtype=np.uint8)
-                        for c in ready:
-                            c.pop_chunk(buf[c.slot])
-                            c.in_flight += 1
-                            on[c.slot] = 1
-                        flying.append(ready)
-                        await self._gpu.call(self.model.engine.submit, buf, on)
+                    n = self._n_fill
+                    pipelined = self._step_s > 0.5 * self.window_s and self.window_s > 0
+                    if n:
+                        g = self._fill
+                        # the next buffer to fill: the one that is neither this one nor in flight (three buffers, at most two taken)
+                        self._fill = next(b for b in range(self.N_BUF) if b != g and b not in flying)
+                        self._n_fill = 0
+                        more, self._more = self._more, set()
+                        for c in more:                                     # connections with a backlog: their next chunk
+                            self._stage(c)
+                        self._inflight[np.nonzero(self._on[g])[0]] += 1
+                        t0 = loop.time()
                         self.n_steps += 1
-                        self.n_stream_steps += len(ready)
-                    if flying and (len(flying) == 2 or not ready):
+                        self.n_stream_steps += n
+                        if self.keep_metrics:
+                            self.step_log.append([n, t0, 0.0, 0.0])
+                        if (not pipelined or self.n_steps % 64 == 0) and not flying:
+                            # a step that is short against the window: submit and collect as ONE job of the GPU thread (every await
+                            # costs a trip through an event loop that is busy with thousands of sockets).  (Every 64th step of the
+                            # pipelined mode runs this way too: it is where the step time is measured.)
+                            scores, dt = await self._gpu.call(self._step_now, self._pcm[g], self._on[g])
+                            scores = scores[:, keep]
+                            now = loop.time()
+                            self._step_s = dt if self._step_s == 0.0 else 0.5 * self._step_s + 0.5 * dt
+                            if self.keep_metrics:
+                                self.step_log[self.n_steps - 1][2:] = [now, now]
+                            self._dispatch(g, scores, now)
+                        else:
+                            flying.append(g)
+                            t_sub.append(t0)
+                            await self._gpu.call(self.model.engine.submit, self._pcm[g], self._on[g])
+                            if self.keep_metrics:
+                                self.step_log[self.n_steps - 1][2] = loop.time()
+                    # collect: otherwise keep two steps in flight, so that the next upload overlaps this step's kernels
+                    while flying and (len(flying) == 2 or not n or not pipelined):
                         scores = (await self._gpu.call(self.model.engine.collect))[:, keep]
-                        for c in flying.popleft():
-                            c.in_flight -= 1
-                            row = scores[c.slot]
-                            if self.on_scores is not None:
-                                self.on_scores(c.cid, c.n_steps, row)
-                            c.n_steps += 1
-                            hits = [self.model.labels[j] for j in np.nonzero(row >= self.threshold)[0]]
-                            if hits and not c.closed:
-                                self._post(c, json.dumps({"activations": hits}))
-                        self._reap()
+                        now = loop.time()
+                        t_sub.popleft()
+                        if self.keep_metrics:
+                            self.step_log[self.n_steps - len(flying)][3] = now
+                        self._dispatch(flying.popleft(), scores, now)
+                    self._reap()
                 except OwwRangeError:
+                    t_sub.clear()
                     await self._recover_range(flying)
-                if any(c.n_pending >= CHUNK for c in self.clients.values()):
-                    self._have_chunk.set()          # somebody sent more than one chunk: go again without waiting for a message
+                if self._n_fill:
+                    self._have_chunk.set()          # something was staged meanwhile (a backlog, or messages that arrived during the step)
         except asyncio.CancelledError:
             raise
         except Exception as e:

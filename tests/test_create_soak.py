@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-@pytest.mark.parametrize("guard,cycles,thread_cycles", [("0", 500, 60), ("2", 500, 40), ("1", 60, 10)])
-def test_create_calibrate_destroy_soak(guard, cycles, thread_cycles, tmp_path):
+@pytest.mark.parametrize("guard,cycles,thread_cycles,max_streams", [("0", 500, 30, 131072), ("2", 500, 20, 4096), ("1", 40, 0, 4096)])
+def test_create_calibrate_destroy_soak(guard, cycles, thread_cycles, max_streams, tmp_path):
     env = dict(os.environ, OWW_GUARD_ALLOC=guard)
     err_path = tmp_path / "stderr.txt"                 # (guard mode prints one line per allocation)
     with open(err_path, "w") as ef:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_create.py"), "--cycles", str(cycles),
-                            "--thread-cycles", str(thread_cycles)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=ef,
-                           text=True, timeout=900)
+                            "--thread-cycles", str(thread_cycles), "--max-streams", str(max_streams)], cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=ef, text=True, timeout=900)
     tail = "\n".join(p.stdout.splitlines()[-6:])
     err_tail = ""
     if p.returncode != 0:
