@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <exception>
 #include <mutex>
 #include <new>
@@ -876,14 +877,12 @@ int do_reset(oww_ctx* h, const int* d_ids, int n, const float* d_featinit) {
 }
 
 template <class T>
-int dalloc(T** p, size_t n, bool zero = true, int line = __builtin_LINE()) {
+int dalloc(hipStream_t st, T** p, size_t n, bool zero = true, int line = __builtin_LINE()) {
     HIPCHK(dev_alloc(p, std::max<size_t>(n, 1) * sizeof(T), line));
-    if (zero) {
-        // the handle's streams are hipStreamNonBlocking: nothing orders them behind the legacy stream this fill runs on, so it has
-        // finished before the pointer is handed out (a kernel that met garbage frame counters would index out of its buffers)
-        HIPCHK(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
-        HIPCHK(hipStreamSynchronize(nullptr));
-    }
+    // the zero fill runs ON THE HANDLE'S STREAM: ordered in front of every kernel the handle will launch on it (its other streams are
+    // forked from it by events), and no host round trip per buffer -- a legacy-stream fill would need one, because nothing orders
+    // the handle's non-blocking streams behind the legacy stream (round 4: ~90 synchronisations per handle creation)
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), st));
     return 0;
 }
 
@@ -1174,6 +1173,15 @@ int park_state(oww_ctx* h, int n_streams, bool save) {
     return 0;
 }
 
+// OWW_COMMIT_TIMING=1: wall-clock of the phases of oww_commit on stderr (development aid; handle creation should stay in the tens of
+// milliseconds -- the reference constructs Model objects freely, utils.py:502-536)
+struct CommitClock {
+    bool on; double t0; const char* tag;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    explicit CommitClock(const char* tag_) : on(getenv("OWW_COMMIT_TIMING") != nullptr), t0(now()), tag(tag_) {}
+    void lap(const char* what) { if (on) { const double t = now(); fprintf(stderr, "[owwhip commit %s] %-28s %8.2f ms\n", tag, what, t - t0); t0 = t; } }
+};
+
 // ---- f16-split family: commit-time calibration and self-test against the exact-fp32 kernels -------------------------------------
 // The reference's graphs are fp32 (onnxruntime CPU kernels, utils.py:84-93): they have no range to leave.  The f16-split kernels
 // carry every activation as an f16 (hi, lo) pair, which is exact to 22 bits only inside the f16 exponent range, so oww_commit
@@ -1191,9 +1199,14 @@ constexpr int CAL_NP = 32, CAL_T = 16, CAL_MAX_BATCHES = 8;
 struct HxCalib {
     int nb = 1;                      // batches
     std::vector<int16_t> pcm;        // [nb][CAL_T][CAL_NP][1280]
+    int16_t* d_pcm = nullptr;        // the same on the device: uploaded once, read by the calibration run and by the self-test replay
     std::vector<float> ref_emb;      // [nb][CAL_T][CAL_NP][96]   exact-fp32 embeddings of the probe run
     std::vector<float> ref_raw;      // [nb][CAL_T][CAL_NP][NL]   exact-fp32 raw head outputs
     int NL = 0;
+    HxCalib() = default;
+    HxCalib(const HxCalib&) = delete;
+    HxCalib& operator=(const HxCalib&) = delete;
+    ~HxCalib() { if (d_pcm) (void)dev_free(d_pcm); }
 };
 
 void make_probe_pcm(std::vector<int16_t>& pcm, const std::vector<int16_t>& user /*[n_seg][CAL_T * 1280]*/) {
@@ -1205,19 +1218,26 @@ void make_probe_pcm(std::vector<int16_t>& pcm, const std::vector<int16_t>& user 
         for (int it = 0; it < CAL_T; ++it)
             memcpy(&pcm[((b * CAL_T + it) * CAL_NP + i) * OWW_CHUNK], &user[k * seg + (size_t)it * OWW_CHUNK], OWW_CHUNK * sizeof(int16_t));
     }
-    uint64_t st = 0x9E3779B97F4A7C15ull;
-    auto u01 = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((st >> 11) + 1) * (1.0 / 9007199254740993.0); };
-    const double amps[5] = {30, 300, 3000, 12000, 32767};
-    for (int i = 1; i < CAL_NP; ++i) {                 // stream 0: silence
-        const double amp = amps[i % 5];
-        for (int n = 0; n < CAL_T * OWW_CHUNK; ++n) {
-            double v;
-            if (i % 3 == 0) v = ((n / (8 << (i % 4))) % 2) ? amp : -amp;                        // square waves, 1 kHz .. 125 Hz
-            else v = std::nearbyint(amp * std::sqrt(-2.0 * std::log(u01())) * std::cos(6.283185307179586 * u01()));
-            v = std::min(32767.0, std::max(-32768.0, v));
-            pcm[((size_t)(n / OWW_CHUNK) * CAL_NP + i) * OWW_CHUNK + n % OWW_CHUNK] = (int16_t)v;
+    // batch 0 (the synthetic set) is the same for every handle: computed once per process (655,360 Gaussian samples in double)
+    static std::once_flag once;
+    static std::vector<int16_t> synth;
+    std::call_once(once, [] {
+        synth.assign((size_t)CAL_T * CAL_NP * OWW_CHUNK, 0);
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        auto u01 = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return ((st >> 11) + 1) * (1.0 / 9007199254740993.0); };
+        const double amps[5] = {30, 300, 3000, 12000, 32767};
+        for (int i = 1; i < CAL_NP; ++i) {                 // stream 0: silence
+            const double amp = amps[i % 5];
+            for (int n = 0; n < CAL_T * OWW_CHUNK; ++n) {
+                double v;
+                if (i % 3 == 0) v = ((n / (8 << (i % 4))) % 2) ? amp : -amp;                        // square waves, 1 kHz .. 125 Hz
+                else v = std::nearbyint(amp * std::sqrt(-2.0 * std::log(u01())) * std::cos(6.283185307179586 * u01()));
+                v = std::min(32767.0, std::max(-32768.0, v));
+                synth[((size_t)(n / OWW_CHUNK) * CAL_NP + i) * OWW_CHUNK + n % OWW_CHUNK] = (int16_t)v;
+            }
         }
-    }
+    });
+    memcpy(pcm.data(), synth.data(), synth.size() * sizeof(int16_t));
 }
 
 // one probe step on handle t: mel of the chunk (separate kernel), CNN, frame counters, optionally the heads
@@ -1245,7 +1265,8 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
     oww_ctx* t = nullptr;
     if (int rc = oww_create(&c2, &t)) return rc;
     int rc = 0;
-    unsigned* d_max = nullptr; int* d_off = nullptr; int16_t* d_chunk = nullptr;
+    unsigned* d_max = nullptr; int* d_off = nullptr; float* d_ref = nullptr;
+    CommitClock clk("calibrate");
     do {
         if ((rc = oww_load_mel(t, h->mel_blob.data(), h->mel_blob.size() * sizeof(float)))) break;
         if ((rc = oww_load_embedding(t, h->emb_blob.data(), h->emb_blob.size() * sizeof(float)))) break;
@@ -1259,13 +1280,18 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
         }
         if (rc) break;
         if ((rc = oww_commit(t))) break;
+        clk.lap("scratch fp32 handle");
         cal.NL = t->NL;
         int off[21]; off[0] = 0;
         for (int l = 0; l < 20; ++l) off[l + 1] = off[l] + kLayerOut[l][0] * kLayerOut[l][1] * kLayerOut[l][2];
+        // probe audio up once, results down once: the run in between is stream-ordered, without a host round trip per probe step
+        const size_t n_steps = (size_t)cal.nb * CAL_T, n_emb = n_steps * CAL_NP * 96, n_raw = n_steps * CAL_NP * std::max(t->NL, 1);
         if (dev_alloc(&d_max, 20 * sizeof(unsigned)) != hipSuccess || dev_alloc(&d_off, sizeof off) != hipSuccess ||
-            dev_alloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_commit: out of device memory (calibration)"); break; }
+            dev_alloc(&cal.d_pcm, cal.pcm.size() * sizeof(int16_t)) != hipSuccess ||
+            dev_alloc(&d_ref, (n_emb + n_raw) * sizeof(float)) != hipSuccess) { rc = fail(OWW_ENOMEM, "oww_commit: out of device memory (calibration)"); break; }
         if (hipMemsetAsync(d_max, 0, 20 * sizeof(unsigned), t->stream) != hipSuccess ||
-            copy_async(d_off, off, sizeof off, hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration setup failed"); break; }
+            copy_async(d_off, off, sizeof off, hipMemcpyHostToDevice, t->stream) != hipSuccess ||
+            copy_async(cal.d_pcm, cal.pcm.data(), cal.pcm.size() * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration setup failed"); break; }
         auto absmax = [&]() { hipLaunchKernelGGL(layer_absmax_kernel, dim3(20, CAL_NP), dim3(256), 0, t->stream, t->d_dbg, (size_t)DBG_FLOATS, d_off, d_max); };
         // (a) the all-ones mel history every stream starts from (utils.py:165): the handle sits in that steady state after its commit
         hipLaunchKernelGGL(fill_kernel, dim3(CAL_NP), dim3(256), 0, t->stream, t->d_mel, (size_t)CAL_NP * 256, 1.0f);
@@ -1278,16 +1304,17 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
             const int it = bt % CAL_T;
             if (it == 0 && bt > 0 && (rc = do_reset(t, nullptr, CAL_NP, nullptr))) break;
             if (getenv("OWW_DEBUG_CALIB")) { const hipError_t e = hipStreamSynchronize(t->stream); fprintf(stderr, "calibrate: probe step %d of %d (%s)\n", bt, cal.nb * CAL_T, hipGetErrorString(e)); }
-            // (the upload waits for the previous step: one staging buffer, stream-ordered copies from pageable memory are synchronous)
-            if (copy_async(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
-            if ((rc = probe_step(t, d_chunk, true))) break;
+            if ((rc = probe_step(t, cal.d_pcm + (size_t)bt * CAL_NP * OWW_CHUNK, true))) break;
             absmax();
-            if (copy_async(&cal.ref_emb[(size_t)bt * CAL_NP * 96], t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
-                (t->NL > 0 && copy_async(&cal.ref_raw[(size_t)bt * CAL_NP * t->NL], t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+            if (hipMemcpyAsync(d_ref + (size_t)bt * CAL_NP * 96, t->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToDevice, t->stream) != hipSuccess ||
+                (t->NL > 0 && hipMemcpyAsync(d_ref + n_emb + (size_t)bt * CAL_NP * t->NL, t->d_raw, (size_t)CAL_NP * t->NL * sizeof(float), hipMemcpyDeviceToDevice, t->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe gather failed"); break; }
         }
         if (rc) break;
         unsigned mx[20];
-        if (copy_async(mx, d_max, sizeof mx, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration run failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (copy_async(cal.ref_emb.data(), d_ref, n_emb * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+            (t->NL > 0 && copy_async(cal.ref_raw.data(), d_ref + n_emb, n_raw * sizeof(float), hipMemcpyDeviceToHost, t->stream) != hipSuccess) ||
+            copy_async(mx, d_max, sizeof mx, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: calibration run failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        clk.lap("probe run (exact fp32)");
         for (int l = 0; l < 20; ++l) {
             float m; memcpy(&m, &mx[l], 4);
             if (!std::isfinite(m)) { rc = fail(OWW_EINVAL, "oww_commit: layer %d of the embedding network produces non-finite activations in exact fp32 -- the weights are broken", l); break; }
@@ -1328,7 +1355,7 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
     } while (0);
     if (d_max) (void)dev_free(d_max);
     if (d_off) (void)dev_free(d_off);
-    if (d_chunk) (void)dev_free(d_chunk);
+    if (d_ref) (void)dev_free(d_ref);
     const std::string keep = g_err;
     // the scratch handle's whole life -- launches whose status nobody looked at, its frees -- must have left no HIP error behind
     const hipError_t e_run = hipStreamSynchronize(t->stream);
@@ -1336,6 +1363,7 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
     const hipError_t e_last = hipGetLastError();
     if (rc) g_err = keep;
     (void)hipSetDevice(h->cfg.device);
+    clk.lap("scratch handle destroyed");
     if (!rc && (e_run != hipSuccess || e_last != hipSuccess))
         rc = fail(OWW_EHIP, "oww_commit: the calibration handle left a HIP error behind (run: %s, last: %s)", hipGetErrorString(e_run), hipGetErrorString(e_last));
     return rc;
@@ -1343,22 +1371,25 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
 
 // replay of the probes on the handle's own (f16-split) kernels; leaves the first CAL_NP streams dirty -- the caller resets all state
 int selftest_hx(oww_ctx* h, const HxCalib& cal) {
-    int16_t* d_chunk = nullptr;
-    if (dev_alloc(&d_chunk, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t)) != hipSuccess) return fail(OWW_ENOMEM, "oww_commit: out of device memory (self-test)");
-    std::vector<float> emb((size_t)cal.nb * CAL_T * CAL_NP * 96), raw((size_t)cal.nb * CAL_T * CAL_NP * std::max(h->NL, 1));
+    const size_t n_steps = (size_t)cal.nb * CAL_T, n_emb = n_steps * CAL_NP * 96, n_raw = n_steps * CAL_NP * std::max(h->NL, 1);
+    float* d_out = nullptr;
+    if (!cal.d_pcm) return fail(OWW_ESTATE, "oww_commit: self-test without calibration probes");
+    if (dev_alloc(&d_out, (n_emb + n_raw) * sizeof(float)) != hipSuccess) return fail(OWW_ENOMEM, "oww_commit: out of device memory (self-test)");
+    std::vector<float> emb(n_emb), raw(n_raw);
     int rc = 0;
     float* saved_dbg = h->d_dbg; h->d_dbg = nullptr;
     for (int bt = 0; bt < cal.nb * CAL_T && !rc; ++bt) {
         if (bt % CAL_T == 0 && bt > 0 && (rc = do_reset(h, nullptr, CAL_NP, nullptr))) break;
         if (getenv("OWW_DEBUG_CALIB")) { const hipError_t e = hipStreamSynchronize(h->stream); fprintf(stderr, "self-test: probe step %d of %d (%s)\n", bt, cal.nb * CAL_T, hipGetErrorString(e)); }
-        if (copy_async(d_chunk, cal.pcm.data() + (size_t)bt * CAL_NP * OWW_CHUNK, (size_t)CAL_NP * OWW_CHUNK * sizeof(int16_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(OWW_EHIP, "oww_commit: probe upload failed"); break; }
-        if ((rc = probe_step(h, d_chunk, true))) break;
-        if (copy_async(&emb[(size_t)bt * CAL_NP * 96], h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            (h->NL > 0 && copy_async(&raw[(size_t)bt * CAL_NP * h->NL], h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe download failed"); break; }
+        if ((rc = probe_step(h, cal.d_pcm + (size_t)bt * CAL_NP * OWW_CHUNK, true))) break;
+        if (hipMemcpyAsync(d_out + (size_t)bt * CAL_NP * 96, h->d_emb, (size_t)CAL_NP * 96 * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+            (h->NL > 0 && hipMemcpyAsync(d_out + n_emb + (size_t)bt * CAL_NP * h->NL, h->d_raw, (size_t)CAL_NP * h->NL * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)) { rc = fail(OWW_EHIP, "oww_commit: probe gather failed"); break; }
     }
     h->d_dbg = saved_dbg;
-    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(OWW_EHIP, "oww_commit: self-test run failed: %s", hipGetErrorString(hipGetLastError()));
-    (void)dev_free(d_chunk);
+    if (!rc && (copy_async(emb.data(), d_out, n_emb * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                (h->NL > 0 && copy_async(raw.data(), d_out + n_emb, n_raw * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
+                hipStreamSynchronize(h->stream) != hipSuccess)) rc = fail(OWW_EHIP, "oww_commit: self-test run failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)dev_free(d_out);
     if (rc) return rc;
     float err = 0.f, ref = 0.f, serr = 0.f;
     bool finite = true;
@@ -1588,9 +1619,11 @@ int oww_commit(oww_ctx* h) {
     h->generic_hmax = hmax;
 
     // ---- f16-split family: per-layer activation scales from a calibration run on the exact-fp32 kernels (calibrate_hx) ----
+    CommitClock clk(h->hx ? "f16-split" : "family");
     HxCalib cal;
     if (h->hx) {
         if (int rc = calibrate_hx(h, cal)) return rc;
+        clk.lap("calibration (total)");
         if (getenv("OWW_DEBUG_CALIB"))
             for (int l = 0; l < 20; ++l) fprintf(stderr, "calib layer %2d: max|a| %-12.5g e_in %4d e_out %4d\n", l, h->hx_absmax[l], h->hx_ein[l], h->hx_e[l]);
     }
@@ -1814,6 +1847,7 @@ int oww_commit(oww_ctx* h) {
         o_vwd = hb.add(q, 64); q += 64;
         h->vad_bd = *q;
     }
+    clk.lap("weight packing (host)");
     HIPCHK(dev_alloc(&h->d_w, hb.data.size() * sizeof(float)));
     HIPCHK(copy_sync(h->d_w, hb.data.data(), hb.data.size() * sizeof(float), hipMemcpyHostToDevice));
     h->d_hann = h->d_w + o_hann; h->d_mstart = reinterpret_cast<const int*>(h->d_w + o_start); h->d_taps = h->d_w + o_taps;
@@ -1867,46 +1901,47 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(hipHostGetDevicePointer(&dp, h->h_range, 0));
         h->d_range = (int*)dp;
     }
+    clk.lap("weight upload");
     // ---- state ----
     const size_t SP = h->Spad;
     for (int a = 0; a < N_STATE; ++a) {
-        if (int rc = dalloc(&h->d_state[a], SP * h->state_len[a])) return rc;
-        if (int rc = dalloc(&h->d_tmpl[a], (size_t)h->state_len[a] * (h->rr ? kStateSpgRr[a] : 1))) return rc;
+        if (int rc = dalloc(h->stream, &h->d_state[a], SP * h->state_len[a])) return rc;
+        if (int rc = dalloc(h->stream, &h->d_tmpl[a], (size_t)h->state_len[a] * (h->rr ? kStateSpgRr[a] : 1))) return rc;
     }
     const int* xlen = h->rr ? kXLenRr : kXLenLds;
-    if (int rc = dalloc(&h->d_xA, SP * xlen[0])) return rc;
-    if (int rc = dalloc(&h->d_xB, SP * xlen[1])) return rc;
-    if (int rc = dalloc(&h->d_xC, SP * xlen[2])) return rc;
-    if (int rc = dalloc(&h->d_xD, SP * xlen[3])) return rc;
-    if (int rc = dalloc(&h->d_mel, SP * 8 * h->kmax * 32)) return rc;
-    if (int rc = dalloc(&h->d_feat, SP * h->TR * 96)) return rc;
-    if (int rc = dalloc(&h->d_emb, SP * 96)) return rc;
-    if (int rc = dalloc(&h->d_raw, SP * std::max(h->NL, 1))) return rc;
-    if (int rc = dalloc(&h->d_scores, SP * std::max(h->NL, 1))) return rc;
-    if (int rc = dalloc(&h->d_ring, SP * std::max(h->NL, 1) * OWW_SCORE_RING)) return rc;
-    if (int rc = dalloc(&h->d_featinit, (size_t)h->TR * 96)) return rc;
-    if (int rc = dalloc(&h->d_nfeat, SP)) return rc;
-    if (int rc = dalloc(&h->d_npred, SP)) return rc;
-    if (int rc = dalloc(&h->d_vadring, SP * 8)) return rc;
-    if (int rc = dalloc(&h->d_nvad, SP)) return rc;
-    if (int rc = dalloc(&h->d_vadin, SP)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_xA, SP * xlen[0])) return rc;
+    if (int rc = dalloc(h->stream, &h->d_xB, SP * xlen[1])) return rc;
+    if (int rc = dalloc(h->stream, &h->d_xC, SP * xlen[2])) return rc;
+    if (int rc = dalloc(h->stream, &h->d_xD, SP * xlen[3])) return rc;
+    if (int rc = dalloc(h->stream, &h->d_mel, SP * 8 * h->kmax * 32)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_feat, SP * h->TR * 96)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_emb, SP * 96)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_raw, SP * std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(h->stream, &h->d_scores, SP * std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(h->stream, &h->d_ring, SP * std::max(h->NL, 1) * OWW_SCORE_RING)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_featinit, (size_t)h->TR * 96)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_nfeat, SP)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_npred, SP)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_vadring, SP * 8)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_nvad, SP)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_vadin, SP)) return rc;
     if (h->vad) {
         const size_t G = (SP + 15) / 16;
-        if (int rc = dalloc(&h->d_vadx, G * 4 * 1024)) return rc;
-        if (int rc = dalloc(&h->d_vadhc, G * 4096)) return rc;
-        if (int rc = dalloc(&h->d_vadlast, SP)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_vadx, G * 4 * 1024)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_vadhc, G * 4096)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_vadlast, SP)) return rc;
         if (int rc = set_lds(owv::vad_front_kernel, owv::V_LDS_BYTES)) return rc;
     }
-    if (int rc = dalloc(&h->d_tail, SP * 480)) return rc;
-    if (int rc = dalloc(&h->d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax)) return rc;
-    if (int rc = dalloc(&h->d_patience, (size_t)std::max(h->NL, 1))) return rc;
-    if (int rc = dalloc(&h->d_threshold, (size_t)std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(h->stream, &h->d_tail, SP * 480)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_pcm, (size_t)h->S * OWW_CHUNK * h->kmax)) return rc;
+    if (int rc = dalloc(h->stream, &h->d_patience, (size_t)std::max(h->NL, 1))) return rc;
+    if (int rc = dalloc(h->stream, &h->d_threshold, (size_t)std::max(h->NL, 1))) return rc;
     {
         std::vector<float> nanv(std::max(h->NL, 1), NAN);
-        HIPCHK(copy_sync(h->d_threshold, nanv.data(), nanv.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(copy_async(h->d_threshold, nanv.data(), nanv.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));   // (behind the buffer's zero fill, same stream)
     }
-    if (h->cfg.debug_layers) if (int rc = dalloc(&h->d_dbg, SP * DBG_FLOATS)) return rc;
-    if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(&h->d_prof, (size_t)4 * 256)) return rc; }
+    if (h->cfg.debug_layers) if (int rc = dalloc(h->stream, &h->d_dbg, SP * DBG_FLOATS)) return rc;
+    if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(h->stream, &h->d_prof, (size_t)4 * 256)) return rc; }
     if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
     // block-pipelined step: OFF by default.  Measured with the round-3 kernels at 131,072 x 3 (same box, OWW_BLOCKS = 1 / 2 / 3 / 4):
@@ -1943,6 +1978,7 @@ int oww_commit(oww_ctx* h) {
 
     // ---- reset state = what an all-ones mel history leaves behind (utils.py:165 melspectrogram_buffer =
     //      ones((76,32))): run the incremental CNN on ones rows until the zero start is flushed out ----
+    clk.lap("state allocation");
     {
         const int warm = std::min<int>(32, (int)SP);
         hipLaunchKernelGGL(fill_kernel, dim3((warm * 256 + 255) / 256), dim3(256), 0, h->stream, h->d_mel, (size_t)warm * 256, 1.0f);
@@ -1957,6 +1993,7 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(hipMemsetAsync(h->d_emb, 0, SP * 96 * sizeof(float), h->stream));
         if (int rc = do_reset(h, nullptr, (int)SP, nullptr)) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
+        clk.lap("warm-up + reset");
         // the warm-up already drove the network with an all-ones mel history: weights that overflow the f16 range there are refused now
         if (int rc = range_check(h, "oww_commit")) return rc;
         // f16-split family: replay the calibration probes and hold the result to the exact-fp32 run (refuses weights the split loses)
@@ -1967,6 +2004,7 @@ int oww_commit(oww_ctx* h) {
             HIPCHK(hipMemsetAsync(h->d_raw, 0, SP * std::max(h->NL, 1) * sizeof(float), h->stream));
             if (int rc = do_reset(h, nullptr, (int)SP, nullptr)) return rc;
             HIPCHK(hipStreamSynchronize(h->stream));
+            clk.lap("self-test replay + reset");
         }
     }
     h->committed = true;
@@ -2221,10 +2259,10 @@ int oww_set_verifier(oww_ctx* h, int32_t label, const float* w, int32_t n_w, flo
         int maxT = 1;
         for (const auto& hh : h->heads) maxT = std::max(maxT, hh.T);
         h->ver_stride = maxT * OWW_EMB_DIM;
-        if (int rc = dalloc(&h->d_verw, (size_t)h->NL * h->ver_stride)) return rc;
-        if (int rc = dalloc(&h->d_verb, (size_t)h->NL)) return rc;
-        if (int rc = dalloc(&h->d_verthr, (size_t)h->NL)) return rc;
-        if (int rc = dalloc(&h->d_verT, (size_t)h->NL)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_verw, (size_t)h->NL * h->ver_stride)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_verb, (size_t)h->NL)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_verthr, (size_t)h->NL)) return rc;
+        if (int rc = dalloc(h->stream, &h->d_verT, (size_t)h->NL)) return rc;
         h->ver_T.assign(h->NL, 0);
     }
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -576,7 +576,7 @@ class FanInServer:
 
 def main(argv=None) -> None:
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--streams", type=int, default=1024, help="client slots (= streams of the batched model)")
+    ap.add_argument("--streams", type=int, default=1024, help="client slots (= streams of the batched model) per worker process")
     ap.add_argument("--models", nargs="+", default=["alexa"])
     ap.add_argument("--weights", default=None, help='"synthetic" for random-init weights; default: the .onnx files next to the package')
     ap.add_argument("--threshold", type=float, default=0.5)
@@ -586,10 +586,31 @@ def main(argv=None) -> None:
     ap.add_argument("--use-mfma", type=int, default=None, choices=(3, 1),
                     help="kernel family (default: the fp16-split family 3, and the exact-fp32 family 1 for weights family 3 refuses at "
                          "commit); the fan-in server steps through oww_submit_masked, which both provide")
+    ap.add_argument("--workers", type=int, default=1,
+                    help="server processes sharing the port (SO_REUSEPORT; the kernel spreads new connections over them), each with its own "
+                         "event loop and its own handle on the GPU: one Python event loop carries about two thousand real-time clients "
+                         "(tools/serve_load.py), the GPU a thousand times that -- the edge scales over host cores, not over GPUs")
+    ap.add_argument("--reuse-port", action="store_true", help="(set for the worker processes of --workers)")
     a = ap.parse_args(argv)
+    if a.workers > 1:
+        import subprocess
+        import sys
+        cmd = [sys.executable, "-m", "openwakeword_amd.serve", "--streams", str(a.streams), "--models", *a.models, "--threshold", str(a.threshold),
+               "--host", a.host, "--port", str(a.port), "--device", str(a.device), "--workers", "1", "--reuse-port"]
+        cmd += ["--weights", a.weights] if a.weights else []
+        cmd += ["--use-mfma", str(a.use_mfma)] if a.use_mfma is not None else []
+        procs = [subprocess.Popen(cmd) for _ in range(a.workers)]
+        try:
+            for p in procs:
+                p.wait()
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        return
     from .model import BatchedModel
     model = BatchedModel(a.streams, a.models, weights=a.weights, device=a.device, use_mfma=a.use_mfma)
-    web.run_app(FanInServer(model, threshold=a.threshold).app(), host=a.host, port=a.port)
+    web.run_app(FanInServer(model, threshold=a.threshold).app(), host=a.host, port=a.port, reuse_port=True if a.reuse_port else None)
 
 
 if __name__ == "__main__":

@@ -158,43 +158,18 @@ def pct(a, q):
     return float(np.percentile(a, q)) if len(a) else None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--clients", type=int, default=8192)
-    ap.add_argument("--slots", type=int, default=0, help="stream slots of the server (default: clients)")
-    ap.add_argument("--seconds", type=float, default=12.0)
-    ap.add_argument("--procs", type=int, default=8)
-    ap.add_argument("--port", type=int, default=0)
-    ap.add_argument("--sample", type=int, default=24, help="clients whose tapped scores are held to a private engine")
-    ap.add_argument("--window-ms", type=float, default=10.0)
-    ap.add_argument("--out", default="")
-    ap.add_argument("--dry-run", action="store_true", help="no GPU: a stand-in model (development aid for the socket plumbing of this tool)")
-    ap.add_argument("--periods-ms", default="40,80,160", help="audio per client message (clients cycle through the list)")
-    ap.add_argument("--threshold", type=float, default=0.0, help="activation threshold; 0 = every stream-step answers (needed for the "
-                    "client-side latency: the k-th answer belongs to the k-th chunk)")
-    a = ap.parse_args()
-    PERIODS[:] = [float(v) * 1e-3 for v in a.periods_ms.split(",")]
-    try:
-        soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
-        resource.setrlimit(resource.RLIMIT_NOFILE, (hard, hard))
-    except Exception:
-        hard = -1
+def serve_until(a, slots, t_end_wall, reuse_port):
+    """Run one FanInServer in this process until `t_end_wall` (or until `a._done` is set by the in-process driver); returns its metrics."""
     import socket
     from aiohttp import web
     from openwakeword_amd import serve, weights as W
     from openwakeword_amd.engine import StreamEngine
     from openwakeword_amd.model import BatchedModel
-
     heads = {n: W.synthetic_head(n, seed=11 + i) for i, n in enumerate(HEADS)}
     emb = W.synthetic_embedding(seed=3)
-    slots = a.slots or a.clients
-    if a.dry_run:
-        model = _FakeModel(slots)
-    else:
-        model = BatchedModel(slots, HEADS, weights={"heads": heads, "embedding": emb})
-    sample = set(range(0, a.clients, max(1, a.clients // a.sample)))
+    model = _FakeModel(slots) if a.dry_run else BatchedModel(slots, HEADS, weights={"heads": heads, "embedding": emb})
+    step = max(1, a.clients // a.sample)
     tap, who = {}, {}                                     # connection id -> rows; connection id -> client number
-
     orig_push = serve._Client.push
 
     def push(self, x, now=0.0):                           # (tool-level hook: learn which client a connection is from its first samples)
@@ -204,48 +179,28 @@ def main():
     serve._Client.push = push
 
     def on_scores(cid, k, row):
-        if who.get(cid) in sample:
+        g = who.get(cid)
+        if g is not None and g % step == 0:
             tap.setdefault(cid, []).append(row.copy())
     srv = serve.FanInServer(model, threshold=a.threshold, window_s=a.window_ms * 1e-3, on_scores=on_scores)
     srv.keep_metrics = True
-    if not a.port:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            a.port = sk.getsockname()[1]
 
     async def run():
         runner = web.AppRunner(srv.app())
         await runner.setup()
-        site = web.TCPSite(runner, "127.0.0.1", a.port, backlog=65535)
+        site = web.TCPSite(runner, "127.0.0.1", a.port, backlog=65535, reuse_port=reuse_port or None)
         await site.start()
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        t0_wall = time.time() + 6.0 + a.clients / 4000.0   # connections are made before the common start
-        ids = [list(range(p, a.clients, a.procs)) for p in range(a.procs)]
-        procs = [ctx.Process(target=client_proc, args=(ids[p], a.port, a.seconds, t0_wall, q, list(PERIODS)), daemon=True) for p in range(a.procs)]
-        for p in procs:
-            p.start()
-        results = []
-        loop = asyncio.get_running_loop()
-        t_begin = time.time()
-        while len(results) < a.procs and time.time() - t_begin < a.seconds + 120:
-            try:
-                results.append(await loop.run_in_executor(None, q.get, True, 1.0))
-            except Exception:
-                pass
+        if a.ready_file:
+            open(a.ready_file, "w").write("ready\n")
+        while time.time() < t_end_wall and not getattr(a, "_done", False):
+            await asyncio.sleep(0.25)
         backlog = sum(c.n_pending // 1280 for c in srv.conns.values())
         n_conn = srv._next_cid
         await runner.cleanup()
-        return results, backlog, n_conn
-
-    t_start = time.time()
-    results, backlog, n_conn = asyncio.run(run())
-    wall = time.time() - t_start
-    lat_srv = np.concatenate(srv.latencies_s) if srv.latencies_s else np.zeros(0)
+        return backlog, n_conn
+    backlog, n_conn = asyncio.run(run())
+    lat = np.concatenate(srv.latencies_s) if srv.latencies_s else np.zeros(0)
     steps = np.asarray(srv.step_log, np.float64).reshape(-1, 4)
-    done = steps[steps[:, 3] > 0]
-    e2e = np.concatenate([r["lat"] for r in results]) if results else np.zeros(0, np.float32)
-    # ---- bit-exactness of the sampled clients
     pool = noise_pool()
     checked, worst, equal = 0, 0.0, True
     for cid, rows in ({} if a.dry_run else tap).items():
@@ -256,26 +211,125 @@ def main():
         e = StreamEngine(1, heads, emb)
         want = np.stack([e.step(x[None, k * 1280:(k + 1) * 1280])[0] for k in range(min(len(rows), x.size // 1280))]) if rows else np.zeros((0, 3))
         e.close()
-        got = np.stack(rows)[:len(want)][:, :want.shape[1]] if rows else want
+        got = np.stack(rows)[:len(want)] if rows else want
         checked += 1
         if len(want):
             worst = max(worst, float(np.abs(got - want[:, model._keep]).max()))
             equal = equal and bool(np.array_equal(got, want[:, model._keep]))
     model.close()
+    return {"lat": lat.astype(np.float32), "steps": steps, "n_steps": int(srv.n_steps), "n_stream_steps": int(srv.n_stream_steps),
+            "backlog": int(backlog), "n_conn": int(n_conn), "dropped": int(srv.n_dropped_messages), "recoveries": int(srv.n_range_recoveries),
+            "checked": checked, "equal": equal, "worst": worst, "slots": slots}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clients", type=int, default=8192)
+    ap.add_argument("--slots", type=int, default=0, help="stream slots per server process (default: clients, or 1.5 x its share + 64)")
+    ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--procs", type=int, default=8, help="client processes")
+    ap.add_argument("--server-procs", type=int, default=1, help="server processes sharing the port (SO_REUSEPORT), each with its own handle on "
+                    "the GPU: how `python -m openwakeword_amd.serve --workers N` scales the Python edge over host cores")
+    ap.add_argument("--port", type=int, default=0)
+    ap.add_argument("--sample", type=int, default=24, help="clients whose tapped scores are held to a private engine")
+    ap.add_argument("--window-ms", type=float, default=10.0)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: a stand-in model (development aid for the socket plumbing of this tool)")
+    ap.add_argument("--periods-ms", default="40,80,160", help="audio per client message (clients cycle through the list)")
+    ap.add_argument("--threshold", type=float, default=0.0, help="activation threshold; 0 = every stream-step answers (needed for the "
+                    "client-side latency: the k-th answer belongs to the k-th chunk)")
+    ap.add_argument("--role", default="driver", choices=("driver", "server"), help="(internal) server = one worker process of --server-procs")
+    ap.add_argument("--t-end", type=float, default=0.0, help="(internal) wall-clock time at which a server worker stops")
+    ap.add_argument("--ready-file", default="")
+    ap.add_argument("--metrics-out", default="")
+    a = ap.parse_args()
+    PERIODS[:] = [float(v) * 1e-3 for v in a.periods_ms.split(",")]
+    try:
+        soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+        resource.setrlimit(resource.RLIMIT_NOFILE, (hard, hard))
+    except Exception:
+        hard = -1
+    if a.role == "server":
+        m = serve_until(a, a.slots, a.t_end, True)
+        np.savez(a.metrics_out, **{k: np.asarray(v) for k, v in m.items()})
+        return
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+    if not a.port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            a.port = sk.getsockname()[1]
+    n_srv = max(1, a.server_procs)
+    slots = a.slots or (a.clients if n_srv == 1 else int(1.5 * a.clients / n_srv) + 64)
+    t_start = time.time()
+    t0_wall = time.time() + 8.0 + a.clients / 3000.0 + (14.0 if n_srv > 1 and not a.dry_run else 0.0)   # connections (and worker start-up) before the common start
+    t_end_wall = t0_wall + a.seconds + 3.0
+    tmp = tempfile.mkdtemp(prefix="serve_load_")
+    workers, metrics = [], []
+    if n_srv > 1:
+        for w in range(n_srv):
+            cmd = [sys.executable, os.path.abspath(__file__), "--role", "server", "--clients", str(a.clients), "--slots", str(slots),
+                   "--seconds", str(a.seconds), "--port", str(a.port), "--sample", str(a.sample), "--window-ms", str(a.window_ms),
+                   "--periods-ms", a.periods_ms, "--threshold", str(a.threshold), "--t-end", str(t_end_wall),
+                   "--ready-file", os.path.join(tmp, f"ready{w}"), "--metrics-out", os.path.join(tmp, f"m{w}.npz")] + (["--dry-run"] if a.dry_run else [])
+            workers.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, f"w{w}.err"), "w")))
+        while not all(os.path.exists(os.path.join(tmp, f"ready{w}")) for w in range(n_srv)):
+            if any(p.poll() is not None for p in workers) or time.time() > t0_wall - 2.0:
+                errs = "".join(open(os.path.join(tmp, f"w{w}.err")).read()[-600:] for w in range(n_srv))
+                raise SystemExit(f"server workers did not come up in time:\n{errs}")
+            time.sleep(0.2)
+    else:
+        a.ready_file = ""
+        box = {}
+        th = threading.Thread(target=lambda: box.update(m=serve_until(a, slots, t_end_wall, False)), daemon=True)
+        th.start()
+        time.sleep(0.5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ids = [list(range(p, a.clients, a.procs)) for p in range(a.procs)]
+    procs = [ctx.Process(target=client_proc, args=(ids[p], a.port, a.seconds, t0_wall, q, list(PERIODS)), daemon=True) for p in range(a.procs)]
+    for p in procs:
+        p.start()
+    results = []
+    while len(results) < a.procs and time.time() < t_end_wall + 60:
+        try:
+            results.append(q.get(True, 1.0))
+        except Exception:
+            pass
+    if n_srv > 1:
+        for w, p in enumerate(workers):
+            p.wait(timeout=300)
+            z = np.load(os.path.join(tmp, f"m{w}.npz"), allow_pickle=True)
+            metrics.append({k: z[k] for k in z.files})
+    else:
+        a._done = True
+        th.join(timeout=300)
+        metrics.append({k: np.asarray(v) for k, v in box["m"].items()})
+    wall = time.time() - t_start
+    lat_srv = np.concatenate([m["lat"] for m in metrics]).astype(np.float64)
+    steps = np.concatenate([m["steps"].reshape(-1, 4) for m in metrics])
+    done = steps[steps[:, 3] > 0]
+    e2e = np.concatenate([r["lat"] for r in results]) if results else np.zeros(0, np.float32)
+    n_stream_steps = int(sum(int(m["n_stream_steps"]) for m in metrics))
+    period = np.concatenate([np.diff(m["steps"].reshape(-1, 4)[:, 1]) for m in metrics if m["steps"].size > 4]) if metrics else np.zeros(0)
     out = {
         "what": "FanInServer under real websocket clients (tools/serve_load.py): reference wire protocol, 127.0.0.1, clients in separate processes",
-        "clients": a.clients, "connections_accepted": n_conn, "client_processes": a.procs, "seconds": a.seconds, "slots": slots,
+        "clients": a.clients, "connections_accepted": int(sum(int(m["n_conn"]) for m in metrics)), "connections_per_server": [int(m["n_conn"]) for m in metrics],
+        "server_processes": n_srv, "slots_per_server": slots,
+        "client_processes": a.procs, "seconds": a.seconds,
         "message_periods_ms": [int(p * 1e3) for p in PERIODS], "duty": "talk spurts / pauses of 0.8-2.4 s, ~50 %", "window_ms": a.window_ms,
         "cpu_quota": __import__("oracle.parity_sample", fromlist=["effective_cpus"]).effective_cpus() if os.path.isdir(os.path.join(ROOT, "oracle")) else None,
         "nofile_limit": hard, "wall_s": round(wall, 1),
-        "pump": {"batched_steps": int(srv.n_steps), "stream_steps": int(srv.n_stream_steps),
+        "pump": {"batched_steps": int(sum(int(m["n_steps"]) for m in metrics)), "stream_steps": n_stream_steps,
                  "participants_per_step_mean": round(float(steps[:, 0].mean()), 1) if len(steps) else None,
                  "participation_mean": round(float(steps[:, 0].mean()) / slots, 4) if len(steps) else None,
-                 "submit_call_ms_p50": round(1e3 * pct(steps[:, 2] - steps[:, 1], 50), 3) if len(steps) else None,
-                 "submit_to_scores_ms_p50": round(1e3 * pct(done[:, 3] - done[:, 1], 50), 3) if len(done) else None,
-                 "submit_to_scores_ms_p99": round(1e3 * pct(done[:, 3] - done[:, 1], 99), 3) if len(done) else None,
-                 "pump_period_ms_p50": round(1e3 * pct(np.diff(steps[:, 1]), 50), 3) if len(steps) > 1 else None,
-                 "stream_steps_per_s": round(srv.n_stream_steps / a.seconds, 1)},
+                 "step_ms_p50": round(1e3 * pct(done[:, 3] - done[:, 1], 50), 3) if len(done) else None,
+                 "step_ms_p99": round(1e3 * pct(done[:, 3] - done[:, 1], 99), 3) if len(done) else None,
+                 "step_what": "submit -> scores dispatched, as the event loop sees it (one GPU-thread job per step while steps are short)",
+                 "pump_period_ms_p50": round(1e3 * pct(period, 50), 3) if len(period) else None,
+                 "stream_steps_per_s": round(n_stream_steps / a.seconds, 1)},
         "server_latency_ms": {"what": "arrival of the message that completed a chunk -> its scores dispatched", "n": int(lat_srv.size),
                               "p50": round(1e3 * pct(lat_srv, 50), 2) if lat_srv.size else None,
                               "p99": round(1e3 * pct(lat_srv, 99), 2) if lat_srv.size else None,
@@ -289,8 +343,10 @@ def main():
         "client_send_lateness_max_ms": round(1e3 * max([r["late"] for r in results] or [0.0]), 1),
         "client_errors": int(sum(r["n_errors"] for r in results)), "client_error_samples": [e for r in results for e in r["errors"]][:5],
         "client_processes_reporting": len(results),
-        "backlog_chunks_at_end": int(backlog), "dropped_messages": int(srv.n_dropped_messages), "range_recoveries": int(srv.n_range_recoveries),
-        "bit_exact_sample": {"clients_checked": checked, "equal": equal, "max_abs_diff": worst},
+        "backlog_chunks_at_end": int(sum(int(m["backlog"]) for m in metrics)), "dropped_messages": int(sum(int(m["dropped"]) for m in metrics)),
+        "range_recoveries": int(sum(int(m["recoveries"]) for m in metrics)),
+        "bit_exact_sample": {"clients_checked": int(sum(int(m["checked"]) for m in metrics)), "equal": bool(all(bool(m["equal"]) for m in metrics)),
+                             "max_abs_diff": float(max(float(m["worst"]) for m in metrics))},
     }
     line = json.dumps(out)
     print(line)
