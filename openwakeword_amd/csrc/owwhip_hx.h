@@ -805,7 +805,7 @@ __device__ __forceinline__ void load_tile_lds(f32x4 (&t)[NCT], const float* base
 }
 
 template <class C, bool LAST, bool DBG, int WG = OWH_WG, int NS = 2>
-__global__ __launch_bounds__(64 * WG, (NS == 3 && C::WPS > 2 ? 2 : C::WPS)) void hstage_kernel(owr::RStageParams p) {
+__global__ __launch_bounds__(64 * WG, (DBG ? 1 : (NS == 3 && C::WPS > 2 ? 2 : C::WPS))) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
@@ -1145,8 +1145,10 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
     const float* w1s = sW1 + z;
     const float* w2s = sW2 + z;
     const float* bn = sbn0 + z;
-    unsigned* hm = reinterpret_cast<unsigned*>(p.hist_mel) + (size_t)s * 64;           // (hi | lo << 16) of the last two mel rows
-    unsigned* h2 = reinterpret_cast<unsigned*>(p.hist2) + (size_t)s * (2 * 2 * 8 * 64);   // [row 2][parity 2][dword 8: 3 hi, 3 lo, 2 unused][64]
+    // (wave-uniform bases in SGPRs, lane offsets in one VGPR: as 64-bit per-lane pointers their loop-invariant parts were hoisted out of
+    //  the stream loop and spilled -- the only scratch traffic of the default step)
+    unsigned* hm = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(uniform_ptr(p.hist_mel + (size_t)s * 64)));           // (hi | lo << 16) of the last two mel rows
+    unsigned* h2 = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(uniform_ptr(p.hist2 + (size_t)s * (2 * 2 * 8 * 64))));   // [row 2][parity 2][dword 8: 3 hi, 3 lo, 2 unused][64]
     {
         const unsigned w = hm[lane];
         const int o = (lane >> 5) * sa::RS + 1 + (lane & 31);
@@ -1161,7 +1163,8 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
     }
     int go[8];
     {
-        const u32x4 g0 = *reinterpret_cast<const u32x4*>(gtab + z + lane * 8), g1 = *reinterpret_cast<const u32x4*>(gtab + z + lane * 8 + 4);
+        const int lz = (lane + z) * 8;             // (iteration-local: not hoisted and kept alive across the mel phase)
+        const u32x4 g0 = *reinterpret_cast<const u32x4*>(gtab + lz), g1 = *reinterpret_cast<const u32x4*>(gtab + lz + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { go[q] = (int)g0[q]; go[4 + q] = (int)g1[q]; }
     }
@@ -1392,7 +1395,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
 }
 
 template <bool DBG>
-__global__ __launch_bounds__(256, OWH_WPS_A) void hstageA_kernel(owr::RAParams p) {
+__global__ __launch_bounds__(256, DBG ? 1 : OWH_WPS_A) void hstageA_kernel(owr::RAParams p) {
     using namespace owr;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

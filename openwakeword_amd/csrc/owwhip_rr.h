@@ -502,7 +502,9 @@ __device__ __forceinline__ void pool_store(const f32x4 (&y)[C::RP][C::NCT], floa
 }
 
 template <class C, bool LAST, bool DBG>
-__global__ __launch_bounds__(256, C::WPS) void rstage_kernel(RStageParams p) {
+// (DBG: the per-layer dumps of tests and of oww_commit's calibration run keep every layer's tiles alive; at the production occupancy
+//  they spilled 100+ bytes per lane into scratch -- a debug launch is a 32-stream grid, so it simply takes the whole register file)
+__global__ __launch_bounds__(256, DBG ? 1 : C::WPS) void rstage_kernel(RStageParams p) {
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::R, RP = C::RP, F = C::F;
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
     constexpr int NBA = 3 * NCTI, NB = 3 * NCT;             // 1 KB blocks per chunk: first layer / other layers
@@ -657,7 +659,7 @@ struct RAParams {
 #endif
 
 template <bool DBG>
-__global__ __launch_bounds__(256, OWR_WPS_A) void rstageA_kernel(RAParams p) {
+__global__ __launch_bounds__(256, DBG ? 1 : OWR_WPS_A) void rstageA_kernel(RAParams p) {
     const int lane = threadIdx.x & 63, pos = lane & 15, j = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
