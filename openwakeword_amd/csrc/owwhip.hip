@@ -463,8 +463,6 @@ struct oww_ctx {
     std::vector<int> generic_nets;    // indices into nets (with verifier right after its primary)
     NetDesc* d_generic = nullptr;
     int generic_hmax = 0;
-    float* d_scratch = nullptr;
-    size_t scratch_streams = 0;
     // state
     float* d_state[N_STATE] = {};
     float* d_tmpl[N_STATE] = {};
@@ -748,16 +746,6 @@ int run_cnn(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
     return h->mfma ? run_cnn_t<true>(h, n_active, mel_stride, mel_off) : run_cnn_t<false>(h, n_active, mel_stride, mel_off);
 }
 
-int ensure_scratch(oww_ctx* h, size_t streams) {
-    if (streams <= h->scratch_streams) return 0;
-    if (h->d_scratch) (void)dev_free(h->d_scratch);
-    h->d_scratch = nullptr; h->scratch_streams = 0;
-    const size_t n = streams * std::max<size_t>(1, h->nets.size()) * 2 * (size_t)std::max(h->generic_hmax, 1);
-    HIPCHK(dev_alloc(&h->d_scratch, n * sizeof(float)));
-    h->scratch_streams = streams;
-    return 0;
-}
-
 int heads_lds_bytes(int NH) { return (HD_SB * 100 + 2 * HD_SB * (NH + 4) + HD_SB * HD_MAXNETS) * 4; }
 
 // heads over streams [0,n_active): ring mode (ext == nullptr) or external features
@@ -823,21 +811,19 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
     }
     // generic kernel: nets that have no fast group, or everything when the fast path is off
     if (!fast_ok) {
-        if (int rc = ensure_scratch(h, (size_t)std::max(n_active, h->Spad))) return rc;
         HeadParams p = base;
         p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
         int nb = 0, ne = (int)h->nets.size();
         if (only_head >= 0) { nb = h->head_nets[only_head].first; ne = h->head_nets[only_head].second; }
-        hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + 63) / 64), dim3(64), 0, st, p, nb, ne, h->d_scratch, h->generic_hmax);
+        hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + GH_SPW * GH_WAVES - 1) / (GH_SPW * GH_WAVES)), dim3(64 * GH_WAVES), 0, st, p, nb, ne);
     } else if (!h->generic_nets.empty()) {
-        if (int rc = ensure_scratch(h, (size_t)std::max(n_active, h->Spad))) return rc;
         for (size_t hi = 0; hi < h->heads.size(); ++hi) {
             if (only_head >= 0 && (int)hi != only_head) continue;
             const int nb = h->head_nets[hi].first, ne = h->head_nets[hi].second;
             if (std::find(h->generic_nets.begin(), h->generic_nets.end(), nb) == h->generic_nets.end()) continue;
             HeadParams p = base;
             p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
-            hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + 63) / 64), dim3(64), 0, st, p, nb, ne, h->d_scratch, h->generic_hmax);
+            hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + GH_SPW * GH_WAVES - 1) / (GH_SPW * GH_WAVES)), dim3(64 * GH_WAVES), 0, st, p, nb, ne);
         }
     }
     HIPCHK(hipGetLastError());
@@ -940,7 +926,7 @@ void free_all(oww_ctx* h) {
     for (hipStream_t st : {h->up_stream, h->down_stream, h->blk_stream[0], h->blk_stream[1], h->blk_stream[2], h->blk_stream[3]})
         if (st) (void)hipStreamSynchronize(st);
     auto fr = [](auto*& p) { if (p) { (void)dev_free((void*)p); p = nullptr; } };
-    fr(h->d_w); fr(h->d_allnets); fr(h->d_generic); fr(h->d_scratch);
+    fr(h->d_w); fr(h->d_allnets); fr(h->d_generic);
     for (auto& g : h->groups) fr(g.d_nets);
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
@@ -1942,7 +1928,6 @@ int oww_commit(oww_ctx* h) {
     }
     if (h->cfg.debug_layers) if (int rc = dalloc(h->stream, &h->d_dbg, SP * DBG_FLOATS)) return rc;
     if (const char* e = getenv("OWW_PROF_BLOCK")) { h->prof_block = atoi(e); if (int rc = dalloc(h->stream, &h->d_prof, (size_t)4 * 256)) return rc; }
-    if (!h->mfma || !h->generic_nets.empty()) if (int rc = ensure_scratch(h, SP)) return rc;   // never allocate inside a graph capture
 
     // block-pipelined step: OFF by default.  Measured with the round-3 kernels at 131,072 x 3 (same box, OWW_BLOCKS = 1 / 2 / 3 / 4):
     // 6.04 / 6.10 / 6.25 / 6.32 ms per step -- two kernels sharing the chip gain nothing now that the front end no longer stalls

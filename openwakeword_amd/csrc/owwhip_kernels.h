@@ -939,75 +939,159 @@ __device__ __forceinline__ void store_raw(const HeadParams& p, int s, int col, f
     *o = p.accumulate_max ? fmaxf(*o, v) : v;
 }
 
-// generic (any T / hidden / n_out / LN / softmax): one thread per (stream, head); slow, fully general
-__global__ void heads_generic_kernel(HeadParams p, int net_begin, int net_end, float* scratch /*[S][n_nets][2*HMAX]*/,
-                                     int HMAX) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= p.S) return;
+// generic (any T / hidden <= 512 / n_out <= 8 / LN / softmax): ONE WAVE per GH_SPW streams, the hidden units spread over the lanes (unit
+// o = lane + 64 i).  Layer 1 walks the T x 96 features in order -- every hidden unit's sum is the k-ordered fmaf chain of the reference
+// formula -- with the feature value broadcast from LDS and the weight row w1[k][.] read coalesced, once per GH_SPW streams; layer 2 the
+// same on the hidden vector in LDS; LayerNorm sums by wave reduction.  (Rounds 1-4 ran one THREAD per stream with its hidden vectors in a
+// global scratch buffer: 0.4 M dependent memory round trips per stream for the multiclass `timer` head -- 70 ms per launch on 32
+// streams, which oww_commit's calibration and self-test issue 66 times: creating a handle with such a head took 4.5 s.)
+constexpr int GH_SPW = 4;            // streams per wave
+constexpr int GH_WAVES = 4;          // waves per workgroup
+constexpr int GH_HMAX = 512;         // oww_add_head refuses hidden > 512
+constexpr int GH_HPL = GH_HMAX / 64; // hidden units per lane
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LayerNorm (optional) + ReLU of the hidden vectors held as acc[stream][i] <-> unit lane + 64 i; then into LDS hv[stream][unit]
+__device__ __forceinline__ void gh_norm_relu_store(float (&acc)[GH_SPW][GH_HPL], int H, int has_ln, const float* __restrict__ g,
+                                                   const float* __restrict__ b, float* hv /*[GH_SPW][GH_HMAX]*/, int lane) {
+#pragma unroll
+    for (int s = 0; s < GH_SPW; ++s) {
+        if (has_ln) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) sum += acc[s][i];
+            const float mu = wave_sum(sum) / (float)H;
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) { const float d = acc[s][i] - mu; var = fmaf(d, d, var); }
+            const float rs = 1.0f / sqrtf(wave_sum(var) / (float)H + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) acc[s][i] = (acc[s][i] - mu) * rs * g[lane + 64 * i] + b[lane + 64 * i];
+        }
+#pragma unroll
+        for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) hv[s * GH_HMAX + lane + 64 * i] = fmaxf(acc[s][i], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(64 * GH_WAVES) void heads_generic_kernel(HeadParams p, int net_begin, int net_end) {
+    __shared__ float s_x[GH_WAVES][GH_SPW][96];
+    __shared__ float s_h[GH_WAVES][GH_SPW * GH_HMAX];
+    __shared__ float s_z[GH_WAVES][GH_SPW][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = (blockIdx.x * GH_WAVES + wave) * GH_SPW;
+    if (s0 >= p.S) return;                                   // (whole waves leave; no workgroup barrier below)
+    float* xs = &s_x[wave][0][0];
+    float* hv = s_h[wave];
+    int sid[GH_SPW];
+#pragma unroll
+    for (int s = 0; s < GH_SPW; ++s) sid[s] = min(s0 + s, p.S - 1);
     for (int ni = net_begin; ni < net_end; ++ni) {
         const NetDesc& n = p.nets[ni];
         if (n.role != 0) continue;
-        float result[8];
-        float gate_score = 0.f;
+        float result[GH_SPW][8];
+        float gate_score[GH_SPW];
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {
                 if (ni + 1 >= net_end) break;
                 if (p.nets[ni + 1].role != 1 || p.nets[ni + 1].head != n.head) break;
             }
             const NetDesc& m = p.nets[ni + pass];
-            float* h1 = scratch + ((size_t)s * p.n_nets + ni) * 2 * HMAX;
-            float* h2 = h1 + HMAX;
-            const int H = m.hidden, T = m.T;
-            for (int o = 0; o < H; ++o) h1[o] = m.b1[o];
+            const int H = m.hidden, T = m.T, O = m.n_out;
+            float acc[GH_SPW][GH_HPL];
+            // ---- layer 1
+#pragma unroll
+            for (int i = 0; i < GH_HPL; ++i) {
+                const float bb = lane + 64 * i < H ? m.b1[lane + 64 * i] : 0.f;
+#pragma unroll
+                for (int s = 0; s < GH_SPW; ++s) acc[s][i] = bb;
+            }
             for (int t = 0; t < T; ++t) {
-                const float* x = feat_row(p, s, T, t);
-                for (int c = 0; c < 96; ++c) {
-                    const float xv = x[c];
-                    const float* w = m.w1 + (size_t)(t * 96 + c) * H;
-                    for (int o = 0; o < H; ++o) h1[o] = fmaf(xv, w[o], h1[o]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-local LDS tile: the previous row's readers are done)
+#pragma unroll
+                for (int s = 0; s < GH_SPW; ++s) {
+                    const float* row = feat_row(p, sid[s], T, t);
+                    xs[s * 96 + lane] = row[lane];
+                    if (lane < 32) xs[s * 96 + 64 + lane] = row[64 + lane];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float* w = m.w1 + (size_t)t * 96 * H;
+                for (int c = 0; c < 96; ++c, w += H) {
+                    float xv[GH_SPW];
+#pragma unroll
+                    for (int s = 0; s < GH_SPW; ++s) xv[s] = xs[s * 96 + c];
+#pragma unroll
+                    for (int i = 0; i < GH_HPL; ++i)
+                        if (lane + 64 * i < H) {
+                            const float wv = w[lane + 64 * i];
+#pragma unroll
+                            for (int s = 0; s < GH_SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
+                        }
                 }
             }
-            for (int layer = 0; layer < 2; ++layer) {
-                float* h = layer ? h2 : h1;
-                if (layer) {
-                    for (int o = 0; o < H; ++o) {
-                        float a = m.b2[o];
-                        for (int i = 0; i < H; ++i) a = fmaf(h1[i], m.w2[i * H + o], a);
-                        h2[o] = a;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gh_norm_relu_store(acc, H, m.has_ln, m.ln1g, m.ln1b, hv, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- layer 2
+#pragma unroll
+            for (int i = 0; i < GH_HPL; ++i) {
+                const float bb = lane + 64 * i < H ? m.b2[lane + 64 * i] : 0.f;
+#pragma unroll
+                for (int s = 0; s < GH_SPW; ++s) acc[s][i] = bb;
+            }
+            for (int k = 0; k < H; ++k) {
+                float xv[GH_SPW];
+#pragma unroll
+                for (int s = 0; s < GH_SPW; ++s) xv[s] = hv[s * GH_HMAX + k];
+                const float* w = m.w2 + (size_t)k * H;
+#pragma unroll
+                for (int i = 0; i < GH_HPL; ++i)
+                    if (lane + 64 * i < H) {
+                        const float wv = w[lane + 64 * i];
+#pragma unroll
+                        for (int s = 0; s < GH_SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
                     }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every lane has read the layer-1 vector
+            gh_norm_relu_store(acc, H, m.has_ln, m.ln2g, m.ln2b, hv, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- output layer: lane o < n_out, the k-ordered chain of the formula; then the final activation per stream
+            if (lane < O) {
+#pragma unroll
+                for (int s = 0; s < GH_SPW; ++s) {
+                    float a = m.b3[lane];
+                    for (int i = 0; i < H; ++i) a = fmaf(hv[s * GH_HMAX + i], m.w3[i * O + lane], a);
+                    s_z[wave][s][lane] = a;
                 }
-                if (m.has_ln) {
-                    const float* g = layer ? m.ln2g : m.ln1g;
-                    const float* b = layer ? m.ln2b : m.ln1b;
-                    float mu = 0.f;
-                    for (int o = 0; o < H; ++o) mu += h[o];
-                    mu /= (float)H;
-                    float var = 0.f;
-                    for (int o = 0; o < H; ++o) { const float d = h[o] - mu; var = fmaf(d, d, var); }
-                    var /= (float)H;
-                    const float rs = 1.0f / sqrtf(var + 1e-5f);
-                    for (int o = 0; o < H; ++o) h[o] = (h[o] - mu) * rs * g[o] + b[o];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < GH_SPW; ++s) {
+                float z[8];
+                for (int o = 0; o < O; ++o) z[o] = s_z[wave][s][o];
+                if (m.final_act == 1) {
+                    float mx = -INFINITY, sum = 0.f;
+                    for (int o = 0; o < O; ++o) { z[o] = fmaxf(z[o], 0.f); mx = fmaxf(mx, z[o]); }
+                    for (int o = 0; o < O; ++o) { z[o] = expf(z[o] - mx); sum += z[o]; }
+                    for (int o = 0; o < O; ++o) z[o] /= sum;
+                } else {
+                    for (int o = 0; o < O; ++o) z[o] = 1.0f / (1.0f + expf(-z[o]));
                 }
-                for (int o = 0; o < H; ++o) h[o] = fmaxf(h[o], 0.f);
+                if (pass == 0) { for (int o = 0; o < O; ++o) result[s][o] = z[o]; gate_score[s] = z[0]; }
+                else if (gate_score[s] > 0.5f) { for (int o = 0; o < O; ++o) result[s][o] = z[o]; }
             }
-            float z[8];
-            for (int o = 0; o < m.n_out; ++o) {
-                float a = m.b3[o];
-                for (int i = 0; i < H; ++i) a = fmaf(h2[i], m.w3[i * m.n_out + o], a);
-                z[o] = a;
-            }
-            if (m.final_act == 1) {
-                float mx = -INFINITY, sum = 0.f;
-                for (int o = 0; o < m.n_out; ++o) { z[o] = fmaxf(z[o], 0.f); mx = fmaxf(mx, z[o]); }
-                for (int o = 0; o < m.n_out; ++o) { z[o] = expf(z[o] - mx); sum += z[o]; }
-                for (int o = 0; o < m.n_out; ++o) z[o] /= sum;
-            } else {
-                for (int o = 0; o < m.n_out; ++o) z[o] = 1.0f / (1.0f + expf(-z[o]));
-            }
-            if (pass == 0) { for (int o = 0; o < m.n_out; ++o) result[o] = z[o]; gate_score = z[0]; }
-            else if (gate_score > 0.5f) { for (int o = 0; o < m.n_out; ++o) result[o] = z[o]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        for (int o = 0; o < n.n_out; ++o) store_raw(p, s, n.out_col + o, result[o]);
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < GH_SPW; ++s)
+                if (s0 + s < p.S)
+                    for (int o = 0; o < n.n_out; ++o) store_raw(p, s0 + s, n.out_col + o, result[s][o]);
+        }
     }
 }
 
