@@ -59,3 +59,32 @@ def test_bare_multi_gpu_invocation_relaunches_itself_under_torchrun(monkeypatch)
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_composite_roofline_is_priced_only_from_a_counter_pass_of_the_loaded_build(tmp_path, monkeypatch):
+    """a kernel change without a fresh PMC pass must not price new times with old instruction counts.  The library
+    carries the hash of its sources (oww_build_info), tools/pmc.sh stores it with every counter summary, and bench.py takes the newest
+    profiles/rNN_<kind>.json whose hash matches -- or says why there is no composite."""
+    import json
+    import types
+    from openwakeword_amd import _build, _lib
+    b = _bench()
+    have = b.loaded_build()
+    assert have == _build.source_hash() and len(have) == 16            # the in-tree library was built from the in-tree sources
+    assert _lib.load().oww_build_info().decode().startswith("src=" + have)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    args = types.SimpleNamespace(valu=False, lds_mfma=False, fp32=False)
+    kern = {"SQ_INSTS_MFMA": 512.0 * 131072, "SQ_INSTS_VALU": 3147.0 * 131072, "SQ_INSTS_LDS": 682.0 * 131072,
+            "SQ_LDS_IDX_ACTIVE": 3.6e8, "SQ_LDS_BANK_CONFLICT": 4.7e7}
+    (prof / "r04_instr.json").write_text(json.dumps({"stageA_hx": kern}))                                   # no hash: an old round's pass
+    (prof / "r05_instr.json").write_text(json.dumps({"stageA_hx": kern, "_csrc_sha16": "0123456789abcdef"}))   # another build's pass
+    b._PROFILE_CACHE.clear()
+    out = b.issue_bound("stageA", 131072, 1.5, args)
+    assert set(out) == {"unavailable"} and have in out["unavailable"]
+    (prof / "r06_instr.json").write_text(json.dumps({"stageA_hx": kern, "_csrc_sha16": have}))
+    b._PROFILE_CACHE.clear()
+    out = b.issue_bound("stageA", 131072, 1.5, args)
+    assert out["wave_instructions_per_stream_step"] == {"valu": 2635.0, "mfma": 512.0, "lds": 682.0} and have in out["source"] and "r06_instr" in out["source"]
+    assert b.pmc_traffic("stageA", 131072, args) is None                # no traffic pass of this build

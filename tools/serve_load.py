@@ -192,7 +192,8 @@ def serve_until(a, slots, t_end_wall, reuse_port):
         await site.start()
         if a.ready_file:
             open(a.ready_file, "w").write("ready\n")
-        while time.time() < t_end_wall and not getattr(a, "_done", False):
+        a._ready = True
+        while time.time() < t_end_wall and not getattr(a, "_done", False) and not (a.stop_file and os.path.exists(a.stop_file)):
             await asyncio.sleep(0.25)
         backlog = sum(c.n_pending // 1280 for c in srv.conns.values())
         n_conn = srv._next_cid
@@ -241,6 +242,7 @@ def main():
     ap.add_argument("--role", default="driver", choices=("driver", "server"), help="(internal) server = one worker process of --server-procs")
     ap.add_argument("--t-end", type=float, default=0.0, help="(internal) wall-clock time at which a server worker stops")
     ap.add_argument("--ready-file", default="")
+    ap.add_argument("--stop-file", default="", help="(internal) a server worker stops when this file appears")
     ap.add_argument("--metrics-out", default="")
     a = ap.parse_args()
     PERIODS[:] = [float(v) * 1e-3 for v in a.periods_ms.split(",")]
@@ -264,28 +266,33 @@ def main():
     n_srv = max(1, a.server_procs)
     slots = a.slots or (a.clients if n_srv == 1 else int(1.5 * a.clients / n_srv) + 64)
     t_start = time.time()
-    t0_wall = time.time() + 8.0 + a.clients / 3000.0 + (14.0 if n_srv > 1 and not a.dry_run else 0.0)   # connections (and worker start-up) before the common start
-    t_end_wall = t0_wall + a.seconds + 3.0
+    t_give_up = t_start + 900.0
     tmp = tempfile.mkdtemp(prefix="serve_load_")
+    a.stop_file = os.path.join(tmp, "stop")
     workers, metrics = [], []
     if n_srv > 1:
         for w in range(n_srv):
             cmd = [sys.executable, os.path.abspath(__file__), "--role", "server", "--clients", str(a.clients), "--slots", str(slots),
                    "--seconds", str(a.seconds), "--port", str(a.port), "--sample", str(a.sample), "--window-ms", str(a.window_ms),
-                   "--periods-ms", a.periods_ms, "--threshold", str(a.threshold), "--t-end", str(t_end_wall),
+                   "--periods-ms", a.periods_ms, "--threshold", str(a.threshold), "--t-end", str(t_give_up), "--stop-file", a.stop_file,
                    "--ready-file", os.path.join(tmp, f"ready{w}"), "--metrics-out", os.path.join(tmp, f"m{w}.npz")] + (["--dry-run"] if a.dry_run else [])
             workers.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, f"w{w}.err"), "w")))
         while not all(os.path.exists(os.path.join(tmp, f"ready{w}")) for w in range(n_srv)):
-            if any(p.poll() is not None for p in workers) or time.time() > t0_wall - 2.0:
+            if any(p.poll() is not None for p in workers) or time.time() > t_start + 300:
                 errs = "".join(open(os.path.join(tmp, f"w{w}.err")).read()[-600:] for w in range(n_srv))
                 raise SystemExit(f"server workers did not come up in time:\n{errs}")
             time.sleep(0.2)
     else:
         a.ready_file = ""
         box = {}
-        th = threading.Thread(target=lambda: box.update(m=serve_until(a, slots, t_end_wall, False)), daemon=True)
+        th = threading.Thread(target=lambda: box.update(m=serve_until(a, slots, t_give_up, False)), daemon=True)
         th.start()
-        time.sleep(0.5)
+        while not getattr(a, "_ready", False):          # (the first `import torch` of a fresh box and the handle's creation take their time)
+            if not th.is_alive() or time.time() > t_start + 300:
+                raise SystemExit("the server did not come up")
+            time.sleep(0.2)
+    t0_wall = time.time() + 6.0 + a.clients / 3000.0      # the clients connect first and start sending together
+    t_end_wall = t0_wall + a.seconds + 3.0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ids = [list(range(p, a.clients, a.procs)) for p in range(a.procs)]
@@ -298,6 +305,8 @@ def main():
             results.append(q.get(True, 1.0))
         except Exception:
             pass
+    time.sleep(max(0.0, t_end_wall - time.time()))
+    open(a.stop_file, "w").write("stop\n")
     if n_srv > 1:
         for w, p in enumerate(workers):
             p.wait(timeout=300)
@@ -313,7 +322,7 @@ def main():
     done = steps[steps[:, 3] > 0]
     e2e = np.concatenate([r["lat"] for r in results]) if results else np.zeros(0, np.float32)
     n_stream_steps = int(sum(int(m["n_stream_steps"]) for m in metrics))
-    period = np.concatenate([np.diff(m["steps"].reshape(-1, 4)[:, 1]) for m in metrics if m["steps"].size > 4]) if metrics else np.zeros(0)
+    period = np.concatenate([np.zeros(0)] + [np.diff(m["steps"].reshape(-1, 4)[:, 1]) for m in metrics if m["steps"].size > 4])
     out = {
         "what": "FanInServer under real websocket clients (tools/serve_load.py): reference wire protocol, 127.0.0.1, clients in separate processes",
         "clients": a.clients, "connections_accepted": int(sum(int(m["n_conn"]) for m in metrics)), "connections_per_server": [int(m["n_conn"]) for m in metrics],
