@@ -289,3 +289,59 @@ def test_masked_submit_pipeline_equals_masked_steps(family):
     got.append(b.collect().copy())
     np.testing.assert_array_equal(np.stack(got), want)
     a.close(); b.close()
+
+
+def test_serve_cli_with_two_worker_processes_on_one_port():
+    """`python -m openwakeword_amd.serve --workers 2`: two server processes share the port (SO_REUSEPORT), each with its own handle on the
+    GPU; every client gets the model list and one answer per 1280-sample chunk it sent (threshold 0), whichever worker took it."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    import aiohttp
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "openwakeword_amd.serve", "--workers", "2", "--streams", "8", "--models", "alexa", "hey_jarvis",
+           "--weights", "synthetic", "--threshold", "0.0", "--host", "127.0.0.1", "--port", str(port)]
+    p = subprocess.Popen(cmd, cwd=root, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        rng = np.random.default_rng(77)
+        audio = [(rng.standard_normal(1280 * 6) * 4000).astype(np.int16) for _ in range(6)]
+
+        async def client(session, x):
+            for _ in range(600):                               # both workers import torch and create their handles first
+                try:
+                    ws = await session.ws_connect(f"http://127.0.0.1:{port}/ws")
+                    break
+                except aiohttp.ClientError:
+                    assert p.poll() is None, p.stderr.read()[-2000:]
+                    await asyncio.sleep(0.2)
+            else:
+                raise AssertionError("the server never came up")
+            assert json.loads((await ws.receive()).data)["loaded_models"] == ["alexa", "hey_jarvis"]
+            await ws.send_str("16000")
+            await ws.send_bytes(x.tobytes())
+            got = []
+            while len(got) < x.size // 1280:
+                msg = await ws.receive(timeout=60)
+                got.append(json.loads(msg.data)["activations"])
+            await ws.close()
+            return got
+
+        async def run():
+            async with aiohttp.ClientSession() as session:
+                first = await client(session, audio[0])        # (wait for the workers once, then the rest in parallel)
+                rest = await asyncio.gather(*[client(session, x) for x in audio[1:]])
+                return [first] + list(rest)
+        answers = asyncio.run(asyncio.wait_for(run(), 300))
+        assert all(len(a) == 6 and all(hits == ["alexa", "hey_jarvis"] for hits in a) for a in answers)
+    finally:
+        import signal
+        os.killpg(p.pid, signal.SIGTERM)                        # the parent and its two workers: the process group this test started
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
