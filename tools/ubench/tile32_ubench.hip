@@ -160,10 +160,91 @@ __global__ __launch_bounds__(256, WPS) void k32(float* out, const float* in, con
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// ---- B with the weights STREAMED like the real stage kernels do it: one 36 KB chunk (one 32-channel output tile) per step, L2 -> LDS by
+// global_load_lds into a three-slot ring shared by the workgroup's four waves, two chunks in flight, counted wait + bare barrier per step
+// (owwhip_hx.h: WRing, NS = 3).  One workgroup per CU (the registers allow one wave per SIMD), so nothing else covers the ring's waits.
+__global__ __launch_bounds__(256, 1) void k32s(float* out, const float* in, const _Float16* w, int iters) {
+    __shared__ __attribute__((aligned(16))) float slot0[9216];
+    __shared__ __attribute__((aligned(16))) float slot1[9216];
+    __shared__ __attribute__((aligned(16))) float slot2[9216];
+    float* const slots[3] = {slot0, slot1, slot2};
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* wf = reinterpret_cast<const float*>(w);
+    auto issue = [&](int chunk, float* dst) {                 // 36 blocks of 1 KB, 9 per wave
+        const float* src = wf + (size_t)(chunk % 3) * 9216;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = u * 4 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+        }
+    };
+    f16x8 Bh[4][6], Bl[4][6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = in[((r * 6 + k) * 8 + e) * 256 + threadIdx.x];
+            split8(x, Bh[r][k], Bl[r][k]);
+        }
+    issue(0, slot0);
+    issue(1, slot1);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int oct = 0; oct < 3; ++oct) {
+            // chunk c = 3 it + oct: wait until it has landed (the newest one, 9 DMA instructions of this wave, may stay in flight), meet the
+            // other waves, then refill the slot everybody has just left
+            __builtin_amdgcn_s_waitcnt((9 & 0xF) | ((9 >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(oct + 2, slots[(oct + 2) % 3]);
+            const f16x8* swz = reinterpret_cast<const f16x8*>(slots[oct]) + lane;
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const f16x8 ah = swz[((tap * 6 + k) * 2 + 0) * 64], al = swz[((tap * 6 + k) * 2 + 1) * 64];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[t + tap][k], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[t + tap][k], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[t + tap][k], acc[t], 0, 0, 0);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = act1(acc[t][8 * s + e], -3.2f);
+                    split8(x, Bh[t][2 * oct + s], Bl[t][2 * oct + s]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            f16x8 th = Bh[0][k], tl = Bl[0][k]; Bh[0][k] = Bh[2][k]; Bl[0][k] = Bl[2][k]; Bh[2][k] = th; Bl[2][k] = tl;
+            th = Bh[1][k]; tl = Bl[1][k]; Bh[1][k] = Bh[3][k]; Bl[1][k] = Bl[3][k]; Bh[3][k] = th; Bl[3][k] = tl;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r += (float)Bh[2][k][0] + (float)Bl[3][k][7];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 template <class K>
 int timeit(const char* name, K kern, int wps, int lds, int streams_per_wave, float* out, const float* in, const _Float16* w) {
     const int iters = 300;
-    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 0) CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     const int grid = 256 * wps;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, out, in, w, iters);
@@ -193,5 +274,6 @@ int main() {
     timeit("A 16x16x32, 4 streams/wave", k16<2, 1>, 1, 100 * 1024, 4, out, in, w);
     timeit("B 32x32x16, 8 streams/wave", k32<1, 2>, 2, 72 * 1024, 8, out, in, w);
     timeit("B 32x32x16, 8 streams/wave", k32<1, 1>, 1, 100 * 1024, 8, out, in, w);
+    timeit("B 32x32x16 + streamed weights", k32s, 1, 0, 8, out, in, w);
     return 0;
 }
