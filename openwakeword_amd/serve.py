@@ -509,6 +509,7 @@ class FanInServer:
                 t_round = loop.time()
                 self._have_chunk.clear()
                 self._reap()
+                g_sync = None
                 try:
                     n = self._n_fill
                     pipelined = self._step_s > 0.5 * self.window_s and self.window_s > 0
@@ -530,7 +531,9 @@ class FanInServer:
                             # a step that is short against the window: submit and collect as ONE job of the GPU thread (every await
                             # costs a trip through an event loop that is busy with thousands of sockets).  (Every 64th step of the
                             # pipelined mode runs this way too: it is where the step time is measured.)
+                            g_sync = g
                             scores, dt = await self._gpu.call(self._step_now, self._pcm[g], self._on[g])
+                            g_sync = None
                             scores = scores[:, keep]
                             now = loop.time()
                             self._step_s = dt if self._step_s == 0.0 else 0.5 * self._step_s + 0.5 * dt
@@ -554,6 +557,9 @@ class FanInServer:
                     self._reap()
                 except OwwRangeError:
                     t_sub.clear()
+                    if g_sync is not None:                  # the one-job step raised: nothing of it is in flight, its rows are dropped
+                        self._release_buffer(g_sync)
+                        g_sync = None
                     await self._recover_range(flying)
                 if self._n_fill:
                     self._have_chunk.set()          # something was staged meanwhile (a backlog, or messages that arrived during the step)

@@ -156,3 +156,70 @@ def test_step_counter_restarts_when_a_slot_changes_hands():
     asyncio.run(asyncio.wait_for(run(), 30))
     assert [k for k, _ in tap[0]] == [0, 1, 2] and [k for k, _ in tap[1]] == [0, 1]
     assert tap[1][0][1][1] == 0.0                       # the engine's own counter was reset with the slot (Model.reset on hand-over)
+
+
+def test_range_error_drops_the_step_and_the_server_carries_on():
+    """OWW_ERANGE out of a step (serve._recover_range): the participants of that step lose one chunk, the streams named by range_where are
+    reset, nothing stays flagged or counted in flight, every later chunk is scored."""
+    from aiohttp.test_utils import TestClient, TestServer
+    from openwakeword_amd._lib import OwwRangeError
+
+    class FailingEngine(_Engine):
+        def __init__(self, S):
+            super().__init__(S)
+            self.n_collect, self.flag, self.resets = 0, False, []
+
+        def collect(self):
+            self.n_collect += 1
+            out = super().collect()
+            if self.n_collect == 4:
+                self.flag = True
+                raise OwwRangeError("libowwhip error -5: test")
+            return out
+
+        def range_where(self):
+            return (1, 1)
+
+        def range_status(self, clear=False):
+            was, self.flag = self.flag, (False if clear else self.flag)
+            return was
+
+    model = _Model(4)
+    model.engine = FailingEngine(4)
+    real_reset = model.reset
+
+    def reset(ids=None, reset_vad=False):
+        model.engine.resets.append(ids)
+        real_reset(slice(None) if ids is None else ids, reset_vad)
+    model.reset = reset
+    tap = {}
+    srv = serve.FanInServer(model, threshold=2.0, window_s=0.002, on_scores=lambda cid, k, row: tap.setdefault(cid, []).append((k, row.copy())))
+    x = [np.random.default_rng(i).integers(-9000, 9000, size=1280 * 10, dtype=np.int16) for i in range(3)]
+
+    async def client(tc, i):
+        ws = await tc.ws_connect("/ws")
+        await ws.receive()
+        for k in range(10):
+            await ws.send_bytes(x[i][k * 1280:(k + 1) * 1280].tobytes())
+            await asyncio.sleep(0.004)
+        await asyncio.sleep(0.1)
+        await ws.close()
+
+    async def run():
+        async with TestClient(TestServer(srv.app())) as tc:
+            await asyncio.gather(*[client(tc, i) for i in range(3)])
+            for _ in range(200):
+                if not srv.conns:
+                    break
+                await asyncio.sleep(0.005)
+    asyncio.run(asyncio.wait_for(run(), 30))
+    assert srv.n_range_recoveries == 1 and srv.failed is None
+    assert [1] in model.engine.resets                                    # the stream range_where named was restarted
+    scored = sum(len(v) for v in tap.values())
+    assert 30 - 3 <= scored < 30                                         # only the participants of the failing step lost a chunk
+    assert not srv.conns and srv.slots.n_used == 0 and int(srv._inflight.sum()) == 0 and all(int(o.sum()) == 0 for o in srv._on)
+    for i in range(3):                                                   # what WAS scored is each client's own audio, in order
+        sums = [np.float32(_checksum(x[i][k * 1280:(k + 1) * 1280])) for k in range(10)]
+        got = [row[0] for _k, row in tap[i]]
+        it = iter(sums)
+        assert all(any(g == s for s in it) for g in got), f"client {i}"
