@@ -120,6 +120,34 @@ def test_multiclass_and_wide_heads(emb):
         e.close()
 
 
+@pytest.mark.parametrize("use_mfma", [3, 1])
+def test_generic_heads_of_any_shape(emb, use_mfma):
+    """The generic heads kernel (one wave per four streams, hidden units over the lanes): hidden sizes that are not multiples of 64, the
+    512 maximum, with and without LayerNorm, a gated pair and a multiclass head outside the fast form, batches that do not fill the
+    last wave -- against the float64 head of the oracle (model.py:299-302, train.py:56-83)."""
+    shapes = {"odd48": dict(kind="binary", T=5, hidden=48, n_out=1, layernorm=True),
+              "odd100": dict(kind="binary", T=16, hidden=100, n_out=1, layernorm=False),
+              "wide512": dict(kind="multiclass", T=3, hidden=512, n_out=8, layernorm=True),
+              "gated96": dict(kind="gated", T=16, hidden=96, n_out=1, layernorm=True),
+              "tiny1": dict(kind="binary", T=1, hidden=1, n_out=1, layernorm=False)}
+    heads = {n: W.synthetic_head(n, 7 + i, **kw) for i, (n, kw) in enumerate(shapes.items())}
+    rng = np.random.default_rng(12)
+    for S in (1, 5, 18):                                   # the last wave of four streams partly filled
+        e = StreamEngine(S, heads, emb, use_mfma=use_mfma)
+        try:
+            for name, h in heads.items():
+                ft = rng.normal(0, 1.5, (S, h["T"], 96)).astype(np.float32)
+                got = e.head(name, ft)
+                np.testing.assert_allclose(got, O.head_stage(ft, h, np.float64), rtol=0, atol=TOL_SCORE, err_msg=f"{name} S={S}")
+            # and through the streaming step (feature ring rows, score columns, post-processing untouched by the head form)
+            pcm = W.synthetic_pcm(S, 1280 * 3, seed=S)
+            for t in range(3):
+                out = e.step(pcm[:, 1280 * t:1280 * (t + 1)])
+            assert out.shape == (S, e.n_labels) and np.isfinite(out).all()
+        finally:
+            e.close()
+
+
 # ------------------------------------------------------------------------------------------- streaming
 def test_streaming_every_layer_and_score(eng, emb, heads, golden):
     S, n_steps = 6, 20
