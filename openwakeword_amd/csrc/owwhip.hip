@@ -417,6 +417,10 @@ struct FastGroup {
     const float* d_b1cat = nullptr;
     const float* d_w1hx = nullptr;    // fp16-split k-step-major layer-1 weights (heads_hx_kernel)
     std::vector<const float*> d_w2hx; // per net
+    // fp16-split fast path: per net the seven per-unit arrays (b1, ln1 g / b, b2, ln2 g / b, w3) padded with zeros to the kernel's 64
+    // hidden units -- a narrower net (the reference's training pipeline defaults to 32: examples/custom_model.yml:89) runs as a
+    // 64-unit net whose padding units are identically zero and are left out of the LayerNorm statistics (owh::HeadHxNet::hidden)
+    std::vector<const float*> d_pad;  // per net: 7 x 64 floats
 };
 
 constexpr int N_STATE = 11;
@@ -782,8 +786,10 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                     const NetHost& n = h->nets[g.nets[i]];
                     const NetDesc d = h->host_descs[g.nets[i]];
                     owh::HeadHxNet& o = q.net[i];
-                    o.w2hx = g.d_w2hx[i]; o.b1 = d.b1; o.ln1g = d.ln1g; o.ln1b = d.ln1b; o.b2 = d.b2; o.ln2g = d.ln2g; o.ln2b = d.ln2b;
-                    o.w3 = d.w3; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
+                    const float* pd = g.d_pad[i];                      // the per-unit arrays padded to 64 units
+                    o.w2hx = g.d_w2hx[i]; o.b1 = pd; o.ln1g = pd + 64; o.ln1b = pd + 128; o.b2 = pd + 192; o.ln2g = pd + 256; o.ln2b = pd + 320;
+                    o.w3 = pd + 384; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
+                    o.hidden = n.hidden; o.inv_hidden = 1.0f / (float)n.hidden;
                     o.u1 = std::ldexp(1.0f, -(h->hx_efeat + n.hx_e1)); o.u2 = std::ldexp(1.0f, -n.hx_e2);
                 }
                 q.fscale = std::ldexp(1.0f, h->hx_efeat);
@@ -1753,12 +1759,15 @@ int oww_commit(oww_ctx* h) {
     }
     // grouping: heads whose nets are all (hidden 64, n_out 1, sigmoid) share a fast group per T (<= 8 nets each)
     h->groups.clear(); h->generic_nets.clear();
-    struct GOff { size_t w1pk, b1cat, w1hx; std::vector<size_t> w2hx; };
+    struct GOff { size_t w1pk, b1cat, w1hx; std::vector<size_t> w2hx, pad; };
     std::vector<GOff> goff;
     for (size_t hi = 0; hi < h->heads.size(); ++hi) {
         const auto [nb, ne] = h->head_nets[hi];
         bool fast = h->mfma;
-        for (int ni = nb; ni < ne; ++ni) fast = fast && h->nets[ni].hidden == 64 && h->nets[ni].n_out == 1 && h->nets[ni].final_act == 0;
+        // the MFMA head kernels: sigmoid nets of one output; exactly 64 hidden units in the fp32 family (heads64_kernel), up to 64 in the
+        // fp16-split family (zero-padded, see FastGroup::d_pad)
+        for (int ni = nb; ni < ne; ++ni)
+            fast = fast && (h->nets[ni].hidden == 64 || (h->hx && h->nets[ni].hidden <= 64)) && h->nets[ni].n_out == 1 && h->nets[ni].final_act == 0;
         if (!fast) { for (int ni = nb; ni < ne; ++ni) h->generic_nets.push_back(ni); continue; }
         FastGroup* g = nullptr;
         const int cap = h->hx ? 4 : HD_MAXNETS;                      // heads_hx_kernel: at most four nets per launch
@@ -1769,20 +1778,22 @@ int oww_commit(oww_ctx* h) {
     for (auto& g : h->groups) {
         g.NH = 64 * g.n_nets;
         const size_t K = (size_t)g.T * 96;
-        std::vector<float> wcat(K * g.NH), bcat(g.NH), pk;
+        std::vector<float> wcat(K * g.NH, 0.f), bcat(g.NH, 0.f), pk;
         for (int gi = 0; gi < g.n_nets; ++gi) {
             const NetHost& n = h->nets[g.nets[gi]];
-            for (size_t k = 0; k < K; ++k) memcpy(&wcat[k * g.NH + 64 * gi], n.w1 + k * 64, 64 * sizeof(float));
-            memcpy(&bcat[64 * gi], n.b1, 64 * sizeof(float));
+            const size_t H = n.hidden;                                   // (<= 64; columns H .. 63 of the net's block stay zero)
+            for (size_t k = 0; k < K; ++k) memcpy(&wcat[k * g.NH + 64 * gi], n.w1 + k * H, H * sizeof(float));
+            memcpy(&bcat[64 * gi], n.b1, H * sizeof(float));
         }
         pack_mfma(wcat.data(), g.T, 96, g.NH, pk);
-        GOff go{hb.add(pk), hb.add(bcat), 0, {}};
+        GOff go{hb.add(pk), hb.add(bcat), 0, {}, {}};
         if (h->hx) {
             // every net's two matrices on their own power-of-two scale (hx_weight_exp); undone on the fp32 accumulators (HeadHxNet::u1, u2)
             std::vector<double> colmul(g.NH);
             for (int gi = 0; gi < g.n_nets; ++gi) {
                 NetHost& n = h->nets[g.nets[gi]];
-                n.hx_e1 = hx_weight_exp(n.w1, K * 64); n.hx_e2 = hx_weight_exp(n.w2, 64 * 64);
+                const size_t H = n.hidden;
+                n.hx_e1 = hx_weight_exp(n.w1, K * H); n.hx_e2 = hx_weight_exp(n.w2, H * H);
                 if (n.hx_e1 == -1000 || n.hx_e2 == -1000) return fail(OWW_EINVAL, "head weights are not finite");
                 for (int c = 0; c < 64; ++c) colmul[64 * gi + c] = std::ldexp(1.0, n.hx_e1);
             }
@@ -1790,9 +1801,17 @@ int oww_commit(oww_ctx* h) {
             go.w1hx = hb.add(pk);
             for (int gi = 0; gi < g.n_nets; ++gi) {
                 const NetHost& n = h->nets[g.nets[gi]];
+                const size_t H = n.hidden;
                 std::vector<double> cm2(64, std::ldexp(1.0, n.hx_e2));
                 HxFold fold; fold.colmul = cm2.data();
-                pack_hx(n.w2, 1, 64, 64, pk, &fold); go.w2hx.push_back(hb.add(pk));
+                std::vector<float> w2p(64 * 64, 0.f);                    // [in 64][out 64], zero rows / columns beyond H
+                for (size_t i = 0; i < H; ++i) memcpy(&w2p[i * 64], n.w2 + i * H, H * sizeof(float));
+                pack_hx(w2p.data(), 1, 64, 64, pk, &fold); go.w2hx.push_back(hb.add(pk));
+                std::vector<float> pad(7 * 64, 0.f);                     // b1, ln1g, ln1b, b2, ln2g, ln2b, w3
+                const float* src[7] = {n.b1, n.has_ln ? n.ln1g : nullptr, n.has_ln ? n.ln1b : nullptr, n.b2,
+                                       n.has_ln ? n.ln2g : nullptr, n.has_ln ? n.ln2b : nullptr, n.w3};
+                for (int a = 0; a < 7; ++a) if (src[a]) memcpy(&pad[a * 64], src[a], H * sizeof(float));
+                go.pad.push_back(hb.add(pad));
             }
         }
         goff.push_back(go);
@@ -1875,7 +1894,11 @@ int oww_commit(oww_ctx* h) {
         HIPCHK(dev_alloc(&g.d_nets, ds.size() * sizeof(NetDesc)));
         HIPCHK(copy_sync(g.d_nets, ds.data(), ds.size() * sizeof(NetDesc), hipMemcpyHostToDevice));
         g.d_w1pk = h->d_w + goff[gi].w1pk; g.d_b1cat = h->d_w + goff[gi].b1cat;
-        if (h->hx) { g.d_w1hx = h->d_w + goff[gi].w1hx; for (size_t o : goff[gi].w2hx) g.d_w2hx.push_back(h->d_w + o); }
+        if (h->hx) {
+            g.d_w1hx = h->d_w + goff[gi].w1hx;
+            for (size_t o : goff[gi].w2hx) g.d_w2hx.push_back(h->d_w + o);
+            for (size_t o : goff[gi].pad) g.d_pad.push_back(h->d_w + o);
+        }
         if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
     }
 

@@ -1442,6 +1442,8 @@ struct HeadHxNet {
     const float *b1, *ln1g, *ln1b, *b2, *ln2g, *ln2b, *w3, *b3;
     int has_ln, role, head, out_col;
     float u1, u2;                            // exact power-of-two un-scales of the two accumulators: 2^-(e_feat + e_w1), 2^-e_w2
+    int hidden;                              // real hidden units (<= 64): units hidden .. 63 are zero padding, outside the LayerNorm statistics
+    float inv_hidden;                        // 1 / hidden
 };
 // Optional tail of the heads kernel: Model.predict's post-processing (model.py:330-381 -- first-5 zeroing, patience / debounce
 // over the 30-deep score ring, ring append, VAD gate) and the step's frame-counter advance for the same streams, instead of two
@@ -1489,8 +1491,10 @@ __device__ __forceinline__ float xsum4(float v) {      // sum over the four j gr
 
 template <int NN>
 __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__ bias, const float* __restrict__ g,
-                                        const float* __restrict__ b, int has_ln, int j, float unscale) {
-    // h: the 64 hidden values of one net for this lane's stream: tile ct, register e <-> hidden 16ct + 4j + e
+                                        const float* __restrict__ b, int has_ln, int j, float unscale, int hidden, float inv_hidden) {
+    // h: the 64 hidden values of one net for this lane's stream: tile ct, register e <-> hidden 16ct + 4j + e.  Units >= `hidden` are
+    // padding: zero weights and bias make them exactly 0 here, zero gamma / beta keep them 0 behind the LayerNorm; only the variance has
+    // to leave them out (their (0 - mu)^2 is not part of the net)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * j);
@@ -1502,13 +1506,13 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum += h[ct][e];
-        const float mu = xsum4(sum) * (1.0f / 64.f);
+        const float mu = xsum4(sum) * inv_hidden;
         float var = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = h[ct][e] - mu; var = fmaf(d, d, var); }
-        const float rs = 1.0f / sqrtf(xsum4(var) * (1.0f / 64.f) + 1e-5f);
+            for (int e = 0; e < 4; ++e) { const float d = (ct * 16 + 4 * j + e < hidden) ? h[ct][e] - mu : 0.f; var = fmaf(d, d, var); }
+        const float rs = 1.0f / sqrtf(xsum4(var) * inv_hidden + 1e-5f);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const f32x4 gg = *reinterpret_cast<const f32x4*>(g + ct * 16 + 4 * j);
@@ -1683,7 +1687,7 @@ __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(H
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 h1[4] = {acc[4 * n][t], acc[4 * n + 1][t], acc[4 * n + 2][t], acc[4 * n + 3][t]};
-            ln_relu<NN>(h1, net.b1, net.ln1g, net.ln1b, net.has_ln, j, net.u1);
+            ln_relu<NN>(h1, net.b1, net.ln1g, net.ln1b, net.has_ln, j, net.u1, net.hidden, net.inv_hidden);
             Op ho[2];
             to_ops<4>(h1, ho);
             f32x4 h2[4];
@@ -1701,7 +1705,7 @@ __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(H
                 h2[oct] = a2;
                 if (oct == 0) nan_guard(bad, a2[0]);
             }
-            ln_relu<NN>(h2, net.b2, net.ln2g, net.ln2b, net.has_ln, j, net.u2);
+            ln_relu<NN>(h2, net.b2, net.ln2g, net.ln2b, net.has_ln, j, net.u2, net.hidden, net.inv_hidden);
             float z = 0.f;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {

@@ -148,6 +148,50 @@ def test_generic_heads_of_any_shape(emb, use_mfma):
             e.close()
 
 
+def test_custom_width_heads_take_the_mfma_path_and_match_the_oracle(emb):
+    """The reference's automatic training pipeline writes heads of 32 hidden units (examples/custom_model.yml:89 `layer_size: 32`,
+    notebooks/training_models.ipynb: layer_dim = 32; train.py's class default is 128).  In the default family every sigmoid net of up to
+    64 hidden units runs on the MFMA head kernel as a zero-padded 64-unit net whose padding stays out of the LayerNorm statistics --
+    streaming scores and the post-processing fused into that launch against per-stream oracle models, and masked steps bit for bit."""
+    heads = {"custom32": W.synthetic_head("custom32", 21, hidden=32),
+             "gated32": W.synthetic_head("gated32", 22, kind="gated", hidden=32),
+             "plain20": W.synthetic_head("plain20", 23, hidden=20, layernorm=False)}
+    S, n_steps = 37, 9
+    eng = StreamEngine(S, heads, emb)
+    try:
+        info = eng.calibration_info()
+        assert np.isfinite(info["selftest_score_err"]) and info["selftest_score_err"] < 1e-4      # f16-split vs the exact family's generic kernel
+        pcm = W.synthetic_pcm(S, 1280 * n_steps, seed=5)
+        models = oracle_streams(eng, heads, emb, 6)
+        worst = 0.0
+        for t in range(n_steps):
+            x = pcm[:, 1280 * t: 1280 * (t + 1)]
+            got = eng.step(x)
+            for s in range(6):
+                want = as_vec(models[s].predict(x[s]), heads)
+                worst = max(worst, float(np.abs(got[s] - want).max()))
+        assert worst <= TOL_SCORE, worst
+        assert (got[:6] > 0).any()
+    finally:
+        eng.close()
+    # masked steps: a stream that sits steps out equals, bit for bit, a private sequence of its active chunks (cf. test_masked_step.py)
+    a, b = StreamEngine(S, heads, emb), StreamEngine(S, heads, emb)
+    try:
+        rng = np.random.default_rng(9)
+        on = rng.random((n_steps, S)) < 0.4
+        masked = np.stack([a.step_masked(pcm[:, 1280 * t: 1280 * (t + 1)], on[t]) for t in range(n_steps)])
+        counts = on.sum(0)
+        packed = np.zeros((int(counts.max()), S, 1280), np.int16)
+        for s in range(S):
+            packed[:counts[s], s] = pcm[s].reshape(n_steps, 1280)[on[:, s]]
+        plain = np.stack([b.step(p) for p in packed])
+        for s in range(S):
+            ts = np.nonzero(on[:, s])[0]
+            np.testing.assert_array_equal(masked[ts, s], plain[:len(ts), s], err_msg=f"stream {s}")
+    finally:
+        a.close(); b.close()
+
+
 # ------------------------------------------------------------------------------------------- streaming
 def test_streaming_every_layer_and_score(eng, emb, heads, golden):
     S, n_steps = 6, 20
