@@ -138,7 +138,7 @@ def issue_bound(kernel: str, streams: int, avg_ms: float, args):
             "frac_of_available": {k: (round(v, 4) if v is not None else None) for k, v in fr.items()}, "binds": binds,
             "lds_bank_conflict_frac": round(t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0), 4),
             "source": f"profiles/{src} (rocprofv3 --pmc passes of tools/pmc.sh on this workload and this build, src={tab['_csrc_sha16']}); the chip sits at its power cap in this regime "
-                      "(profiles/r04_power.jsonl: 1,354 W of 1,400 W, sclk 1.99 of 2.4 GHz), so ~0.83 of 'available' is the practical ceiling"}
+                      "(profiles/r05_power.jsonl: 1,372 W of 1,400 W, sclk 1.99 of 2.4 GHz), so ~0.83 of 'available' is the practical ceiling"}
 
 
 def make_pcm_pool(torch, dev, S, n_pool, kind, gen, rank):
