@@ -223,3 +223,19 @@ def test_range_error_drops_the_step_and_the_server_carries_on():
         got = [row[0] for _k, row in tap[i]]
         it = iter(sums)
         assert all(any(g == s for s in it) for g in got), f"client {i}"
+
+
+def test_load_driver_dry_run_on_two_server_processes():
+    """tools/serve_load.py (the real-socket load driver of DESIGN.md 5.9) end to end without a GPU: two server processes on one port,
+    two client processes, a stand-in model -- every chunk sent is answered, nothing is left in a backlog."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "serve_load.py"), "--clients", "120", "--seconds", "3", "--procs", "2",
+                        "--server-procs", "2", "--dry-run"], cwd=root, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["connections_accepted"] == 120 and sum(d["connections_per_server"]) == 120 and d["server_processes"] == 2
+    assert d["chunks_sent"] > 500 and d["answers_received"] == d["chunks_sent"] == d["pump"]["stream_steps"]
+    assert d["backlog_chunks_at_end"] == 0 and d["client_errors"] == 0 and d["server_latency_ms"]["p50"] < 200
