@@ -10,9 +10,11 @@ single model's streaming state.  This module keeps the example's wire protocol -
     server -> client   TEXT    {"activations": [...]} for labels scoring >= threshold      (streaming_server.py:62-68)
 
 -- and changes what happens behind it: every connection owns one stream slot of a `BatchedModel` (its own sample tail, conv
-histories, rings and counters on the device), the handler only appends (resampled) samples to the connection's queue, and a single
-pump coroutine gathers one 1280-sample chunk from every connection that has one and runs ONE masked step (`oww_submit_masked`) for
-all of them, two steps in flight (upload of step t+1 while the kernels of step t run).
+histories, rings and counters on the device); the handler appends the message's (resampled) samples to the connection's queue and
+moves each complete 1280-sample chunk into the connection's row of the batch buffer being filled; a single paced pump swaps
+buffers and runs ONE masked step (`oww_submit_masked`) for every row that carries a chunk (two steps in flight when steps are long
+against the round period).  `--workers N` runs N such processes on one port (SO_REUSEPORT), each with its own handle on the GPU:
+one Python event loop carries about two thousand real-time clients (tools/serve_load.py), the GPU a thousand times that.
 A connection without a full chunk sits the step out bit-exactly (no zero padding, no skipped audio), so each client gets exactly the
 scores a private `openwakeword.Model` would have produced on its own audio in 1280-sample calls.
 
