@@ -244,6 +244,18 @@ template <int N> __device__ __forceinline__ float dpp_shr_zero(float x) {
 template <int N> __device__ __forceinline__ float dpp_shl_zero(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xf, 0xf, true));
 }
+// A sum that becomes an element of an MFMA C operand is a build-vector seed for the SLP vectoriser, which pairs the adds into
+// v_pk_add_f32 -- two issue passes all the same, and a form the DPP combiner cannot fold the row shift into (v_mov_b32_dpp stays:
+// 8 passes per tile instead of 4).  Passing the scalar through an empty asm keeps it a plain v_add_f32 (dpp): same arithmetic,
+// bit-identical results, 5..7 % fewer VALU passes per stage.  Same-box A/B at 131,072 streams (profiles/r05_unpaired_ab.txt):
+// stage B -0.9 %, C -1.1 %, D +0.5 %, E +2.8 % (two more spilled registers at three waves per SIMD) -- so B and C (F >= 8) take it.
+#ifndef OWH_UNPAIRED_MIN_F
+#define OWH_UNPAIRED_MIN_F 8
+#endif
+template <int F> __device__ __forceinline__ float unpaired(float s) {
+    if (F >= OWH_UNPAIRED_MIN_F) asm("" : "+v"(s));
+    return s;
+}
 
 // debug dump of the f16-split family (cf. owr::dump_tile): a half last tile keeps channel 16 ct + 2j + e in register e < 2
 template <int NCT, int F, int C>
@@ -410,7 +422,7 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
                     for (int e = 0; e < 4; ++e) {
                         if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
                         const float l = dpp_shr_zero<SH>(accs[0][t][e]);
-                        acc[t][e] = I[e] + ((MASKS && first) ? 0.f : l);
+                        acc[t][e] = unpaired<F>(I[e] + ((MASKS && first) ? 0.f : l));
                     }
                 }
             }
@@ -524,7 +536,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (HOUT && oct == NCTO - 1 && e >= 2) { acc[t][e] = 0.f; continue; }      // padding rows of a half tile
-                        acc[t][e] = I[e] + dpp_shr_zero<SH>(accs[0][t][e]);
+                        acc[t][e] = unpaired<F>(I[e] + dpp_shr_zero<SH>(accs[0][t][e]));
                     }
                 }
             }
