@@ -42,6 +42,7 @@ extern "C" {
 #define OWW_EMB_DIM        96 /* embedding_model.onnx output     (utils.py:323)     */
 #define OWW_SCORE_RING     30 /* prediction_buffer maxlen        (model.py:198)     */
 #define OWW_MAX_HEADS      16
+#define OWW_MAX_HEAD_BLOCKS 8    /* hidden blocks of one head network (train.py:73); the released models have 1 */
 #define OWW_MAX_LABELS     32
 
 typedef struct oww_ctx oww_ctx;
@@ -74,9 +75,12 @@ int  oww_destroy(oww_ctx* h);
  *  mel   : float hann[400]; int32 start[32]; float taps[32][16]          (window + sparse mel filterbank)
  *  embed : for each of the 20 conv layers in graph order: float w[kh][kw][cin][cout] (Keras HWIO),
  *          then for layers 0..18: float scale[cout]; float shift[cout]   (inference BatchNorm folded)
- *  head  : int32 hdr[8] = {kind(0 binary,1 gated,2 multiclass), T, hidden, n_out, has_layernorm,0,0,0}
+ *  head  : int32 hdr[8] = {kind(0 binary,1 gated,2 multiclass), T, hidden, n_out, has_layernorm, extra_blocks,0,0}
  *          then per net (1 net; 2 for gated): w1[T*96][hidden] b1[hidden] (ln1_g ln1_b [hidden] if
- *          has_layernorm) w2[hidden][hidden] b2 (ln2_g ln2_b) w3[hidden][n_out] b3[n_out]
+ *          has_layernorm), then 1 + extra_blocks times { w2[hidden][hidden] b2 (ln2_g ln2_b) }, then w3[hidden][n_out] b3[n_out].
+ *          extra_blocks = 0 is the network of every released model (train.py:27,67: n_blocks = 1); train.py's Net takes any
+ *          n_blocks (train.py:73): extra_blocks = n_blocks - 1, from -1 (no hidden block) to OWW_MAX_HEAD_BLOCKS - 1.  Nets with
+ *          other than one block are evaluated by the generic heads kernel (any kernel family), not by the MFMA head kernels.
  */
 int  oww_load_mel(oww_ctx* h, const void* blob, size_t nbytes);
 int  oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes);

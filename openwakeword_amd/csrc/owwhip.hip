@@ -401,11 +401,13 @@ struct HostBuf {                      // host image of the device weight buffer 
 
 struct NetHost {
     int hidden, n_out, has_ln, T, final_act, head, role, out_col;
-    const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // into the owning head blob
+    int n_blocks;                     // hidden blocks behind the first layer (train.py:73: Net's n_blocks; 1 in every released model)
+    const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // into the owning head blob (w2 .. ln2b: block 0)
+    const float* blocks;              // the n_blocks blocks back to back: w[H][H] b[H] (g[H] be[H])
     int hx_e1 = 0, hx_e2 = 0;         // fp16-split heads: power-of-two scales of w1 / w2 (hx_weight_exp)
 };
 struct HeadHost {
-    int kind, T, hidden, n_out, has_ln;
+    int kind, T, hidden, n_out, has_ln, n_blocks;
     std::vector<float> blob;
     int out_col;
 };
@@ -1264,7 +1266,7 @@ int calibrate_hx(oww_ctx* h, HxCalib& cal) {
         if ((rc = oww_load_embedding(t, h->emb_blob.data(), h->emb_blob.size() * sizeof(float)))) break;
         for (const HeadHost& hh : h->heads) {
             std::vector<float> blob(8 + hh.blob.size());
-            const int32_t hdr[8] = {hh.kind, hh.T, hh.hidden, hh.n_out, hh.has_ln, 0, 0, 0};
+            const int32_t hdr[8] = {hh.kind, hh.T, hh.hidden, hh.n_out, hh.has_ln, hh.n_blocks - 1, 0, 0};
             memcpy(blob.data(), hdr, sizeof hdr);
             memcpy(blob.data() + 8, hh.blob.data(), hh.blob.size() * sizeof(float));
             if ((rc = oww_add_head(t, blob.data(), blob.size() * sizeof(float))) < 0) break;
@@ -1500,10 +1502,12 @@ int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
     const int32_t* hdr = (const int32_t*)blob;
     HeadHost hh{};
     hh.kind = hdr[0]; hh.T = hdr[1]; hh.hidden = hdr[2]; hh.n_out = hdr[3]; hh.has_ln = hdr[4];
-    if (hh.kind < 0 || hh.kind > 2 || hh.T < 1 || hh.T > 120 || hh.hidden < 1 || hh.hidden > 512 || hh.n_out < 1 || hh.n_out > 8)
-        return fail(OWW_EINVAL, "oww_add_head: bad header kind=%d T=%d hidden=%d n_out=%d", hh.kind, hh.T, hh.hidden, hh.n_out);
+    hh.n_blocks = 1 + hdr[5];                  // (hdr[5] = hidden blocks beyond the one every released model has; -1 = none)
+    if (hh.kind < 0 || hh.kind > 2 || hh.T < 1 || hh.T > 120 || hh.hidden < 1 || hh.hidden > 512 || hh.n_out < 1 || hh.n_out > 8 ||
+        hh.n_blocks < 0 || hh.n_blocks > OWW_MAX_HEAD_BLOCKS)
+        return fail(OWW_EINVAL, "oww_add_head: bad header kind=%d T=%d hidden=%d n_out=%d blocks=%d", hh.kind, hh.T, hh.hidden, hh.n_out, hh.n_blocks);
     const size_t in = (size_t)hh.T * 96, H = hh.hidden, O = hh.n_out;
-    const size_t per_net = in * H + H + (hh.has_ln ? 2 * H : 0) + H * H + H + (hh.has_ln ? 2 * H : 0) + H * O + O;
+    const size_t per_net = in * H + H + (hh.has_ln ? 2 * H : 0) + (size_t)hh.n_blocks * (H * H + H + (hh.has_ln ? 2 * H : 0)) + H * O + O;
     const size_t n_nets = hh.kind == 1 ? 2 : 1;
     if (nbytes != 32 + per_net * n_nets * 4)
         return fail(OWW_EINVAL, "oww_add_head: blob is %zu bytes, expected %zu", nbytes, 32 + per_net * n_nets * 4);
@@ -1593,10 +1597,15 @@ int oww_commit(oww_ctx* h) {
             NetHost n{};
             n.hidden = hh.hidden; n.n_out = hh.n_out; n.has_ln = hh.has_ln; n.T = hh.T;
             n.final_act = hh.kind == 2 ? 1 : 0; n.head = (int)hi; n.role = r; n.out_col = col;
+            n.n_blocks = hh.n_blocks;
             n.w1 = q; q += in * H; n.b1 = q; q += H;
             if (hh.has_ln) { n.ln1g = q; q += H; n.ln1b = q; q += H; }
-            n.w2 = q; q += H * H; n.b2 = q; q += H;
-            if (hh.has_ln) { n.ln2g = q; q += H; n.ln2b = q; q += H; }
+            n.blocks = q;
+            if (hh.n_blocks > 0) {                                           // (block 0 by name: what the MFMA head kernels read)
+                n.w2 = q; n.b2 = q + H * H;
+                if (hh.has_ln) { n.ln2g = n.b2 + H; n.ln2b = n.ln2g + H; }
+            }
+            q += (size_t)hh.n_blocks * (H * H + H + (hh.has_ln ? 2 * H : 0));
             n.w3 = q; q += H * O; n.b3 = q; q += O;
             h->nets.push_back(n);
         }
@@ -1743,7 +1752,7 @@ int oww_commit(oww_ctx* h) {
         }
     }
     // heads: natural arrays for every net (+ packed w2 for hidden==64), fast groups
-    struct NetOff { size_t w1, b1, ln1g, ln1b, w2, b2, ln2g, ln2b, w3, b3, w2pk; };
+    struct NetOff { size_t w1, b1, ln1g, ln1b, w2, b2, ln2g, ln2b, w3, b3, w2pk, blocks; };
     std::vector<NetOff> noff(h->nets.size());
     for (size_t ni = 0; ni < h->nets.size(); ++ni) {
         const NetHost& n = h->nets[ni];
@@ -1751,11 +1760,16 @@ int oww_commit(oww_ctx* h) {
         NetOff& o = noff[ni];
         o.w1 = hb.add(n.w1, in * H); o.b1 = hb.add(n.b1, H);
         o.ln1g = n.has_ln ? hb.add(n.ln1g, H) : 0; o.ln1b = n.has_ln ? hb.add(n.ln1b, H) : 0;
-        o.w2 = hb.add(n.w2, H * H); o.b2 = hb.add(n.b2, H);
-        o.ln2g = n.has_ln ? hb.add(n.ln2g, H) : 0; o.ln2b = n.has_ln ? hb.add(n.ln2b, H) : 0;
+        const size_t blk = H * H + H + (n.has_ln ? 2 * H : 0);
+        o.blocks = n.n_blocks > 0 ? hb.add(n.blocks, (size_t)n.n_blocks * blk) : 0;      // (the generic kernel walks them in place)
+        o.w2 = o.b2 = o.ln2g = o.ln2b = 0;
+        if (n.n_blocks > 0) {
+            o.w2 = hb.add(n.w2, H * H); o.b2 = hb.add(n.b2, H);
+            o.ln2g = n.has_ln ? hb.add(n.ln2g, H) : 0; o.ln2b = n.has_ln ? hb.add(n.ln2b, H) : 0;
+        }
         o.w3 = hb.add(n.w3, H * O); o.b3 = hb.add(n.b3, O);
         o.w2pk = 0;
-        if (n.hidden == 64) { std::vector<float> pk; pack_mfma(n.w2, 1, 64, 64, pk); o.w2pk = hb.add(pk); }
+        if (n.hidden == 64 && n.n_blocks == 1) { std::vector<float> pk; pack_mfma(n.w2, 1, 64, 64, pk); o.w2pk = hb.add(pk); }
     }
     // grouping: heads whose nets are all (hidden 64, n_out 1, sigmoid) share a fast group per T (<= 8 nets each)
     h->groups.clear(); h->generic_nets.clear();
@@ -1764,10 +1778,11 @@ int oww_commit(oww_ctx* h) {
     for (size_t hi = 0; hi < h->heads.size(); ++hi) {
         const auto [nb, ne] = h->head_nets[hi];
         bool fast = h->mfma;
-        // the MFMA head kernels: sigmoid nets of one output; exactly 64 hidden units in the fp32 family (heads64_kernel), up to 64 in the
-        // fp16-split family (zero-padded, see FastGroup::d_pad)
+        // the MFMA head kernels: sigmoid nets of one output and one hidden block; exactly 64 hidden units in the fp32 family
+        // (heads64_kernel), up to 64 in the fp16-split family (zero-padded, see FastGroup::d_pad)
         for (int ni = nb; ni < ne; ++ni)
-            fast = fast && (h->nets[ni].hidden == 64 || (h->hx && h->nets[ni].hidden <= 64)) && h->nets[ni].n_out == 1 && h->nets[ni].final_act == 0;
+            fast = fast && (h->nets[ni].hidden == 64 || (h->hx && h->nets[ni].hidden <= 64)) && h->nets[ni].n_out == 1 &&
+                   h->nets[ni].final_act == 0 && h->nets[ni].n_blocks == 1;
         if (!fast) { for (int ni = nb; ni < ne; ++ni) h->generic_nets.push_back(ni); continue; }
         FastGroup* g = nullptr;
         const int cap = h->hx ? 4 : HD_MAXNETS;                      // heads_hx_kernel: at most four nets per launch
@@ -1874,10 +1889,12 @@ int oww_commit(oww_ctx* h) {
         d.head = n.head; d.role = n.role; d.out_col = n.out_col; d.hid_off = hid_off;
         d.w1 = h->d_w + o.w1; d.b1 = h->d_w + o.b1;
         d.ln1g = n.has_ln ? h->d_w + o.ln1g : nullptr; d.ln1b = n.has_ln ? h->d_w + o.ln1b : nullptr;
-        d.w2 = h->d_w + o.w2; d.b2 = h->d_w + o.b2;
-        d.ln2g = n.has_ln ? h->d_w + o.ln2g : nullptr; d.ln2b = n.has_ln ? h->d_w + o.ln2b : nullptr;
+        d.n_blocks = n.n_blocks;
+        d.blocks = n.n_blocks > 0 ? h->d_w + o.blocks : nullptr;
+        d.w2 = n.n_blocks > 0 ? h->d_w + o.w2 : nullptr; d.b2 = n.n_blocks > 0 ? h->d_w + o.b2 : nullptr;
+        d.ln2g = n.has_ln && n.n_blocks > 0 ? h->d_w + o.ln2g : nullptr; d.ln2b = n.has_ln && n.n_blocks > 0 ? h->d_w + o.ln2b : nullptr;
         d.w3 = h->d_w + o.w3; d.b3 = h->d_w + o.b3;
-        d.w2pk = n.hidden == 64 ? h->d_w + o.w2pk : nullptr;
+        d.w2pk = n.hidden == 64 && n.n_blocks == 1 ? h->d_w + o.w2pk : nullptr;
         return d;
     };
     if (!h->nets.empty()) {

@@ -905,7 +905,9 @@ struct NetDesc {
     int head, role;                          // role 0 = primary net, 1 = gate verifier (hey_jarvis style)
     int out_col;                             // first score column of the owning head
     int hid_off;                             // column offset inside the group's hidden matrix (fast path)
-    const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // natural layouts
+    const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // natural layouts (w2 .. ln2b: hidden block 0)
+    int n_blocks;                            // hidden blocks (train.py:73); the MFMA head kernels take nets with exactly one
+    const float* blocks;                     // all of them back to back, w[H][H] b[H] (g[H] be[H]) each: heads_generic_kernel
     const float *w2pk;                       // MFMA-packed [hidden/16][hidden/4][64] (fast path)
 };
 
@@ -1036,29 +1038,33 @@ __global__ __launch_bounds__(64 * GH_WAVES) void heads_generic_kernel(HeadParams
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gh_norm_relu_store(acc, H, m.has_ln, m.ln1g, m.ln1b, hv, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // ---- layer 2
+            // ---- hidden blocks (train.py:56-65 FCNBlock: Linear -> LayerNorm -> ReLU; one in the released models)
+            for (int blk = 0; blk < m.n_blocks; ++blk) {
+                const float* w2 = m.blocks + (size_t)blk * ((size_t)H * H + H + (m.has_ln ? 2 * H : 0));
+                const float* b2 = w2 + (size_t)H * H;
 #pragma unroll
-            for (int i = 0; i < GH_HPL; ++i) {
-                const float bb = lane + 64 * i < H ? m.b2[lane + 64 * i] : 0.f;
+                for (int i = 0; i < GH_HPL; ++i) {
+                    const float bb = lane + 64 * i < H ? b2[lane + 64 * i] : 0.f;
 #pragma unroll
-                for (int s = 0; s < GH_SPW; ++s) acc[s][i] = bb;
+                    for (int s = 0; s < GH_SPW; ++s) acc[s][i] = bb;
+                }
+                for (int k = 0; k < H; ++k) {
+                    float xv[GH_SPW];
+#pragma unroll
+                    for (int s = 0; s < GH_SPW; ++s) xv[s] = hv[s * GH_HMAX + k];
+                    const float* w = w2 + (size_t)k * H;
+#pragma unroll
+                    for (int i = 0; i < GH_HPL; ++i)
+                        if (lane + 64 * i < H) {
+                            const float wv = w[lane + 64 * i];
+#pragma unroll
+                            for (int s = 0; s < GH_SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every lane has read the previous layer's vector
+                gh_norm_relu_store(acc, H, m.has_ln, b2 + H, b2 + 2 * H, hv, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            for (int k = 0; k < H; ++k) {
-                float xv[GH_SPW];
-#pragma unroll
-                for (int s = 0; s < GH_SPW; ++s) xv[s] = hv[s * GH_HMAX + k];
-                const float* w = m.w2 + (size_t)k * H;
-#pragma unroll
-                for (int i = 0; i < GH_HPL; ++i)
-                    if (lane + 64 * i < H) {
-                        const float wv = w[lane + 64 * i];
-#pragma unroll
-                        for (int s = 0; s < GH_SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
-                    }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every lane has read the layer-1 vector
-            gh_norm_relu_store(acc, H, m.has_ln, m.ln2g, m.ln2b, hv, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // ---- output layer: lane o < n_out, the k-ordered chain of the formula; then the final activation per stream
             if (lane < O) {
 #pragma unroll

@@ -52,18 +52,22 @@ def pack_embedding_blob(emb: dict) -> np.ndarray:
 def pack_head_blob(head: dict) -> np.ndarray:
     T, H, O = int(head["T"]), int(head["hidden"]), int(head["n_out"])
     has_ln = head["net"].get("ln1") is not None
-    hdr = np.array([_KIND[head["kind"]], T, H, O, int(has_ln), 0, 0, 0], dtype=np.int32)
+    n_blocks = len(W.net_blocks(head["net"]))             # train.py:73; hdr[5] counts the blocks beyond the released models' one
+    hdr = np.array([_KIND[head["kind"]], T, H, O, int(has_ln), n_blocks - 1, 0, 0], dtype=np.int32)
     parts = [hdr.view(np.float32)]
     nets = [head["net"]] + ([head["net2"]] if head["kind"] == "gated" else [])
     for net in nets:
-        if net["w1"].shape != (T * EMB_DIM, H) or net["w2"].shape != (H, H) or net["w3"].shape != (H, O):
+        blocks = W.net_blocks(net)
+        if net["w1"].shape != (T * EMB_DIM, H) or net["w3"].shape != (H, O) or len(blocks) != n_blocks or \
+                any(w.shape != (H, H) or b.shape != (H,) or (ln is not None) != has_ln for w, b, ln in blocks):
             raise ValueError("head weight shapes do not match its header")
         parts += [net["w1"].ravel(), net["b1"]]
         if has_ln:
             parts += list(net["ln1"])
-        parts += [net["w2"].ravel(), net["b2"]]
-        if has_ln:
-            parts += list(net["ln2"])
+        for w, b, ln in blocks:
+            parts += [w.ravel(), b]
+            if has_ln:
+                parts += list(ln)
         parts += [net["w3"].ravel(), net["b3"]]
     return np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in parts])
 

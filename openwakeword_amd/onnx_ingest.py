@@ -351,26 +351,49 @@ def _walk_linear(fl: _Flow, n: dict, where: str):
     return np.ascontiguousarray(w, np.float32), bias, out
 
 
+MAX_HEAD_BLOCKS = 8     # OWW_MAX_HEAD_BLOCKS of include/owwhip.h
+
+
 def _walk_net(fl: _Flow, first: dict, where: str):
-    """One MLP of train.py:56-83 from its first linear node: Linear -> [LN] -> Relu -> Linear -> [LN] -> Relu -> Linear, then the
-    output activation(s).  Returns (net dict, tail operator names, last tensor)."""
-    net, node = {}, first
-    for li in (1, 2, 3):
+    """One MLP of train.py:56-83 from its first linear node: Linear -> [LN] -> Relu, n_blocks times the same (train.py:73; one block
+    in every released model), a last Linear, then the output activation(s).  A linear layer followed by [LN] + Relu + another linear
+    layer is a hidden layer; the first one that is not is the output layer.  Returns (net dict in the layout of weights.net_blocks,
+    tail operator names, last tensor)."""
+    net, node, hidden_layers = {}, first, []
+    while True:
+        li = len(hidden_layers) + 1
         w, b, cur = _walk_linear(fl, node, f"{where} layer {li}")
-        net[f"w{li}"], net[f"b{li}"] = w, b
-        if li == 3:
+        # hidden layer?  [LayerNorm] -> exactly one Relu -> exactly one linear layer
+        nxt = None
+        try_ln = _peek_hidden(fl, cur, w.shape[1], f"{where} layer {li}")
+        if try_ln is not None:
+            ln, relu_out = try_ln
+            cons = fl.consumers.get(relu_out, [])
+            if len(cons) == 1 and cons[0]["op"] in ("Gemm", "MatMul"):
+                nxt = cons[0]
+        if nxt is None:
+            net["w3"], net["b3"] = w, b
             break
-        ln, cur = _walk_layernorm(fl, cur, w.shape[1], f"{where} layer {li}")
-        net[f"ln{li}"] = ln
-        cons = fl.consumers.get(cur, [])
-        if len(cons) != 1 or cons[0]["op"] != "Relu":
-            fl.refuse(f"{where}: expected exactly one Relu after linear layer {li}, found {[c['op'] for c in cons]}")
-        cons = fl.consumers.get(cons[0]["outputs"][0], [])
-        if len(cons) != 1 or cons[0]["op"] not in ("Gemm", "MatMul"):
-            fl.refuse(f"{where}: expected a linear layer after the Relu of layer {li}, found {[c['op'] for c in cons]}")
-        node = cons[0]
-    if (net["ln1"] is None) != (net["ln2"] is None):
-        fl.refuse(f"{where}: LayerNorm after one hidden layer but not the other")
+        hidden_layers.append((w, b, ln))
+        if len(hidden_layers) > 1 + MAX_HEAD_BLOCKS:
+            fl.refuse(f"{where}: more than {MAX_HEAD_BLOCKS} hidden blocks behind the first layer (train.py's Net with n_blocks > "
+                      f"{MAX_HEAD_BLOCKS}); the head kernels take at most that many")
+        node = nxt
+    if not hidden_layers:
+        fl.refuse(f"{where}: a single linear layer, no hidden layer (expected Linear -> [LN] -> Relu -> ... -> Linear)")
+    if len({ln is None for _w, _b, ln in hidden_layers}) != 1:
+        fl.refuse(f"{where}: LayerNorm after some hidden layers but not the others")
+    (net["w1"], net["b1"], net["ln1"]), blocks = hidden_layers[0], hidden_layers[1:]
+    net["w2"], net["b2"], net["ln2"] = blocks[0] if blocks else (None, None, None)
+    if len(blocks) > 1:
+        net["more"] = [{"w": w, "b": b, "ln": ln} for w, b, ln in blocks[1:]]
+    hidden = net["w1"].shape[1]
+    for k, (w, _b, _ln) in enumerate(blocks):
+        if w.shape != (hidden, hidden):
+            fl.refuse(f"{where}: hidden block {k} maps {w.shape[0]} -> {w.shape[1]} units, the first layer has {hidden} (train.py's "
+                      "blocks are square)")
+    if net["w3"].shape[0] != hidden:
+        fl.refuse(f"{where}: the output layer reads {net['w3'].shape[0]} units, the hidden layers have {hidden}")
     tail = []
     while True:
         cons = fl.consumers.get(cur, [])
@@ -380,13 +403,20 @@ def _walk_net(fl: _Flow, first: dict, where: str):
             tail.append(cons[0]["op"])
             cur = cons[0]["outputs"][0]
         else:
-            # a fourth linear layer (or the LayerNorm in front of it) behind the third: train.py's Net built with n_blocks != 1
-            # (train.py:56-83 accepts any number of hidden blocks) -- name the real cause instead of an odd "output activation"
-            deeper = [c["op"] for c in cons if c["op"] in ("Gemm", "MatMul", "LayerNormalization", "ReduceMean")]
-            if deeper:
-                fl.refuse(f"{where}: the third linear layer is followed by {deeper}: a network with more than two hidden layers (train.py's "
-                          "Net with n_blocks != 1) is not supported by the head kernels (Linear -> [LN] -> ReLU twice, then the output layer)")
             return net, tail, cur
+
+
+def _peek_hidden(fl: _Flow, cur: str, width: int, where: str):
+    """(ln, tensor behind the Relu) if tensor `cur` -- a linear layer's output -- goes through an optional LayerNorm and exactly one
+    Relu, as a hidden layer of train.py:56-83 does; None if it does not (the output layer).  A LayerNorm that is there but is not the
+    one the kernels apply is refused by _walk_layernorm, not skipped."""
+    ln, out = _walk_layernorm(fl, cur, width, where)               # (None, cur) when `cur` is not normalised
+    cons = fl.consumers.get(out, [])
+    if len(cons) == 1 and cons[0]["op"] == "Relu":
+        return ln, cons[0]["outputs"][0]
+    if ln is not None:
+        fl.refuse(f"{where}: expected exactly one Relu after the LayerNorm, found {[c['op'] for c in cons]}")
+    return None
 
 
 GATE_THRESHOLD = 0.5   # docs/models/hey_jarvis.md:38: the verifier network replaces the score where the first network is > 0.5
@@ -416,6 +446,11 @@ def load_head(path: str) -> dict:
     cons = fl.consumers.get(feats, [])
     lin = [c for c in cons if c["op"] in ("Gemm", "MatMul")]
     ifs = [n for n in g["nodes"] if n["op"] == "If"]
+    rec = sorted({n["op"] for n in g["nodes"] if n["op"] in ("LSTM", "GRU", "RNN")})
+    if rec:
+        # train.py:85-98: model_type = "rnn" (two bidirectional LSTM layers over the T feature rows, then a linear layer)
+        fl.refuse(f"a recurrent network ({', '.join(rec)}: train.py's model_type 'rnn'); the head kernels evaluate the fully connected "
+                  "form (model_type 'dnn', train.py:56-83) only")
     if not lin:
         fl.refuse(f"no linear layer consumes the (flattened) input; found {[c['op'] for c in cons]}")
     if len(lin) > 2 or len(lin) + len(ifs) > 2:
@@ -425,8 +460,6 @@ def load_head(path: str) -> dict:
     if rem:
         fl.refuse(f"first layer input {net['w1'].shape[0]} is not a multiple of {W.EMB_DIM}")
     hidden, n_out = net["w1"].shape[1], net["w3"].shape[1]
-    if net["w2"].shape != (hidden, hidden) or net["w3"].shape[0] != hidden:
-        fl.refuse(f"layer shapes {net['w1'].shape}, {net['w2'].shape}, {net['w3'].shape}")
     net2 = None
     if len(lin) == 2 or ifs:
         if ifs:
@@ -436,12 +469,14 @@ def load_head(path: str) -> dict:
             if tail2 != tail:
                 fl.refuse(f"the two networks of a gated model end differently: {tail} / {tail2}")
             s_out = _gate_where(fl, s1, s2)
-        for k in ("w1", "w2", "w3"):
+        for k in ("w1", "w3"):
             if net2[k].shape != net[k].shape:
                 fl.refuse(f"the two networks of a gated model differ in shape: {net[k].shape} / {net2[k].shape}")
+        if len(W.net_blocks(net2)) != len(W.net_blocks(net)):
+            fl.refuse(f"the two networks of a gated model differ in depth: {len(W.net_blocks(net))} / {len(W.net_blocks(net2))} hidden blocks")
         if (net2["ln1"] is None) != (net["ln1"] is None):
             fl.refuse("LayerNorm in one network of a gated model but not the other")
-    # the activations the kernels apply are fixed (Linear -> [LN] -> ReLU twice, then Sigmoid, or ReLU + Softmax for a multiclass
+    # the activations the kernels apply are fixed (Linear -> [LN] -> ReLU per hidden layer, then Sigmoid, or ReLU + Softmax for a multiclass
     # model): the file must have exactly them
     if tail == ["Sigmoid"]:
         kind = "gated" if net2 is not None else "binary"

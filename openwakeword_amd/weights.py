@@ -149,8 +149,19 @@ def embedding_param_count(emb: dict) -> int:
     return int(sum(w.size for w in emb["conv"]) + sum(sum(a.size for a in t) for t in emb["bn"]))
 
 
+def net_blocks(net: dict) -> list:
+    """The hidden blocks of a head network in order, as (w [H, H], b [H], ln or None): block 0 under the keys every released model
+    has ('w2', 'b2', 'ln2'; absent or None for a network without hidden block), further ones (train.py:73, n_blocks > 1) in
+    net['more'] = [{'w', 'b', 'ln'}, ...]."""
+    if net.get("w2") is None:
+        if net.get("more"):
+            raise ValueError("head network with further hidden blocks but no first one")
+        return []
+    return [(net["w2"], net["b2"], net.get("ln2"))] + [(m["w"], m["b"], m.get("ln")) for m in net.get("more") or []]
+
+
 def _synthetic_mlp(r: np.random.Generator, n_in: int, hidden: int, n_out: int, layernorm: bool,
-                   out_gain: float = 8.0) -> dict:
+                   out_gain: float = 8.0, n_blocks: int = 1) -> dict:
     def lin(i, o, gain=1.0):
         return (r.normal(0.0, gain / np.sqrt(i), size=(i, o)).astype(np.float32),
                 r.normal(0.0, 0.1, size=o).astype(np.float32))
@@ -161,16 +172,26 @@ def _synthetic_mlp(r: np.random.Generator, n_in: int, hidden: int, n_out: int, l
     w1, b1 = lin(n_in, hidden)
     w2, b2 = lin(hidden, hidden, 1.4)
     w3, b3 = lin(hidden, n_out, out_gain)
-    return {"w1": w1, "b1": b1, "ln1": ln(hidden) if layernorm else None,
-            "w2": w2, "b2": b2, "ln2": ln(hidden) if layernorm else None,
-            "w3": w3, "b3": b3}
+    net = {"w1": w1, "b1": b1, "ln1": ln(hidden) if layernorm else None,
+           "w2": w2, "b2": b2, "ln2": ln(hidden) if layernorm else None,
+           "w3": w3, "b3": b3}
+    if n_blocks == 0:                                   # (drawn all the same, so that the other layers do not depend on n_blocks)
+        net["w2"] = net["b2"] = net["ln2"] = None
+    more = []
+    for _ in range(max(0, n_blocks - 1)):
+        w, b = lin(hidden, hidden, 1.4)
+        more.append({"w": w, "b": b, "ln": ln(hidden) if layernorm else None})
+    if more:
+        net["more"] = more
+    return net
 
 
 def synthetic_head(name: str, seed: int = 1234, kind: Optional[str] = None, T: Optional[int] = None,
                    hidden: Optional[int] = None, n_out: Optional[int] = None,
-                   layernorm: Optional[bool] = None) -> dict:
+                   layernorm: Optional[bool] = None, n_blocks: int = 1) -> dict:
     """Random-init wakeword head with the catalogue shape of `name` (102,849 params for the binary
-    heads, docs/models/alexa.md:26-29).  Unknown names get the standard binary shape."""
+    heads, docs/models/alexa.md:26-29).  Unknown names get the standard binary shape.  n_blocks: hidden blocks of
+    train.py:73 (1 in the released models)."""
     base = name.split("_v0")[0]
     cat = HEAD_CATALOGUE.get(base, ("binary", 16, 64, 1, True))
     kind = kind or cat[0]
@@ -181,9 +202,9 @@ def synthetic_head(name: str, seed: int = 1234, kind: Optional[str] = None, T: O
     r = _rng(seed, f"head:{base}")
     head = {"kind": kind, "T": int(T), "hidden": int(hidden), "n_out": int(n_out),
             "net": _synthetic_mlp(r, T * EMB_DIM, hidden, n_out, layernorm,
-                                  out_gain=0.5 if kind == "multiclass" else 8.0)}
+                                  out_gain=0.5 if kind == "multiclass" else 8.0, n_blocks=n_blocks)}
     if kind == "gated":
-        head["net2"] = _synthetic_mlp(r, T * EMB_DIM, hidden, n_out, layernorm)
+        head["net2"] = _synthetic_mlp(r, T * EMB_DIM, hidden, n_out, layernorm, n_blocks=n_blocks)
     # Conditioning of the synthetic data only: random heads sit far from 0.5 on the synthetic
     # embedding's (large, static) mean vector.  For the default seed the output biases are shifted by
     # minus the mean logit measured once on the three fixture clips, so that scores swing either
@@ -201,6 +222,9 @@ def head_param_count(head: dict) -> int:
         n = 0
         for k, v in net.items():
             if v is None:
+                continue
+            if k == "more":
+                n += sum(m["w"].size + m["b"].size + (sum(a.size for a in m["ln"]) if m.get("ln") is not None else 0) for m in v)
                 continue
             n += sum(a.size for a in v) if isinstance(v, tuple) else v.size
         return n

@@ -275,17 +275,27 @@ def _layernorm(x, g, b):
     return (x - mu) / np.sqrt(var + x.dtype.type(LN_EPS)) * g + b
 
 
+def net_blocks(net):
+    """Hidden blocks of a head network as (w, b, ln): 'w2' / 'b2' / 'ln2' (None = no hidden block), then net['more'] = [{'w', 'b',
+    'ln'}, ...] for train.py:73's n_blocks > 1."""
+    if net.get("w2") is None:
+        return []
+    return [(net["w2"], net["b2"], net.get("ln2"))] + [(m["w"], m["b"], m.get("ln")) for m in net.get("more") or []]
+
+
 def _mlp(x, net, dtype):
-    """Flatten -> Linear -> [LN] -> ReLU -> Linear -> [LN] -> ReLU -> Linear  (train.py:66-83)."""
+    """Flatten -> Linear -> [LN] -> ReLU -> n_blocks x (Linear -> [LN] -> ReLU) -> Linear  (train.py:56-83; n_blocks = 1 in the
+    released models)."""
     h = x.reshape(x.shape[0], -1).astype(dtype)
     h = h @ net["w1"].astype(dtype) + net["b1"].astype(dtype)
     if net.get("ln1") is not None:
         h = _layernorm(h, net["ln1"][0].astype(dtype), net["ln1"][1].astype(dtype))
     h = np.maximum(h, dtype(0))
-    h = h @ net["w2"].astype(dtype) + net["b2"].astype(dtype)
-    if net.get("ln2") is not None:
-        h = _layernorm(h, net["ln2"][0].astype(dtype), net["ln2"][1].astype(dtype))
-    h = np.maximum(h, dtype(0))
+    for w, b, ln in net_blocks(net):
+        h = h @ w.astype(dtype) + b.astype(dtype)
+        if ln is not None:
+            h = _layernorm(h, ln[0].astype(dtype), ln[1].astype(dtype))
+        h = np.maximum(h, dtype(0))
     return h @ net["w3"].astype(dtype) + net["b3"].astype(dtype)
 
 

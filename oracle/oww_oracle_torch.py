@@ -42,10 +42,11 @@ class TorchCpuPort:
     @staticmethod
     def _head_tensors(h):
         def net(n):
-            d = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in n.items()}
-            for k in ("ln1", "ln2"):
-                if n.get(k) is not None:
-                    d[k] = tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in n[k])
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+            d = {k: (tt(v) if isinstance(v, np.ndarray) else v) for k, v in n.items()}
+            if n.get("ln1") is not None:
+                d["ln1"] = tuple(tt(a) for a in n["ln1"])
+            d["blocks"] = [(tt(w), tt(b), None if ln is None else tuple(tt(a) for a in ln)) for w, b, ln in O.net_blocks(n)]
             return d
         out = {"net": net(h["net"])}
         if "net2" in h:
@@ -87,9 +88,10 @@ class TorchCpuPort:
             x = feats.reshape(feats.shape[0], -1) @ n["w1"] + n["b1"]
             if n.get("ln1") is not None:
                 x = TF.layer_norm(x, (x.shape[1],), n["ln1"][0], n["ln1"][1], O.LN_EPS)
-            x = torch.relu(x) @ n["w2"] + n["b2"]
-            if n.get("ln2") is not None:
-                x = TF.layer_norm(x, (x.shape[1],), n["ln2"][0], n["ln2"][1], O.LN_EPS)
+            for w, b, ln in n["blocks"]:
+                x = torch.relu(x) @ w + b
+                if ln is not None:
+                    x = TF.layer_norm(x, (x.shape[1],), ln[0], ln[1], O.LN_EPS)
             return torch.relu(x) @ n["w3"] + n["b3"]
 
         if hd["kind"] == "multiclass":

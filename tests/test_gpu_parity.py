@@ -123,13 +123,19 @@ def test_multiclass_and_wide_heads(emb):
 @pytest.mark.parametrize("use_mfma", [3, 1])
 def test_generic_heads_of_any_shape(emb, use_mfma):
     """The generic heads kernel (one wave per four streams, hidden units over the lanes): hidden sizes that are not multiples of 64, the
-    512 maximum, with and without LayerNorm, a gated pair and a multiclass head outside the fast form, batches that do not fill the
-    last wave -- against the float64 head of the oracle (model.py:299-302, train.py:56-83)."""
+    512 maximum, with and without LayerNorm, a gated pair and a multiclass head outside the fast form, networks of 0, 2, 3 and 8 hidden
+    blocks (a 64-unit sigmoid net with other than one block leaves the MFMA path), batches that do not fill the last wave -- against
+    the float64 head of the oracle (model.py:299-302, train.py:56-83)."""
     shapes = {"odd48": dict(kind="binary", T=5, hidden=48, n_out=1, layernorm=True),
               "odd100": dict(kind="binary", T=16, hidden=100, n_out=1, layernorm=False),
               "wide512": dict(kind="multiclass", T=3, hidden=512, n_out=8, layernorm=True),
               "gated96": dict(kind="gated", T=16, hidden=96, n_out=1, layernorm=True),
-              "tiny1": dict(kind="binary", T=1, hidden=1, n_out=1, layernorm=False)}
+              "tiny1": dict(kind="binary", T=1, hidden=1, n_out=1, layernorm=False),
+              # train.py:67-73: any number of hidden blocks behind the first layer (1 in the released models)
+              "deep3": dict(kind="binary", T=16, hidden=64, n_out=1, layernorm=True, n_blocks=3),
+              "flat0": dict(kind="binary", T=16, hidden=64, n_out=1, layernorm=True, n_blocks=0),
+              "deep2gated": dict(kind="gated", T=4, hidden=40, n_out=1, layernorm=True, n_blocks=2),
+              "deep8multi": dict(kind="multiclass", T=2, hidden=130, n_out=5, layernorm=False, n_blocks=8)}
     heads = {n: W.synthetic_head(n, 7 + i, **kw) for i, (n, kw) in enumerate(shapes.items())}
     rng = np.random.default_rng(12)
     for S in (1, 5, 18):                                   # the last wave of four streams partly filled

@@ -731,16 +731,81 @@ def test_heads_written_by_pytorchs_own_exporter_load_to_the_same_weights(tmp_pat
     np.testing.assert_allclose(want.reshape(ref.shape), ref, rtol=0, atol=2e-6)
 
 
-def test_a_torch_exported_head_with_two_blocks_is_refused_not_misread(tmp_path):
-    """n_blocks = 2 (train.py:70) is a network the kernels do not implement: the reader must say so instead of dropping a layer."""
-    pytest.importorskip("torch")
-    head = W.synthetic_head("alexa", 92)
-    path = os.path.join(tmp_path, "two_blocks.onnx")
+@pytest.mark.parametrize("name,n_blocks,opset,hidden", [("alexa", 2, 17, None), ("alexa", 3, 13, 32), ("alexa", 0, 17, None), ("timer", 2, 12, 48),
+                                                       ("hey_mycroft", 0, 11, 32)])
+def test_torch_exported_heads_of_any_depth_load_to_the_same_network(tmp_path, name, n_blocks, opset, hidden):
+    """train.py:67-73: Net takes any n_blocks (hidden blocks Linear -> LayerNorm -> ReLU behind the first layer; 1 in the released
+    models).  The reader must return every block, in order, bit for bit -- not drop one, and not mistake a hidden layer for the output
+    layer -- and the oracle must compute with the loaded head what torch computed."""
+    torch = pytest.importorskip("torch")
+    head = W.synthetic_head(name, 92, n_blocks=n_blocks, hidden=hidden)
+    assert len(W.net_blocks(head["net"])) == n_blocks
+    module = _torch_head(head["net"], head["T"], head["n_out"])
+    path = os.path.join(tmp_path, f"{name}_{n_blocks}_blocks.onnx")
     try:
-        _torch_export(_torch_head(head["net"], head["T"], 1, n_blocks=2), head["T"], path, 17)
+        _torch_export(module, head["T"], path, opset)
     except Exception as e:                                  # noqa: BLE001
         pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
-    with pytest.raises(ValueError):
+    got = onnx_ingest.load_head(path)
+    assert (got["kind"], got["T"], got["hidden"], got["n_out"]) == (head["kind"], head["T"], head["hidden"], head["n_out"])
+    for k in ("w1", "b1", "w3", "b3"):
+        np.testing.assert_array_equal(got["net"][k], head["net"][k], err_msg=k)
+    want_blocks, got_blocks = W.net_blocks(head["net"]), W.net_blocks(got["net"])
+    assert len(got_blocks) == n_blocks
+    for bi, ((w, b, ln), (w2, b2, ln2)) in enumerate(zip(want_blocks, got_blocks)):
+        np.testing.assert_array_equal(w, w2, err_msg=f"block {bi} weight")
+        np.testing.assert_array_equal(b, b2, err_msg=f"block {bi} bias")
+        assert (ln is None) == (ln2 is None)
+        if ln is not None:
+            np.testing.assert_array_equal(ln[0], ln2[0]); np.testing.assert_array_equal(ln[1], ln2[1])
+    feats = np.random.default_rng(3).normal(0, 2, (6, head["T"], 96)).astype(np.float32)
+    want = O.head_stage(feats, head, np.float32)
+    np.testing.assert_array_equal(O.head_stage(feats, got, np.float32), want)
+    with torch.no_grad():
+        ref = module.eval()(torch.from_numpy(feats)).numpy()
+    np.testing.assert_allclose(want.reshape(ref.shape), ref, rtol=0, atol=2e-6)
+    # the C ABI blob carries the depth in its header (include/owwhip.h: hdr[5] = blocks beyond the first)
+    from openwakeword_amd import engine
+    blob = engine.pack_head_blob(got)
+    assert blob[:8].view(np.int32)[5] == n_blocks - 1
+    H, O_, T = head["hidden"], head["n_out"], head["T"]
+    ln_n = 2 * H if head["net"]["ln1"] is not None else 0
+    assert blob.size == 8 + T * 96 * H + H + ln_n + n_blocks * (H * H + H + ln_n) + H * O_ + O_
+
+
+def test_the_recurrent_model_type_is_refused_by_name(tmp_path):
+    """train.py:85-98: model_type = 'rnn' is a two-layer bidirectional LSTM over the feature rows -- not a network the head kernels run."""
+    torch = pytest.importorskip("torch")
+
+    class Rnn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer1 = torch.nn.LSTM(96, 64, num_layers=2, bidirectional=True, batch_first=True, dropout=0.0)
+            self.layer2 = torch.nn.Linear(128, 1)
+            self.layer3 = torch.nn.Sigmoid()
+
+        def forward(self, x):
+            out, _h = self.layer1(x)
+            return self.layer3(self.layer2(out[:, -1]))
+
+    path = os.path.join(tmp_path, "rnn.onnx")
+    try:
+        _torch_export(Rnn().eval(), 16, path, 13)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    with pytest.raises(ValueError, match="recurrent network"):
+        onnx_ingest.load_head(path)
+
+
+def test_a_head_deeper_than_the_kernels_take_is_refused_by_name(tmp_path):
+    pytest.importorskip("torch")
+    head = W.synthetic_head("alexa", 92, hidden=16)
+    path = os.path.join(tmp_path, "ten_blocks.onnx")
+    try:
+        _torch_export(_torch_head(head["net"], head["T"], 1, n_blocks=onnx_ingest.MAX_HEAD_BLOCKS + 1), head["T"], path, 17)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    with pytest.raises(ValueError, match="hidden blocks"):
         onnx_ingest.load_head(path)
 
 

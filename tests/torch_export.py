@@ -43,7 +43,7 @@ def torch_export_head(module, T, path, opset):
     export(module, torch.rand(T, 96)[None, ], path, opset, output_names=["out"])
 
 
-def torch_head(net, T, n_out, n_blocks=1):
+def torch_head(net, T, n_out, n_blocks=None):
     """The architecture of train.py:56-83 (flatten, Linear + LayerNorm + ReLU, blocks of the same, Linear, Sigmoid | ReLU) with the
     given weights; multiclass models end in ReLU and are exported under a softmax wrapper (train.py:152-165)."""
     import torch
@@ -68,7 +68,9 @@ def torch_head(net, T, n_out, n_blocks=1):
             super().__init__()
             self.flatten = nn.Flatten()
             self.first = Block(net["w1"], net["b1"], net["ln1"])
-            self.blocks = nn.ModuleList([Block(net["w2"], net["b2"], net["ln2"]) for _ in range(n_blocks)])
+            # (n_blocks = None: the network's own hidden blocks, weights.net_blocks; a number: that many copies of block 0)
+            blocks = W.net_blocks(net) if n_blocks is None else [(net["w2"], net["b2"], net["ln2"])] * n_blocks
+            self.blocks = nn.ModuleList([Block(w, b, ln) for w, b, ln in blocks])
             self.last = nn.Linear(net["w3"].shape[0], n_out)
             self.last_act = nn.Sigmoid() if n_out == 1 else nn.ReLU()
             with torch.no_grad():
