@@ -36,8 +36,9 @@ VAD_CASES = [
 
 # The reference on real model FILES (tests/golden/make_golden_onnx.py): heads written by PyTorch's exporter under these names and
 # opsets (13 and older: decomposed LayerNorm; 17: the fused operator), loaded BY PATH; multiclass = the catalogue's timer shape.
-ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom", "jarvis_custom", "jarvis_custom_if"]
-ONNX_HEAD_OPSETS = {"alexa_custom": 13, "mycroft_custom": 17, "timer_custom": 12, "jarvis_custom": 13, "jarvis_custom_if": 13}
+ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom", "jarvis_custom", "jarvis_custom_if", "deep2_custom", "flat0_custom"]
+ONNX_HEAD_OPSETS = {"alexa_custom": 13, "mycroft_custom": 17, "timer_custom": 12, "jarvis_custom": 13, "jarvis_custom_if": 13,
+                    "deep2_custom": 17, "flat0_custom": 13}
 ONNX_FILE_CASES = [
     ("f1280", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=1280)),
     ("f1280j", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=1280)),
@@ -49,6 +50,8 @@ ONNX_FILE_CASES = [
     # hey_jarvis-style verifier routing (docs/models/hey_jarvis.md:38) as torch.where and as a scripted branch (an ONNX If)
     ("fjarvis", ["jarvis_custom", "alexa_custom"], "hey_jane", dict(chunk_size=1280)),
     ("fjarvisif", ["jarvis_custom_if"], "hey_jane", dict(chunk_size=1280)),
+    # train.py:67-73: Net(n_blocks) -- two hidden blocks of 32 units (the training pipeline's width) and none at all
+    ("fdeep", ["deep2_custom", "flat0_custom", "alexa_custom"], "hey_jane", dict(chunk_size=1280)),
 ]
 
 
@@ -57,7 +60,10 @@ def onnx_file_weights():
     from openwakeword_amd import weights as W
     base = {"alexa_custom": "alexa", "mycroft_custom": "hey_mycroft", "timer_custom": "timer", "jarvis_custom": "hey_jarvis",
             "jarvis_custom_if": "hey_jarvis"}
-    return {"embedding": W.synthetic_embedding(SEED_WEIGHTS), "heads": {n: W.synthetic_head(b, SEED_WEIGHTS) for n, b in base.items()}}
+    heads = {n: W.synthetic_head(b, SEED_WEIGHTS) for n, b in base.items()}
+    heads["deep2_custom"] = W.synthetic_head("deep2", SEED_WEIGHTS, hidden=32, n_blocks=2)
+    heads["flat0_custom"] = W.synthetic_head("flat0", SEED_WEIGHTS, n_blocks=0)
+    return {"embedding": W.synthetic_embedding(SEED_WEIGHTS), "heads": heads}
 
 # direct predict() calls of ragged sizes, empty calls included (model.py:232-386 on whatever the caller hands over)
 ONNX_SEQUENCE = ("fseq", ["alexa_custom", "timer_custom"], "hey_jane",
