@@ -469,6 +469,7 @@ struct oww_ctx {
     std::vector<int> generic_nets;    // indices into nets (with verifier right after its primary)
     NetDesc* d_generic = nullptr;
     int generic_hmax = 0;
+    int generic_spw = 0;              // OWW_GENERIC_SPW: 4 / 16 pins the generic heads kernel's shape, 0 = by launch size
     // state
     float* d_state[N_STATE] = {};
     float* d_tmpl[N_STATE] = {};
@@ -755,6 +756,17 @@ int run_cnn(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
 int heads_lds_bytes(int NH) { return (HD_SB * 100 + 2 * HD_SB * (NH + 4) + HD_SB * HD_MAXNETS) * 4; }
 
 // heads over streams [0,n_active): ring mode (ext == nullptr) or external features
+// heads_generic_kernel in the shape that fits the launch (owwhip_kernels.h): <4 streams per wave, 4 waves> below GH_BIG_STREAMS
+// streams, <16, 2> from there on when no head is wider than 128 hidden units (its accumulator registers are sized for that:
+// train.py's default width and the released multiclass models).  OWW_GENERIC_SPW=4|16 pins one -- tests run both on the same inputs.
+// hs = LDS stride of a hidden vector.
+void launch_generic_heads(oww_ctx* h, const HeadParams& p, int n_active, int nb, int ne, hipStream_t st) {
+    const int hs = (std::max(h->generic_hmax, 1) + 3) & ~3;
+    const bool big = h->generic_hmax <= 128 && (h->generic_spw == 16 || (h->generic_spw == 0 && n_active >= GH_BIG_STREAMS));
+    if (big) hipLaunchKernelGGL((heads_generic_kernel<16, 2, 2>), dim3((n_active + 31) / 32), dim3(128), gh_lds_bytes(16, 2, hs), st, p, nb, ne, hs);
+    else hipLaunchKernelGGL((heads_generic_kernel<4, 4>), dim3((n_active + 15) / 16), dim3(256), gh_lds_bytes(4, 4, hs), st, p, nb, ne, hs);
+}
+
 int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, int only_head, float* raw_out, int force_generic) {
     hipStream_t st = h->stream;
     Timed t(h, 6);
@@ -823,7 +835,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
         p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
         int nb = 0, ne = (int)h->nets.size();
         if (only_head >= 0) { nb = h->head_nets[only_head].first; ne = h->head_nets[only_head].second; }
-        hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + GH_SPW * GH_WAVES - 1) / (GH_SPW * GH_WAVES)), dim3(64 * GH_WAVES), 0, st, p, nb, ne);
+        launch_generic_heads(h, p, n_active, nb, ne, st);
     } else if (!h->generic_nets.empty()) {
         for (size_t hi = 0; hi < h->heads.size(); ++hi) {
             if (only_head >= 0 && (int)hi != only_head) continue;
@@ -831,7 +843,7 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
             if (std::find(h->generic_nets.begin(), h->generic_nets.end(), nb) == h->generic_nets.end()) continue;
             HeadParams p = base;
             p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
-            hipLaunchKernelGGL(heads_generic_kernel, dim3((n_active + GH_SPW * GH_WAVES - 1) / (GH_SPW * GH_WAVES)), dim3(64 * GH_WAVES), 0, st, p, nb, ne);
+            launch_generic_heads(h, p, n_active, nb, ne, st);
         }
     }
     HIPCHK(hipGetLastError());
@@ -1986,6 +1998,7 @@ int oww_commit(oww_ctx* h) {
     h->fuse = h->hx && !getenv("OWW_NO_FUSE");
     if (const char* e = getenv("OWW_SMALL_WGS")) h->small_wgs = atoi(e);
     if (const char* e = getenv("OWW_SMALL_WGS_HEADS")) h->small_wgs_heads = atoi(e);
+    if (const char* e = getenv("OWW_GENERIC_SPW")) { const int v = atoi(e); h->generic_spw = v == 4 || v == 16 ? v : 0; }
     if (const char* e = getenv("OWW_RING3_ALWAYS")) for (int i = 0; i < 4; ++i) h->ring3_always[i] = strchr(e, "BCDE"[i]) != nullptr;
     h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
     if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;

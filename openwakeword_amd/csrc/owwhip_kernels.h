@@ -941,16 +941,22 @@ __device__ __forceinline__ void store_raw(const HeadParams& p, int s, int col, f
     *o = p.accumulate_max ? fmaxf(*o, v) : v;
 }
 
-// generic (any T / hidden <= 512 / n_out <= 8 / LN / softmax): ONE WAVE per GH_SPW streams, the hidden units spread over the lanes (unit
-// o = lane + 64 i).  Layer 1 walks the T x 96 features in order -- every hidden unit's sum is the k-ordered fmaf chain of the reference
-// formula -- with the feature value broadcast from LDS and the weight row w1[k][.] read coalesced, once per GH_SPW streams; layer 2 the
-// same on the hidden vector in LDS; LayerNorm sums by wave reduction.  (Rounds 1-4 ran one THREAD per stream with its hidden vectors in a
-// global scratch buffer: 0.4 M dependent memory round trips per stream for the multiclass `timer` head -- 70 ms per launch on 32
-// streams, which oww_commit's calibration and self-test issue 66 times: creating a handle with such a head took 4.5 s.)
-constexpr int GH_SPW = 4;            // streams per wave
-constexpr int GH_WAVES = 4;          // waves per workgroup
+// generic (any T / hidden <= 512 / n_out <= 8 / LN / softmax / 0..8 hidden blocks): ONE WAVE per SPW streams, the hidden units spread
+// over the lanes (unit o = lane + 64 i).  Layer 1 walks the T x 96 features in order -- every hidden unit's sum is the k-ordered fmaf
+// chain of the reference formula -- with the feature values broadcast from LDS (four k per read) and the weight row w1[k][.] read
+// coalesced, once per SPW streams; the hidden blocks the same on the hidden vector in LDS; LayerNorm sums by wave reduction.
+// Two shapes of one template: <4 streams, 4 waves> for small batches (calibration probes, single streams: more waves in flight) and
+// <16, 2> from GH_BIG_STREAMS streams on -- every weight value read from L2 then feeds 16 streams' FMAs instead of 4 (the multiclass
+// `timer` head, T = 34 x 128 hidden units, at 131,072 streams: 24.3 ms with four streams per wave).  Per-stream arithmetic is the
+// same in both, so results do not depend on the shape.  LDS is dynamic: [WAVES][SPW] x (96 features + hs hidden + 8 outputs).
+// The big shape is built with accumulator registers for 128 hidden units (HPL = 2: train.py's default width and the released
+// multiclass models); with registers for 512 it spills inside the feature loop, so wider nets keep the small shape at any batch.
+// (Rounds 1-4 ran one THREAD per stream with its hidden vectors in a global scratch buffer: 0.4 M dependent memory round trips per
+// stream for `timer` -- 70 ms per launch on 32 streams, which oww_commit's calibration and self-test issue 66 times.)
 constexpr int GH_HMAX = 512;         // oww_add_head refuses hidden > 512
 constexpr int GH_HPL = GH_HMAX / 64; // hidden units per lane
+constexpr int GH_BIG_STREAMS = 2048; // launches of at least this many streams take the <16, 2> shape
+inline size_t gh_lds_bytes(int spw, int waves, int hs) { return (size_t)waves * spw * (96 + hs + 8) * sizeof(float); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -959,44 +965,50 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // LayerNorm (optional) + ReLU of the hidden vectors held as acc[stream][i] <-> unit lane + 64 i; then into LDS hv[stream][unit]
-__device__ __forceinline__ void gh_norm_relu_store(float (&acc)[GH_SPW][GH_HPL], int H, int has_ln, const float* __restrict__ g,
-                                                   const float* __restrict__ b, float* hv /*[GH_SPW][GH_HMAX]*/, int lane) {
+template <int SPW, int HPL>
+__device__ __forceinline__ void gh_norm_relu_store(float (&acc)[SPW][HPL], int H, int has_ln, const float* __restrict__ g,
+                                                   const float* __restrict__ b, float* hv /*[SPW][hs]*/, int hs, int lane) {
 #pragma unroll
-    for (int s = 0; s < GH_SPW; ++s) {
+    for (int s = 0; s < SPW; ++s) {
         if (has_ln) {
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) sum += acc[s][i];
+            for (int i = 0; i < HPL; ++i) if (lane + 64 * i < H) sum += acc[s][i];
             const float mu = wave_sum(sum) / (float)H;
             float var = 0.f;
 #pragma unroll
-            for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) { const float d = acc[s][i] - mu; var = fmaf(d, d, var); }
+            for (int i = 0; i < HPL; ++i) if (lane + 64 * i < H) { const float d = acc[s][i] - mu; var = fmaf(d, d, var); }
             const float rs = 1.0f / sqrtf(wave_sum(var) / (float)H + 1e-5f);
 #pragma unroll
-            for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) acc[s][i] = (acc[s][i] - mu) * rs * g[lane + 64 * i] + b[lane + 64 * i];
+            for (int i = 0; i < HPL; ++i) if (lane + 64 * i < H) acc[s][i] = (acc[s][i] - mu) * rs * g[lane + 64 * i] + b[lane + 64 * i];
         }
 #pragma unroll
-        for (int i = 0; i < GH_HPL; ++i) if (lane + 64 * i < H) hv[s * GH_HMAX + lane + 64 * i] = fmaxf(acc[s][i], 0.f);
+        for (int i = 0; i < HPL; ++i) if (lane + 64 * i < H) hv[s * hs + lane + 64 * i] = fmaxf(acc[s][i], 0.f);
     }
 }
 
-__global__ __launch_bounds__(64 * GH_WAVES) void heads_generic_kernel(HeadParams p, int net_begin, int net_end) {
-    __shared__ float s_x[GH_WAVES][GH_SPW][96];
-    __shared__ float s_h[GH_WAVES][GH_SPW * GH_HMAX];
-    __shared__ float s_z[GH_WAVES][GH_SPW][8];
+template <int SPW, int WAVES, int HPL = GH_HPL>       // HPL = hidden units per lane the registers are sized for (hidden <= 64 HPL)
+// (the big shape is held to two waves per SIMD: left alone the compiler unrolls the feature loop into 300-400 registers, one wave per SIMD)
+__global__ __launch_bounds__(64 * WAVES, SPW >= 16 ? 2 : 1) void heads_generic_kernel(HeadParams p, int net_begin, int net_end, int hs) {
+    typedef float f32x4g __attribute__((ext_vector_type(4)));
+    static_assert(SPW <= 64, "one lane per stream finishes the output layer");
+    extern __shared__ __attribute__((aligned(16))) float gh_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s0 = (blockIdx.x * GH_WAVES + wave) * GH_SPW;
+    const int s0 = (blockIdx.x * WAVES + wave) * SPW;
     if (s0 >= p.S) return;                                   // (whole waves leave; no workgroup barrier below)
-    float* xs = &s_x[wave][0][0];
-    float* hv = s_h[wave];
-    int sid[GH_SPW];
+    float* xs = gh_lds + (size_t)wave * SPW * 96;                                    // [SPW][96] feature row t of the wave's streams
+    float* hv = gh_lds + (size_t)WAVES * SPW * 96 + (size_t)wave * SPW * hs;         // [SPW][hs] hidden vectors
+    float* sz = gh_lds + (size_t)WAVES * SPW * (96 + hs) + (size_t)wave * SPW * 8;   // [SPW][8]  output-layer sums
+    int sid[SPW];
 #pragma unroll
-    for (int s = 0; s < GH_SPW; ++s) sid[s] = min(s0 + s, p.S - 1);
+    for (int s = 0; s < SPW; ++s) sid[s] = min(s0 + s, p.S - 1);
     for (int ni = net_begin; ni < net_end; ++ni) {
         const NetDesc& n = p.nets[ni];
         if (n.role != 0) continue;
-        float result[GH_SPW][8];
-        float gate_score[GH_SPW];
+        float result[8];                                     // lane s < SPW: the scores of stream s0 + s
+        float gate_score = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) result[o] = 0.f;
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {
                 if (ni + 1 >= net_end) break;
@@ -1004,99 +1016,127 @@ __global__ __launch_bounds__(64 * GH_WAVES) void heads_generic_kernel(HeadParams
             }
             const NetDesc& m = p.nets[ni + pass];
             const int H = m.hidden, T = m.T, O = m.n_out;
-            float acc[GH_SPW][GH_HPL];
+            float acc[SPW][HPL];
             // ---- layer 1
 #pragma unroll
-            for (int i = 0; i < GH_HPL; ++i) {
+            for (int i = 0; i < HPL; ++i) {
                 const float bb = lane + 64 * i < H ? m.b1[lane + 64 * i] : 0.f;
 #pragma unroll
-                for (int s = 0; s < GH_SPW; ++s) acc[s][i] = bb;
+                for (int s = 0; s < SPW; ++s) acc[s][i] = bb;
             }
             for (int t = 0; t < T; ++t) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-local LDS tile: the previous row's readers are done)
 #pragma unroll
-                for (int s = 0; s < GH_SPW; ++s) {
+                for (int s = 0; s < SPW; ++s) {
                     const float* row = feat_row(p, sid[s], T, t);
                     xs[s * 96 + lane] = row[lane];
                     if (lane < 32) xs[s * 96 + 64 + lane] = row[64 + lane];
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // four feature columns per trip; the NEXT trip's weight rows are requested before this trip's FMAs (the loop is kept
+                // rolled: unrolled, its 16 feature vectors per trip push the kernel past the register file)
                 const float* w = m.w1 + (size_t)t * 96 * H;
-                for (int c = 0; c < 96; ++c, w += H) {
-                    float xv[GH_SPW];
+                float wcur[4][HPL], wnxt[4][HPL];
 #pragma unroll
-                    for (int s = 0; s < GH_SPW; ++s) xv[s] = xs[s * 96 + c];
+                for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-                    for (int i = 0; i < GH_HPL; ++i)
-                        if (lane + 64 * i < H) {
-                            const float wv = w[lane + 64 * i];
+                    for (int i = 0; i < HPL; ++i) wcur[cc][i] = lane + 64 * i < H ? w[(size_t)cc * H + lane + 64 * i] : 0.f;
+#pragma unroll 1
+                for (int c = 0; c < 96; c += 4) {
+                    w += 4 * (size_t)H;
 #pragma unroll
-                            for (int s = 0; s < GH_SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
-                        }
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int i = 0; i < HPL; ++i) wnxt[cc][i] = (c + 4 < 96 && lane + 64 * i < H) ? w[(size_t)cc * H + lane + 64 * i] : 0.f;
+                    f32x4g xv[SPW];
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) xv[s] = *reinterpret_cast<const f32x4g*>(xs + s * 96 + c);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int i = 0; i < HPL; ++i)
+                            if (lane + 64 * i < H) {
+#pragma unroll
+                                for (int s = 0; s < SPW; ++s) acc[s][i] = fmaf(xv[s][cc], wcur[cc][i], acc[s][i]);
+                            }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int i = 0; i < HPL; ++i) wcur[cc][i] = wnxt[cc][i];
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            gh_norm_relu_store(acc, H, m.has_ln, m.ln1g, m.ln1b, hv, lane);
+            gh_norm_relu_store<SPW, HPL>(acc, H, m.has_ln, m.ln1g, m.ln1b, hv, hs, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // ---- hidden blocks (train.py:56-65 FCNBlock: Linear -> LayerNorm -> ReLU; one in the released models)
             for (int blk = 0; blk < m.n_blocks; ++blk) {
                 const float* w2 = m.blocks + (size_t)blk * ((size_t)H * H + H + (m.has_ln ? 2 * H : 0));
                 const float* b2 = w2 + (size_t)H * H;
 #pragma unroll
-                for (int i = 0; i < GH_HPL; ++i) {
+                for (int i = 0; i < HPL; ++i) {
                     const float bb = lane + 64 * i < H ? b2[lane + 64 * i] : 0.f;
 #pragma unroll
-                    for (int s = 0; s < GH_SPW; ++s) acc[s][i] = bb;
+                    for (int s = 0; s < SPW; ++s) acc[s][i] = bb;
                 }
+#pragma unroll 1
                 for (int k = 0; k < H; ++k) {
-                    float xv[GH_SPW];
+                    float xv[SPW];
 #pragma unroll
-                    for (int s = 0; s < GH_SPW; ++s) xv[s] = hv[s * GH_HMAX + k];
+                    for (int s = 0; s < SPW; ++s) xv[s] = hv[s * hs + k];
                     const float* w = w2 + (size_t)k * H;
 #pragma unroll
-                    for (int i = 0; i < GH_HPL; ++i)
+                    for (int i = 0; i < HPL; ++i)
                         if (lane + 64 * i < H) {
                             const float wv = w[lane + 64 * i];
 #pragma unroll
-                            for (int s = 0; s < GH_SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
+                            for (int s = 0; s < SPW; ++s) acc[s][i] = fmaf(xv[s], wv, acc[s][i]);
                         }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every lane has read the previous layer's vector
-                gh_norm_relu_store(acc, H, m.has_ln, b2 + H, b2 + 2 * H, hv, lane);
+                gh_norm_relu_store<SPW, HPL>(acc, H, m.has_ln, b2 + H, b2 + 2 * H, hv, hs, lane);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            // ---- output layer: lane o < n_out, the k-ordered chain of the formula; then the final activation per stream
+            // ---- output layer: lane o < n_out, the k-ordered chain of the formula; then the final activation, one lane per stream
             if (lane < O) {
 #pragma unroll
-                for (int s = 0; s < GH_SPW; ++s) {
+                for (int s = 0; s < SPW; ++s) {
                     float a = m.b3[lane];
-                    for (int i = 0; i < H; ++i) a = fmaf(hv[s * GH_HMAX + i], m.w3[i * O + lane], a);
-                    s_z[wave][s][lane] = a;
+                    for (int i = 0; i < H; ++i) a = fmaf(hv[s * hs + i], m.w3[i * O + lane], a);
+                    sz[s * 8 + lane] = a;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int s = 0; s < GH_SPW; ++s) {
+            if (lane < SPW) {
                 float z[8];
-                for (int o = 0; o < O; ++o) z[o] = s_z[wave][s][o];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) z[o] = o < O ? sz[lane * 8 + o] : 0.f;
                 if (m.final_act == 1) {
                     float mx = -INFINITY, sum = 0.f;
-                    for (int o = 0; o < O; ++o) { z[o] = fmaxf(z[o], 0.f); mx = fmaxf(mx, z[o]); }
-                    for (int o = 0; o < O; ++o) { z[o] = expf(z[o] - mx); sum += z[o]; }
-                    for (int o = 0; o < O; ++o) z[o] /= sum;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) if (o < O) { z[o] = fmaxf(z[o], 0.f); mx = fmaxf(mx, z[o]); }
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) if (o < O) { z[o] = expf(z[o] - mx); sum += z[o]; }
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) if (o < O) z[o] /= sum;
                 } else {
-                    for (int o = 0; o < O; ++o) z[o] = 1.0f / (1.0f + expf(-z[o]));
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) if (o < O) z[o] = 1.0f / (1.0f + expf(-z[o]));
                 }
-                if (pass == 0) { for (int o = 0; o < O; ++o) result[s][o] = z[o]; gate_score[s] = z[0]; }
-                else if (gate_score[s] > 0.5f) { for (int o = 0; o < O; ++o) result[s][o] = z[o]; }
+                if (pass == 0) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) result[o] = z[o];
+                    gate_score = z[0];
+                } else if (gate_score > 0.5f) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) result[o] = z[o];
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (lane == 0) {
+        if (lane < SPW && s0 + lane < p.S) {
 #pragma unroll
-            for (int s = 0; s < GH_SPW; ++s)
-                if (s0 + s < p.S)
-                    for (int o = 0; o < n.n_out; ++o) store_raw(p, s0 + s, n.out_col + o, result[s][o]);
+            for (int o = 0; o < 8; ++o)
+                if (o < n.n_out) store_raw(p, s0 + lane, n.out_col + o, result[o]);
         }
     }
 }

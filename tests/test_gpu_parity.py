@@ -154,6 +154,43 @@ def test_generic_heads_of_any_shape(emb, use_mfma):
             e.close()
 
 
+def test_generic_heads_kernel_gives_the_same_scores_in_both_of_its_shapes(emb, monkeypatch):
+    """heads_generic_kernel runs four streams per wave below 2,048 streams and sixteen from there on (heads of up to 128 hidden units):
+    the per-stream arithmetic is the same, so the scores must be bit-identical -- pinned shapes on a batch with a partly filled last
+    wave, the default choice on a batch above the switch -- and within 1e-4 of the float64 oracle."""
+    shapes = {"timer": dict(), "odd100": dict(kind="binary", T=16, hidden=100, n_out=1, layernorm=False),
+              "deep2gated": dict(kind="gated", T=4, hidden=40, n_out=1, layernorm=True, n_blocks=2),
+              "wide128": dict(kind="binary", T=16, hidden=128, n_out=1, layernorm=True, n_blocks=3),
+              "flat0": dict(kind="binary", T=16, hidden=64, n_out=1, layernorm=True, n_blocks=0)}
+    heads = {n: W.synthetic_head(n, 31 + i, **kw) for i, (n, kw) in enumerate(shapes.items())}
+    rng = np.random.default_rng(13)
+
+    def run(S, spw, feats, pcm):
+        if spw:
+            monkeypatch.setenv("OWW_GENERIC_SPW", str(spw))
+        else:
+            monkeypatch.delenv("OWW_GENERIC_SPW", raising=False)
+        e = StreamEngine(S, heads, emb, use_mfma=1)
+        try:
+            out = {n: e.head(n, feats[n]) for n in heads}
+            steps = [e.step(pcm[:, 1280 * t:1280 * (t + 1)]).copy() for t in range(3)]
+            return out, steps
+        finally:
+            e.close()
+
+    for S, variants in ((37, (4, 16)), (2100, (4, 0))):
+        feats = {n: rng.normal(0, 1.5, (S, h["T"], 96)).astype(np.float32) for n, h in heads.items()}
+        pcm = W.synthetic_pcm(S, 1280 * 3, seed=S)
+        a, sa = run(S, variants[0], feats, pcm)
+        b, sb = run(S, variants[1], feats, pcm)
+        for n, h in heads.items():
+            np.testing.assert_array_equal(a[n], b[n], err_msg=f"{n} S={S}")
+            np.testing.assert_allclose(b[n], O.head_stage(feats[n], h, np.float64), rtol=0, atol=TOL_SCORE, err_msg=f"{n} S={S}")
+        for x, y in zip(sa, sb):
+            np.testing.assert_array_equal(x, y)
+    monkeypatch.delenv("OWW_GENERIC_SPW", raising=False)
+
+
 def test_custom_width_heads_take_the_mfma_path_and_match_the_oracle(emb):
     """The reference's automatic training pipeline writes heads of 32 hidden units (examples/custom_model.yml:89 `layer_size: 32`,
     notebooks/training_models.ipynb: layer_dim = 32; train.py's class default is 128).  In the default family every sigmoid net of up to
