@@ -404,7 +404,7 @@ struct NetHost {
     int n_blocks;                     // hidden blocks behind the first layer (train.py:73: Net's n_blocks; 1 in every released model)
     const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // into the owning head blob (w2 .. ln2b: block 0)
     const float* blocks;              // the n_blocks blocks back to back: w[H][H] b[H] (g[H] be[H])
-    int hx_e1 = 0, hx_e2 = 0;         // fp16-split heads: power-of-two scales of w1 / w2 (hx_weight_exp)
+    int hx_e1 = 0, hx_e2 = 0, hx_e3 = 0;   // fp16-split heads: power-of-two scales of w1 / w2 (/ w3: wide form) (hx_weight_exp)
 };
 struct HeadHost {
     int kind, T, hidden, n_out, has_ln, n_blocks;
@@ -422,7 +422,12 @@ struct FastGroup {
     // fp16-split fast path: per net the seven per-unit arrays (b1, ln1 g / b, b2, ln2 g / b, w3) padded with zeros to the kernel's 64
     // hidden units -- a narrower net (the reference's training pipeline defaults to 32: examples/custom_model.yml:89) runs as a
     // 64-unit net whose padding units are identically zero and are left out of the LayerNorm statistics (owh::HeadHxNet::hidden)
-    std::vector<const float*> d_pad;  // per net: 7 x 64 floats
+    std::vector<const float*> d_pad;  // per net: 7 x 64 floats (wide form: 6 x 128 + 16, see below)
+    // wide form (owh::heads_wide_tail: nets of up to 128 hidden units / 8 outputs, sigmoid or ReLU + softmax -- the multiclass `timer`
+    // model): ht = 8 hidden tiles per net, at most two nets per launch; d_pad = b1, ln1 g / b, b2, ln2 g / b padded to 128 units + b3
+    // padded to 16 outputs; the output layer as a third f16-split matrix
+    int ht = 4;
+    std::vector<const float*> d_w3hx; // per net
 };
 
 constexpr int N_STATE = 11;
@@ -800,11 +805,14 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                     const NetHost& n = h->nets[g.nets[i]];
                     const NetDesc d = h->host_descs[g.nets[i]];
                     owh::HeadHxNet& o = q.net[i];
-                    const float* pd = g.d_pad[i];                      // the per-unit arrays padded to 64 units
-                    o.w2hx = g.d_w2hx[i]; o.b1 = pd; o.ln1g = pd + 64; o.ln1b = pd + 128; o.b2 = pd + 192; o.ln2g = pd + 256; o.ln2b = pd + 320;
-                    o.w3 = pd + 384; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
+                    const float* pd = g.d_pad[i];                      // the per-unit arrays padded to 64 (wide form: 128) units
+                    const int HP = 16 * g.ht;
+                    o.w2hx = g.d_w2hx[i]; o.b1 = pd; o.ln1g = pd + HP; o.ln1b = pd + 2 * HP; o.b2 = pd + 3 * HP; o.ln2g = pd + 4 * HP; o.ln2b = pd + 5 * HP;
+                    o.w3 = pd + 6 * HP; o.b3 = d.b3; o.has_ln = n.has_ln; o.role = n.role; o.head = n.head; o.out_col = n.out_col;
                     o.hidden = n.hidden; o.inv_hidden = 1.0f / (float)n.hidden;
                     o.u1 = std::ldexp(1.0f, -(h->hx_efeat + n.hx_e1)); o.u2 = std::ldexp(1.0f, -n.hx_e2);
+                    o.n_out = n.n_out; o.final_act = n.final_act;
+                    if (g.ht == 8) { o.w3 = nullptr; o.b3 = pd + 6 * HP; o.w3hx = g.d_w3hx[i]; o.u3 = std::ldexp(1.0f, -n.hx_e3); }
                 }
                 q.fscale = std::ldexp(1.0f, h->hx_efeat);
                 const dim3 grid((n_pos + 32 * owh::HX_WG - 1) / (32 * owh::HX_WG)), block(64 * owh::HX_WG);
@@ -812,6 +820,13 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
                 const bool deep = (int)grid.x <= h->small_wgs_heads;
                 const int nn = std::min(g.n_nets, 4);
                 const int lds = 0;                                  // (the ring slots are static LDS objects: owwhip_hx.h hslot)
+                if (g.ht == 8) {                                    // wide nets (<= 128 hidden units, <= 8 outputs): one or two per launch
+                    if (nn == 1 && !deep) hipLaunchKernelGGL((owh::heads_hx_kernel<1, owh::HX_NBUF, owh::HX_WG, 8>), grid, block, lds, st, q);
+                    else if (nn == 1) hipLaunchKernelGGL((owh::heads_hx_kernel<1, owh::HeadsDeep<2>::NBUF, owh::HX_WG, 8>), grid, block, lds, st, q);
+                    else if (!deep) hipLaunchKernelGGL((owh::heads_hx_kernel<2, owh::HX_NBUF, owh::HX_WG, 8>), grid, block, lds, st, q);
+                    else hipLaunchKernelGGL((owh::heads_hx_kernel<2, owh::HeadsDeep<4>::NBUF, owh::HX_WG, 8>), grid, block, lds, st, q);
+                    continue;
+                }
                 switch (nn * 2 + (deep ? 1 : 0)) {
                     case 2: hipLaunchKernelGGL(owh::heads_hx_kernel<1>, grid, block, lds, st, q); break;
                     case 3: hipLaunchKernelGGL((owh::heads_hx_kernel<1, owh::HeadsDeep<1>::NBUF>), grid, block, lds, st, q); break;
@@ -1785,7 +1800,7 @@ int oww_commit(oww_ctx* h) {
     }
     // grouping: heads whose nets are all (hidden 64, n_out 1, sigmoid) share a fast group per T (<= 8 nets each)
     h->groups.clear(); h->generic_nets.clear();
-    struct GOff { size_t w1pk, b1cat, w1hx; std::vector<size_t> w2hx, pad; };
+    struct GOff { size_t w1pk, b1cat, w1hx; std::vector<size_t> w2hx, pad, w3hx; };
     std::vector<GOff> goff;
     for (size_t hi = 0; hi < h->heads.size(); ++hi) {
         const auto [nb, ne] = h->head_nets[hi];
@@ -1795,14 +1810,59 @@ int oww_commit(oww_ctx* h) {
         for (int ni = nb; ni < ne; ++ni)
             fast = fast && (h->nets[ni].hidden == 64 || (h->hx && h->nets[ni].hidden <= 64)) && h->nets[ni].n_out == 1 &&
                    h->nets[ni].final_act == 0 && h->nets[ni].n_blocks == 1;
-        if (!fast) { for (int ni = nb; ni < ne; ++ni) h->generic_nets.push_back(ni); continue; }
+        // the wide form of the fp16-split heads kernel: ungated nets of up to 128 hidden units and 8 outputs with one hidden block
+        // (the released multiclass `timer`: docs/models/timers.md:9-27; train.py's default layer_dim = 128)
+        bool wide = !fast && h->hx && h->mfma && ne - nb == 1 && !getenv("OWW_NO_WIDE_HEADS");
+        for (int ni = nb; ni < ne; ++ni) wide = wide && h->nets[ni].hidden <= 128 && h->nets[ni].n_out <= 8 && h->nets[ni].n_blocks == 1 && h->nets[ni].role == 0;
+        if (!fast && !wide) { for (int ni = nb; ni < ne; ++ni) h->generic_nets.push_back(ni); continue; }
         FastGroup* g = nullptr;
-        const int cap = h->hx ? 4 : HD_MAXNETS;                      // heads_hx_kernel: at most four nets per launch
-        for (auto& gg : h->groups) if (gg.T == h->nets[nb].T && gg.n_nets + (ne - nb) <= cap) { g = &gg; break; }
-        if (!g) { h->groups.push_back(FastGroup{}); g = &h->groups.back(); g->T = h->nets[nb].T; g->n_nets = 0; }
+        const int ht = wide ? 8 : 4;
+        const int cap = h->hx ? 16 / ht : HD_MAXNETS;                // heads_hx_kernel: at most sixteen hidden tiles per launch
+        for (auto& gg : h->groups) if (gg.T == h->nets[nb].T && gg.ht == ht && gg.n_nets + (ne - nb) <= cap) { g = &gg; break; }
+        if (!g) { h->groups.push_back(FastGroup{}); g = &h->groups.back(); g->T = h->nets[nb].T; g->n_nets = 0; g->ht = ht; }
         for (int ni = nb; ni < ne; ++ni) { g->nets.push_back(ni); g->n_nets++; }
     }
     for (auto& g : h->groups) {
+        if (g.ht == 8) {
+            // ---- wide group: hidden columns padded to 128 per net
+            const int HP = 128;
+            g.NH = HP * g.n_nets;
+            const size_t K = (size_t)g.T * 96;
+            std::vector<float> wcat(K * g.NH, 0.f), pk;
+            std::vector<double> colmul(g.NH);
+            GOff go{0, 0, 0, {}, {}, {}};
+            for (int gi = 0; gi < g.n_nets; ++gi) {
+                NetHost& n = h->nets[g.nets[gi]];
+                const size_t H = n.hidden, O = n.n_out;
+                for (size_t k = 0; k < K; ++k) memcpy(&wcat[k * g.NH + HP * gi], n.w1 + k * H, H * sizeof(float));
+                n.hx_e1 = hx_weight_exp(n.w1, K * H); n.hx_e2 = hx_weight_exp(n.w2, H * H); n.hx_e3 = hx_weight_exp(n.w3, H * O);
+                if (n.hx_e1 == -1000 || n.hx_e2 == -1000 || n.hx_e3 == -1000) return fail(OWW_EINVAL, "head weights are not finite");
+                for (int c = 0; c < HP; ++c) colmul[HP * gi + c] = std::ldexp(1.0, n.hx_e1);
+            }
+            pack_hx_w1(wcat.data(), (int)K, g.NH, colmul.data(), pk);
+            go.w1hx = hb.add(pk);
+            for (int gi = 0; gi < g.n_nets; ++gi) {
+                const NetHost& n = h->nets[g.nets[gi]];
+                const size_t H = n.hidden, O = n.n_out;
+                std::vector<double> cm2(HP, std::ldexp(1.0, n.hx_e2)), cm3(16, std::ldexp(1.0, n.hx_e3));
+                HxFold f2; f2.colmul = cm2.data();
+                std::vector<float> w2p((size_t)HP * HP, 0.f);            // [in 128][out 128], zero rows / columns beyond H
+                for (size_t i = 0; i < H; ++i) memcpy(&w2p[i * HP], n.w2 + i * H, H * sizeof(float));
+                pack_hx(w2p.data(), 1, HP, HP, pk, &f2); go.w2hx.push_back(hb.add(pk));
+                HxFold f3; f3.colmul = cm3.data();
+                std::vector<float> w3p((size_t)HP * 16, 0.f);            // [in 128][out 16], outputs O .. 15 zero
+                for (size_t i = 0; i < H; ++i) memcpy(&w3p[i * 16], n.w3 + i * O, O * sizeof(float));
+                pack_hx(w3p.data(), 1, HP, 16, pk, &f3); go.w3hx.push_back(hb.add(pk));
+                std::vector<float> pad(6 * HP + 16, 0.f);                // b1, ln1g, ln1b, b2, ln2g, ln2b | b3
+                const float* src[6] = {n.b1, n.has_ln ? n.ln1g : nullptr, n.has_ln ? n.ln1b : nullptr, n.b2,
+                                       n.has_ln ? n.ln2g : nullptr, n.has_ln ? n.ln2b : nullptr};
+                for (int a = 0; a < 6; ++a) if (src[a]) memcpy(&pad[a * HP], src[a], H * sizeof(float));
+                memcpy(&pad[6 * HP], n.b3, O * sizeof(float));
+                go.pad.push_back(hb.add(pad));
+            }
+            goff.push_back(go);
+            continue;
+        }
         g.NH = 64 * g.n_nets;
         const size_t K = (size_t)g.T * 96;
         std::vector<float> wcat(K * g.NH, 0.f), bcat(g.NH, 0.f), pk;
@@ -1813,7 +1873,7 @@ int oww_commit(oww_ctx* h) {
             memcpy(&bcat[64 * gi], n.b1, H * sizeof(float));
         }
         pack_mfma(wcat.data(), g.T, 96, g.NH, pk);
-        GOff go{hb.add(pk), hb.add(bcat), 0, {}, {}};
+        GOff go{hb.add(pk), hb.add(bcat), 0, {}, {}, {}};
         if (h->hx) {
             // every net's two matrices on their own power-of-two scale (hx_weight_exp); undone on the fp32 accumulators (HeadHxNet::u1, u2)
             std::vector<double> colmul(g.NH);
@@ -1927,8 +1987,9 @@ int oww_commit(oww_ctx* h) {
             g.d_w1hx = h->d_w + goff[gi].w1hx;
             for (size_t o : goff[gi].w2hx) g.d_w2hx.push_back(h->d_w + o);
             for (size_t o : goff[gi].pad) g.d_pad.push_back(h->d_w + o);
+            for (size_t o : goff[gi].w3hx) g.d_w3hx.push_back(h->d_w + o);
         }
-        if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
+        if (g.ht == 4) if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
     }
 
     // ---- sticky range flag of the f16-split kernels: page-locked + device-mapped, so the host reads it without a copy ----
@@ -2000,7 +2061,7 @@ int oww_commit(oww_ctx* h) {
     if (const char* e = getenv("OWW_SMALL_WGS_HEADS")) h->small_wgs_heads = atoi(e);
     if (const char* e = getenv("OWW_GENERIC_SPW")) { const int v = atoi(e); h->generic_spw = v == 4 || v == 16 ? v : 0; }
     if (const char* e = getenv("OWW_RING3_ALWAYS")) for (int i = 0; i < 4; ++i) h->ring3_always[i] = strchr(e, "BCDE"[i]) != nullptr;
-    h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
+    h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->groups[0].ht == 4 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
     if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(owf::hmelA_kernel<true>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;

@@ -1454,8 +1454,12 @@ struct HeadHxNet {
     const float *b1, *ln1g, *ln1b, *b2, *ln2g, *ln2b, *w3, *b3;
     int has_ln, role, head, out_col;
     float u1, u2;                            // exact power-of-two un-scales of the two accumulators: 2^-(e_feat + e_w1), 2^-e_w2
-    int hidden;                              // real hidden units (<= 64): units hidden .. 63 are zero padding, outside the LayerNorm statistics
+    int hidden;                              // real hidden units (<= 64; wide form <= 128): the units beyond are zero padding, outside the LayerNorm statistics
     float inv_hidden;                        // 1 / hidden
+    // wide form (HT = 8: up to 128 hidden units, up to 8 outputs -- the multiclass `timer` model, docs/models/timers.md:9-27):
+    const float* w3hx;                       // output layer [4 ks][2 part][64][8 halves]: 16 output rows, rows n_out .. 15 zero (b3: 16 floats)
+    float u3;                                // 2^-e_w3
+    int n_out, final_act;                    // final_act 0: sigmoid per output; 1: ReLU + softmax over the n_out outputs (train.py:79,152-165)
 };
 // Optional tail of the heads kernel: Model.predict's post-processing (model.py:330-381 -- first-5 zeroing, patience / debounce
 // over the 30-deep score ring, ring append, VAD gate) and the step's frame-counter advance for the same streams, instead of two
@@ -1540,6 +1544,163 @@ __device__ __forceinline__ void ln_relu(f32x4 (&h)[4], const float* __restrict__
     }
 }
 
+// ---- wide form of the heads kernel (HT = 8 hidden tiles) --------------------------------------------------------------------------
+// Nets of up to 128 hidden units and up to 8 outputs, with or without LayerNorm, sigmoid or ReLU + softmax at the end: train.py's class
+// default width (train.py:67, layer_dim = 128) and the released multiclass `timer` model (T = 34: 3264 -> 128 -> 128 -> 7, ReLU between
+// the layers, softmax added at export: docs/models/timers.md:9-27, train.py:152-165).  Same first GEMM as the 64-unit form -- a net is
+// eight hidden tiles instead of four -- then 128 x 128 and 128 x 16 (outputs zero-padded) on the matrix pipe as well.  Without a
+// LayerNorm nothing bounds a hidden vector, so each stream's vector is carried into the next GEMM multiplied by ITS OWN power of two
+// (largest unit at 2^9..2^10, undone exactly on the fp32 accumulator by v_ldexp): no hidden magnitude leaves the f16 range or loses the
+// low halves of its split, and a stream's bits do not depend on its neighbours.
+template <int HT>
+__device__ __forceinline__ void ln_relu_w(f32x4 (&h)[HT], const float* __restrict__ bias, const float* __restrict__ g, const float* __restrict__ b,
+                                          int has_ln, int j, float unscale, int unexp, int hidden, float inv_hidden) {
+#pragma unroll
+    for (int ct = 0; ct < HT; ++ct) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[ct][e] = ldexpf(h[ct][e] * unscale, unexp) + bb[e];
+    }
+    if (has_ln) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += h[ct][e];
+        const float mu = xsum4(sum) * inv_hidden;
+        float var = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = (ct * 16 + 4 * j + e < hidden) ? h[ct][e] - mu : 0.f; var = fmaf(d, d, var); }
+        const float rs = 1.0f / sqrtf(xsum4(var) * inv_hidden + 1e-5f);
+#pragma unroll
+        for (int ct = 0; ct < HT; ++ct) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + ct * 16 + 4 * j);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(b + ct * 16 + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[ct][e] = fmaxf((h[ct][e] - mu) * rs * gg[e] + be[e], 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[ct][e] = owr::fmax_nc(h[ct][e], 0.f);
+    }
+}
+// the stream's own scale: multiplies the (non-negative) hidden vector by 2^e with its largest unit at 2^9 .. 2^10; returns e
+template <int HT>
+__device__ __forceinline__ int scale_own(f32x4 (&h)[HT]) {
+    float m = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, h[ct][e]);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    int ex = __builtin_amdgcn_frexp_expf(m);                     // m = f 2^ex, f in [0.5, 1); 0 for m = 0 (an all-zero vector stays zero)
+    ex = 10 - min(max(ex, -110), 120);
+#pragma unroll
+    for (int ct = 0; ct < HT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[ct][e] = ldexpf(h[ct][e], ex);
+    return ex;
+}
+
+template <int NN, int WG, int HT, int NCT>
+__device__ __forceinline__ void heads_wide_tail(const HeadHxParams& p, f32x4 (&acc)[NCT][2], lanemask_t& bad, int lane, int wave) {
+    constexpr int KS = HT / 2;                  // k-steps of a hidden vector
+    const int pos = lane & 15, j = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const HeadHxNet& net = p.net[n];
+        Op ho[2][KS];
+        int ex[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 h1[HT];
+#pragma unroll
+            for (int ct = 0; ct < HT; ++ct) h1[ct] = acc[HT * n + ct][t];
+            ln_relu_w<HT>(h1, net.b1, net.ln1g, net.ln1b, net.has_ln, j, net.u1, 0, net.hidden, net.inv_hidden);
+            ex[t] = scale_own<HT>(h1);
+            to_ops<HT>(h1, ho[t]);
+        }
+        // ---- hidden block: 128 x 128, one output tile at a time, each weight block read once for both stream tiles
+        f32x4 h2[2][HT];
+#pragma unroll
+        for (int oct = 0; oct < HT; ++oct) {
+            f32x4 a2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k2 = 0; k2 < KS; ++k2) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(net.w2hx + (((oct * KS + k2) * 2 + 0) * 64 + lane) * 4);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(net.w2hx + (((oct * KS + k2) * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a2[t] = OWH_MFMA(wh, ho[t][k2].h, a2[t]);
+                    a2[t] = OWH_MFMA(wh, ho[t][k2].l, a2[t]);
+                    a2[t] = OWH_MFMA(wl, ho[t][k2].h, a2[t]);
+                }
+            }
+            h2[0][oct] = a2[0]; h2[1][oct] = a2[1];
+            if (oct == 0) { nan_guard(bad, a2[0][0]); nan_guard(bad, a2[1][0]); }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ln_relu_w<HT>(h2[t], net.b2, net.ln2g, net.ln2b, net.has_ln, j, net.u2, -ex[t], net.hidden, net.inv_hidden);
+            ex[t] = scale_own<HT>(h2[t]);
+            to_ops<HT>(h2[t], ho[t]);
+        }
+        // ---- output layer: 16 rows (n_out real ones) x 128 -- lane (pos, j), register e <-> output 4j + e of stream pos
+        f32x4 z[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k2 = 0; k2 < KS; ++k2) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(net.w3hx + ((k2 * 2 + 0) * 64 + lane) * 4);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(net.w3hx + ((k2 * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                z[t] = OWH_MFMA(wh, ho[t][k2].h, z[t]);
+                z[t] = OWH_MFMA(wh, ho[t][k2].l, z[t]);
+                z[t] = OWH_MFMA(wl, ho[t][k2].h, z[t]);
+            }
+        }
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(net.b3 + 4 * j);
+        const int O = net.n_out;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            nan_guard(bad, z[t][0]);
+            float v[4];
+            if (net.final_act == 1) {                                   // ReLU, then softmax over the n_out outputs (rows 0..7: lane groups 0, 1)
+                float mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(ldexpf(z[t][e] * net.u3, -ex[t]) + b3[e], 0.f);
+                    if (4 * j + e < O) mx = fmaxf(mx, v[e]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = 4 * j + e < O ? expf(v[e] - mx) : 0.f; sum += v[e]; }
+                sum += __shfl_xor(sum, 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] /= sum;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-(ldexpf(z[t][e] * net.u3, -ex[t]) + b3[e])));
+            }
+            const int idx = (blockIdx.x * WG + wave) * 32 + t * 16 + pos;
+            if (j >= 2 || idx >= (p.ids ? p.n_ids : p.S - p.s_base)) continue;
+            const int st = p.ids ? p.ids[idx] : idx + p.s_base;
+            if (p.stream_on && !p.stream_on[st]) continue;              // sits this step out: its scores stay as they are
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * j + e < O) {
+                    float* o = p.raw + (size_t)st * p.NL + net.out_col + 4 * j + e;
+                    *o = p.accumulate_max ? fmaxf(*o, v[e]) : v[e];
+                }
+        }
+    }
+}
+
 // Waves per workgroup and weight chunks in the LDS ring.  The first layer is a K = 96 T GEMM whose weights (NN x 8 KB per k-step
 // of 32 features) stream L2 -> LDS once per workgroup.  Defaults: 4 waves (128 streams), double buffer.  A deeper pipeline --
 // 8 waves = 256 streams per chunk and a ring of 3 or 4 chunks with a counted s_waitcnt vmcnt(n) in front of the barrier, so
@@ -1585,10 +1746,10 @@ __device__ __forceinline__ float* hslot_at(int i) {         // slot i of 0..I (i
 // WG = waves per workgroup (32 streams each).  Round 5 A/B at 4,096 streams x hey_jarvis (same box, per-launch hipEvents): one wave per
 // workgroup (128 workgroups instead of 32 on the 256 CUs) 79 us against 71 us for WG = 4 -- every workgroup then streams the weights
 // itself and the launch is bound by exactly that stream; two-wave workgroups in stages D / E: 36.6 / 39.3 against 35.2 / 38.6 us.
-template <int NN, int NBUF = HX_NBUF, int WG = HX_WG>
+template <int NN, int NBUF = HX_NBUF, int WG = HX_WG, int HT = 4>       // HT = hidden tiles per net: 4 (<= 64 units) or 8 (wide form, <= 128)
 __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(HeadHxParams p) {
     using namespace owr;
-    constexpr int NCT = NN * 4;                 // hidden tiles of 16
+    constexpr int NCT = NN * HT;                // hidden tiles of 16
     constexpr int NBLK = NCT * 2;               // 1 KB blocks per k-step chunk
     constexpr int CHUNK = NBLK * 256;           // floats
     constexpr int D = NBUF - 1;                 // chunks in flight ahead of the one being consumed
@@ -1691,6 +1852,12 @@ __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(H
     lanemask_t bad = 0;
     nan_guard(bad, acc[0][0][0]);               // a feature beyond the f16 range
     nan_guard(bad, acc[0][1][0]);
+    if constexpr (HT != 4) {                    // wide nets: their own tail (no gating, no fused post-processing)
+        heads_wide_tail<NN, WG, HT, NCT>(p, acc, bad, lane, wave);
+        if (p.ids) raise_range_flag(bad, p.range_flag);
+        else raise_range_flag(bad, p.range_flag, (blockIdx.x * WG + wave) * 32 + p.s_base, 32);
+        return;
+    } else {
     // ---- per net: bias, LayerNorm, ReLU, 64x64, bias, LayerNorm, ReLU, dot, sigmoid
     float score[NN][2];
 #pragma unroll
@@ -1794,6 +1961,7 @@ __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(H
     // (which streams: the wave's 32 positions; with a participant list they are not contiguous -- reported as unknown)
     if (p.ids) raise_range_flag(bad, p.range_flag);
     else raise_range_flag(bad, p.range_flag, (blockIdx.x * WG + wave) * 32 + p.s_base, 32);
+    }
 }
 
 }  // namespace owh
