@@ -205,7 +205,8 @@ def parity_check(torch, eng, pool, scores, dev, head_names, ref, rank, vad=False
     ids = PS.probe_stream_ids(S, seed=7 + rank)
     ids_t = torch.from_numpy(ids).to(dev)
     pcm = torch.from_numpy(PS.probe_pcm()).to(dev)
-    cols = [list(PS.HEADS3).index(h) for h in head_names]
+    ref_labels = [str(x) for x in ref["labels"]]
+    cols = [ref_labels.index(l) for l in PS.labels_of(head_names)]       # the engine's score columns (a multiclass head: n_out of them)
     want = torch.from_numpy(ref["scores"][:, :, cols]).to(dev)
     keep = torch.ones(PS.N_PROBE, PS.N_FRAMES, dtype=torch.bool, device=dev)
     if vad:
@@ -544,14 +545,17 @@ def main():
         cpu_base = cpu_baseline.run(head_names, budget_s=args.cpu_seconds)
     parity_ref = None
     family_ok = not (args.valu or args.lds_mfma)
-    want_parity = (not args.no_parity and family_ok and set(head_names) <= {"alexa", "hey_mycroft", "hey_jarvis"}
+    want_parity = (not args.no_parity and family_ok and set(head_names) <= set(PS6)
                    and not (args.host_pcm or args.host_pcm_blocking))
-    vad_parity_ref = None
+    vad_parity_ref = default6_ref = None
+    PS6 = ("alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather")        # (= oracle.parity_sample.HEADS6)
     if want_parity and rank0:
         from oracle import parity_sample as PS
-        parity_ref = PS.oracle_reference(vad=args.vad)  # computed once by a child interpreter, cached under $TMPDIR
+        # computed once by a child interpreter, cached under $TMPDIR (the three-head sample unless the run names other catalogue heads)
+        parity_ref = PS.oracle_reference(vad=args.vad, head_names=PS.HEADS3 if set(head_names) <= set(PS.HEADS3) else tuple(head_names))
         if world == 1 and not args.no_extras and not args.vad and set(head_names) == set(PS.HEADS3):
             vad_parity_ref = PS.oracle_reference(vad=True)     # for the vad_fused record (BASELINE configs[4])
+            default6_ref = PS.oracle_reference(head_names=PS.HEADS6)      # for configs.default6 (the reference's default six models)
 
     t_pre_done = time.perf_counter()
     import torch
@@ -583,7 +587,7 @@ def main():
             dist.barrier()                               # rank 0 wrote the cache file before it joined
             if not rank0:
                 from oracle import parity_sample as PS
-                parity_ref = PS.oracle_reference(vad=args.vad)
+                parity_ref = PS.oracle_reference(vad=args.vad, head_names=PS.HEADS3 if set(head_names) <= set(PS.HEADS3) else tuple(head_names))
 
     S = args.streams
     emb = W.synthetic_embedding(1234)
@@ -728,6 +732,10 @@ def main():
                     #  loaded chip has left its low-power clocks, which is what made this figure swing 0.35 .. 0.75 ms box to box)
                     "c1_4096x1": quick_config(torch, dev, stream, 4096, ["hey_jarvis"], 1000, 300),
                     "c2_65536x3": quick_config(torch, dev, stream, 65536, head_names, 50, 10),
+                    # the reference's default Model(): all six pretrained models (model.py:84-87) -- five 64-unit heads (six nets: two
+                    # launches of the f16-split heads kernel) + the multiclass `timer` (T = 34, 128 units, 7 classes: its wide form);
+                    # 12 score columns per stream, held to the oracle on the same 1,024 (stream, step) pairs
+                    "default6_131072x6": quick_config(torch, dev, stream, S, list(PS6), 20, 5, parity_ref=default6_ref),
                 }
                 extras["vad_fused"] = quick_config(torch, dev, stream, S, head_names, 20, 5, vad=True, parity_ref=vad_parity_ref)
                 extras["masked_step"] = masked_leg(torch, dev, stream, S, head_names)

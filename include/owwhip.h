@@ -44,6 +44,7 @@ extern "C" {
 #define OWW_MAX_HEADS      16
 #define OWW_MAX_HEAD_BLOCKS 8    /* hidden blocks of one head network (train.py:73); the released models have 1 */
 #define OWW_MAX_LABELS     32
+#define OWW_MAX_CALL_CHUNKS 4096 /* longest oww_step call: 4096 x 80 ms = 5.5 minutes of audio per stream */
 
 typedef struct oww_ctx oww_ctx;
 
@@ -158,6 +159,10 @@ int  oww_reset_vad(oww_ctx* h, const int32_t* stream_ids, int32_t n);
  * *_on_device: 0 = host pointer (copied on the handle's stream), 1 = device pointer.
  * n_chunks > 1 reproduces the reference's multi-chunk call: one mel pass over the whole span
  * (single top_db clamp), one embedding + head evaluation per chunk, max over chunks (model.py:287-298).
+ * n_chunks may exceed oww_config.max_chunks (up to OWW_MAX_CALL_CHUNKS): the call is then evaluated in slices of max_chunks chunks
+ * behind one extra pass of the mel kernel that finds the CALL's maximum, so that the clamp floor is still the reference's single
+ * "max - 80 dB" over the whole call (utils.py:387-401: one run of melspectrogram.onnx per call); such a call is synchronous when pcm
+ * is a host pointer, and is refused with the on-device VAD network (one chunk per step).
  * Asynchronous on the handle's stream unless scores is a host pointer.
  * A DEVICE pcm pointer should be 16-byte aligned: the fused front end loads eight samples at a time; any other alignment (a slice of
  * a larger int16 buffer) is accepted and takes the separate mel launch with scalar sample loads -- same scores to fp32 round-off

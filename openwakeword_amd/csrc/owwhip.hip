@@ -503,6 +503,8 @@ struct oww_ctx {
     float vad_bd = 0.f, vad_gain = 50.f;
     float *d_vadx = nullptr, *d_vadhc = nullptr, *d_vadlast = nullptr;
     int16_t *d_tail = nullptr, *d_pcm = nullptr;
+    int16_t* d_long = nullptr; size_t long_cap = 0;      // oww_step with n_chunks > max_chunks: the whole call's PCM when it arrives from the host
+    float* d_callmax = nullptr;                          // ... and the call's per-stream mel maximum (launch_step_long)
     int* h_range = nullptr;          // sticky f16-range flag: one page-locked, device-mapped word the f16-split kernels raise
     int* d_range = nullptr;          // the same word as the kernels address it
     void* d_rs = nullptr; size_t rs_bytes = 0;     // oww_resample scratch: [taps | in | out] as needed
@@ -865,9 +867,11 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
     return 0;
 }
 
-int launch_mel(oww_ctx* h, const int16_t* d_pcm, int n_streams, int n_samples, int n_frames, int streaming, float* out, float* smax) {
+int launch_mel(oww_ctx* h, const int16_t* d_pcm, int n_streams, int n_samples, int n_frames, int streaming, float* out, float* smax,
+               int pcm_stride = 0, int max_only = 0, const float* floor_max = nullptr) {
     MelParams p{};
     p.pcm = d_pcm; p.n_samples = n_samples; p.n_frames = n_frames; p.streaming = streaming;
+    p.pcm_stride = pcm_stride; p.max_only = max_only; p.floor_max = floor_max;
     p.tail = h->d_tail; p.nfeat = h->d_nfeat; p.out = out; p.smax = smax;
     p.hann = h->d_hann; p.mel_start = h->d_mstart; p.mel_taps = h->d_taps; p.S = n_streams;
     p.stream_on = streaming ? h->on_now : nullptr;
@@ -966,7 +970,8 @@ void free_all(oww_ctx* h) {
     for (int a = 0; a < N_STATE; ++a) { fr(h->d_state[a]); fr(h->d_tmpl[a]); }
     fr(h->d_xA); fr(h->d_xB); fr(h->d_xC); fr(h->d_xD); fr(h->d_mel); fr(h->d_feat); fr(h->d_emb); fr(h->d_raw);
     fr(h->d_scores); fr(h->d_ring); fr(h->d_featinit); fr(h->d_dbg); fr(h->d_nfeat); fr(h->d_npred); fr(h->d_tail); fr(h->d_vadring); fr(h->d_nvad); fr(h->d_vadin); fr(h->d_vadx); fr(h->d_vadhc); fr(h->d_vadlast); fr(h->d_verw); fr(h->d_verb); fr(h->d_verthr); fr(h->d_verT);
-    fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save);
+    fr(h->d_prof); fr(h->d_pcm); fr(h->d_ids); fr(h->d_patience); fr(h->d_threshold); fr(h->d_save); fr(h->d_long); fr(h->d_callmax);
+    h->long_cap = 0;
     h->save_floats = 0;
     if (h->d_on) { (void)dev_free(h->d_on); h->d_on = nullptr; }
     for (int b = 0; b < 4; ++b) {
@@ -999,14 +1004,17 @@ void free_all(oww_ctx* h) {
 }
 
 // one chunk of the streaming step on device-resident mel rows
-int step_chunk(oww_ctx* h, int k, int c) {
+// (k, c: the mel rows of this chunk sit at row 8c of 8k per stream; first / last: of the CALL, which may span several mel slices)
+int step_chunk(oww_ctx* h, int k, int c, bool first, bool last, bool single);
+int step_chunk(oww_ctx* h, int k, int c) { return step_chunk(h, k, c, c == 0, c == k - 1, k == 1); }
+int step_chunk(oww_ctx* h, int k, int c, bool first, bool last, bool single) {
     if (int rc = run_cnn(h, h->Spad, 8 * k * 32, c * 8 * 32)) return rc;
-    h->post_in_heads_now = h->post_in_heads && k == 1 && h->n_verifiers == 0;
-    const int rc = run_heads(h, h->Spad, c > 0, nullptr, -1, h->d_raw, 0);
+    h->post_in_heads_now = h->post_in_heads && single && h->n_verifiers == 0;
+    const int rc = run_heads(h, h->Spad, !first, nullptr, -1, h->d_raw, 0);
     const bool done_in_heads = h->post_in_heads_now;
     h->post_in_heads_now = false;
     if (rc) return rc;
-    if (h->n_verifiers > 0 && c == k - 1) {          // after the maximum over the call's chunks, on the newest feature rows
+    if (h->n_verifiers > 0 && last) {                // after the maximum over the call's chunks, on the newest feature rows
         VerifierParams v{};
         v.raw = h->d_raw; v.feat = h->d_feat; v.nfeat = h->d_nfeat; v.w = h->d_verw; v.bias = h->d_verb; v.thr = h->d_verthr; v.T = h->d_verT;
         v.wstride = h->ver_stride; v.NL = h->NL; v.TR = h->TR; v.S = h->S; v.stream_on = h->on_now;
@@ -1114,6 +1122,7 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
     return n_act;
 }
 
+int launch_postproc(oww_ctx* h);
 int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
     if (h->vad) {
         if (k != 1) return fail(OWW_EINVAL, "with the on-device VAD network a step carries exactly one 1280-sample chunk per stream (got %d)", k);
@@ -1148,6 +1157,30 @@ int launch_step(oww_ctx* h, const int16_t* d_pcm, int k) {
             if (int rc = step_chunk(h, k, c)) return rc;
     }
     if (h->post_in_heads && k == 1 && h->n_verifiers == 0) { HIPCHK(hipGetLastError()); return 0; }      // post-processing already ran inside the heads launch
+    return launch_postproc(h);
+}
+
+// A call of more chunks than the handle's mel buffer holds (n_chunks > max_chunks; the reference takes any length: model.py:287-298,
+// utils.py:387-401).  The reference runs its melspectrogram graph ONCE over the call, so the clamp floor "maximum - 80 dB" is the
+// call's; evaluating the call in slices of max_chunks chunks with each slice's own maximum would move the floor (a quiet start of a
+// call whose loud part comes later).  Two passes: the mel kernel over the whole call for its per-stream maximum only, then the
+// slices -- mel rows with that shared floor, one embedding and one heads evaluation per chunk, raw scores max-combined over ALL
+// chunks of the call -- and one post-processing pass.  d_pcm: [S][1280 K] on the device.
+int launch_step_long(oww_ctx* h, const int16_t* d_pcm, int K) {
+    if (h->vad) return fail(OWW_EINVAL, "with the on-device VAD network a step carries exactly one 1280-sample chunk per stream (got %d)", K);
+    if (!h->d_callmax) if (int rc = dalloc(h->stream, &h->d_callmax, (size_t)h->Spad)) return rc;
+    if (int rc = launch_mel(h, d_pcm, h->S, OWW_CHUNK * K, 8 * K, 1, nullptr, h->d_callmax, 0, 1, nullptr)) return rc;
+    for (int o = 0; o < K; o += h->kmax) {
+        const int ks = std::min(h->kmax, K - o);
+        if (int rc = launch_mel(h, d_pcm + (size_t)o * OWW_CHUNK, h->S, OWW_CHUNK * ks, 8 * ks, 1, h->d_mel, nullptr, OWW_CHUNK * K, 0, h->d_callmax)) return rc;
+        for (int c = 0; c < ks; ++c)
+            if (int rc = step_chunk(h, ks, c, o + c == 0, o + c == K - 1, false)) return rc;
+        h->k_last = ks;
+    }
+    return launch_postproc(h);
+}
+
+int launch_postproc(oww_ctx* h) {
     PostParams pp{};
     pp.raw = h->d_raw; pp.scores = h->d_scores; pp.ring = h->d_ring; pp.npred = h->d_npred;
     pp.patience = h->d_patience; pp.threshold = h->d_threshold; pp.debounce_frames = h->debounce_frames;
@@ -2161,11 +2194,33 @@ int oww_step(oww_ctx* h, const int16_t* pcm, int pcm_on_device, int32_t n_chunks
     OWW_GUARD_BEGIN
     if (!h || !h->committed) return fail(OWW_ESTATE, "oww_step: handle not committed");
     if (!pcm) return fail(OWW_EINVAL, "oww_step: pcm is null");
-    if (n_chunks < 1 || n_chunks > h->kmax) return fail(OWW_EINVAL, "oww_step: n_chunks=%d outside [1,%d]", n_chunks, h->kmax);
+    if (n_chunks < 1 || n_chunks > OWW_MAX_CALL_CHUNKS) return fail(OWW_EINVAL, "oww_step: n_chunks=%d outside [1,%d]", n_chunks, OWW_MAX_CALL_CHUNKS);
     if (int rc = range_check(h, "oww_step")) return rc;          // raised by an earlier (asynchronous) step: sticky
     HIPCHK(hipSetDevice(h->cfg.device));
     h->k_last = n_chunks;
     const size_t n_pcm = (size_t)h->S * OWW_CHUNK * n_chunks;
+    if (n_chunks > h->kmax) {                                    // longer than the mel buffer: slices that share the call's clamp floor
+        const int16_t* d_call = pcm;
+        if (!pcm_on_device) {
+            if (n_pcm > h->long_cap) {
+                if (h->d_long) { HIPCHK(hipStreamSynchronize(h->stream)); (void)dev_free(h->d_long); h->d_long = nullptr; h->long_cap = 0; }
+                if (dev_alloc(&h->d_long, n_pcm * sizeof(int16_t)) != hipSuccess) return fail(OWW_ENOMEM, "oww_step: out of device memory for a call of %d chunks", n_chunks);
+                h->long_cap = n_pcm;
+            }
+            HIPCHK(copy_async(h->d_long, pcm, n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+            d_call = h->d_long;
+        }
+        if (int rc = launch_step_long(h, d_call, n_chunks)) return rc;
+        if (scores) {
+            const size_t nb = (size_t)h->S * h->NL * sizeof(float);
+            if (nb) HIPCHK(copy_async(scores, h->d_scores, nb, scores_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        }
+        if (!scores_on_device || !pcm_on_device) {               // (the caller's host buffer is free to change when this returns)
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (int rc = range_check(h, "oww_step")) return rc;
+        }
+        return OWW_OK;
+    }
     const bool graphable = h->want_graph && n_chunks == 1 && !h->timing;
     const int16_t* d_pcm = pcm;
     if (!pcm_on_device || graphable) {

@@ -629,6 +629,11 @@ struct MelParams {
     const float* mel_taps;  // [32][16]
     int S;
     const uint8_t* stream_on;   // oww_step_masked (streaming mode): a stream with stream_on[s] == 0 keeps its sample tail; nullptr = all take part
+    // A call longer than the handle's mel buffer (oww_step with n_chunks > max_chunks) is evaluated in slices that share ONE clamp floor,
+    // the reference's: melspectrogram.onnx runs once over the whole call (utils.py:387-401), so "max - 80 dB" is the call's maximum.
+    int pcm_stride;             // samples between two streams' rows of `pcm` (0 = n_samples): a slice of a longer call
+    int max_only;               // streaming mode, first pass over the WHOLE call: only its maximum (-> smax); no rows, no tail update
+    const float* floor_max;     // streaming mode, the slices: [S] the call's maximum from that pass (replaces the slice's own)
 };
 
 // dB value and host transform of the mel front end (ipynb cell 15: 10 log10(max(p, 1e-10)); utils.py:180,206: x / 10 + 2) with the two
@@ -676,7 +681,7 @@ __device__ __forceinline__ void wave_sync() {
 // (lane l: samples 8l..8l+7 and, lanes < 21, 512+8l..): virtual index c of [tail(hist) ; pcm], zero beyond the input.
 // Issued one loop iteration ahead of its use so the HBM latency overlaps the previous FFT.
 __device__ __forceinline__ void mel_fetch(const MelParams& p, int s, int g, int wave, int lane, int hist, int4 (&raw)[2]) {
-    const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
+    const int16_t* pcm = p.pcm + (size_t)s * (p.pcm_stride ? p.pcm_stride : p.n_samples);
     const int16_t* tail = p.tail + (size_t)s * 480;
     const int c0 = g * 1280 + 320 * wave;
 #pragma unroll
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
     int4 raw[2] = {};
     if ((int)blockIdx.x < p.S) mel_fetch(p, blockIdx.x, 0, wave, lane, hist, raw);
     for (int s = blockIdx.x; s < p.S; s += gridDim.x, ++it) {
-        const int16_t* pcm = p.pcm + (size_t)s * p.n_samples;
+        const int16_t* pcm = p.pcm + (size_t)s * (p.pcm_stride ? p.pcm_stride : p.n_samples);
         const bool first = p.streaming && (p.nfeat[s] == 0);
         float vmax = -INFINITY;
         float last_db = 0.f;
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
                 if (!masked) vmax = fmaxf(vmax, db);
                 if (masked) db = INFINITY;                 // marker: becomes 1.0 below
                 last_db = db;
-                if (n_groups > 1 || !p.streaming) p.out[((size_t)s * p.n_frames + frame) * 32 + mbin] = db;
+                if ((n_groups > 1 || !p.streaming) && !p.max_only) p.out[((size_t)s * p.n_frames + frame) * 32 + mbin] = db;
             }
         }
         // ---- workgroup maximum over the whole call (the only point where the four waves meet)
@@ -848,8 +853,10 @@ __global__ __launch_bounds__(MEL_NT) void mel_kernel(MelParams p) {
         if (lane == 0) s_red[it & 1][wave] = vmax;
         __syncthreads();
         vmax = fmaxf(fmaxf(s_red[it & 1][0], s_red[it & 1][1]), fmaxf(s_red[it & 1][2], s_red[it & 1][3]));
-        if (p.streaming) {
-            const float floor_db = vmax - 80.0f;
+        if (p.max_only) {
+            if (tid == 0) p.smax[s] = vmax;
+        } else if (p.streaming) {
+            const float floor_db = (p.floor_max ? p.floor_max[s] : vmax) - 80.0f;
             for (int g = 0; g < n_groups; ++g) {
                 const int frame = g * 8 + fr;
                 if (frame >= p.n_frames) break;

@@ -298,15 +298,11 @@ class AudioFeatures:
             return n                                             # nothing processed yet: the caller repeats its last scores
         k = n // CHUNK
         # one device step: mel over the k chunks (one clamp floor), k embeddings, heads per chunk, max over chunks.  A call
-        # longer than max_chunks x 1280 samples (2.56 s by default; the reference takes any length, model.py:287-298) is fed
-        # in slices of max_chunks chunks and the raw scores are max-combined the same way -- the one deviation: the mel clamp
-        # floor (max - 80 dB) is then taken per slice instead of over the whole call.
-        cap = self.engine.max_chunks * CHUNK
-        raw = None
-        for o in range(0, n, cap):
-            part = self.engine.step_raw(self._pending[None, o:o + cap])[0]
-            raw = part if raw is None else np.maximum(raw, part)
-        self.last_scores = raw
+        # longer than max_chunks x 1280 samples (2.56 s by default; the reference takes any length, model.py:287-298) is
+        # evaluated by the library in slices of max_chunks chunks that share the CALL's clamp floor (oww_step: one extra pass of
+        # the mel kernel finds the call's maximum first), i.e. the reference's single run of the melspectrogram graph
+        # (utils.py:387-401); calls beyond the ABI's limit (5.5 minutes in one predict()) are refused by it.
+        self.last_scores = self.engine.step_raw(self._pending[None])[0]
         self._n_features = min(self._n_features + k, self.feature_buffer_max_len)
         self._pending = np.empty(0, dtype=np.int16)
         self.accumulated_samples = 0

@@ -25,8 +25,9 @@ N_PROBE = 64
 N_FRAMES = 16
 SEED_WEIGHTS = 1234
 SEED_INIT_NOISE = 3
-PROBE_VERSION = 3           # bump when probe_pcm changes (part of the cache file name)
+PROBE_VERSION = 4           # bump when probe_pcm or the result layout changes (part of the cache file name)
 HEADS3 = ("alexa", "hey_mycroft", "hey_jarvis")
+HEADS6 = ("alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather")   # the reference's default Model(): model.py:84-87
 _GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_streaming.npz")
 
 
@@ -73,10 +74,25 @@ def init_noise() -> np.ndarray:
 VAD_THRESHOLD = 0.5        # the gate of BASELINE configs[4] (model.py:366-381) as bench.py / the tests configure it
 
 
+def labels_of(head_names: Sequence[str]) -> List[str]:
+    """Score columns in the engine's order: one per head, n_out per multiclass head (`timer`: 7, class 0 = the negative class included
+    -- the columns are compared raw, before any class_mapping drops it: model.py:313-317)."""
+    from openwakeword_amd import weights as W
+    out: List[str] = []
+    for n in head_names:
+        n_out = W.HEAD_CATALOGUE[n][3]
+        out.extend([n] if n_out == 1 else [f"{n}#{i}" for i in range(n_out)])
+    return out
+
+
+def _class_mapping(heads):
+    return {n: {str(i): f"{n}#{i}" for i in range(int(h["n_out"]))} for n, h in heads.items() if int(h["n_out"]) > 1}
+
+
 def _model(heads, emb, vad: bool):
     from oracle import oww_oracle as O
     if not vad:
-        return O.OracleModel(heads, emb, init_noise=init_noise())
+        return O.OracleModel(heads, emb, init_noise=init_noise(), class_mapping=_class_mapping(heads))
     from oracle import vad_standin as V
     from openwakeword_amd import weights as W
     return O.OracleModel(heads, emb, init_noise=init_noise(), vad_threshold=VAD_THRESHOLD,
@@ -89,14 +105,15 @@ def _worker(args) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
     proto = _model(heads, emb, vad)
     feats0 = np.array(proto.preprocessor.features, dtype=np.float32)
     n_frames = rows[0].shape[0] // CHUNK
-    out = np.zeros((len(rows), n_frames, len(head_names)), np.float64)
+    labels = labels_of(head_names)
+    out = np.zeros((len(rows), n_frames, len(labels)), np.float64)
     last = np.zeros((len(rows), 16, 96), np.float32)
     gate = np.full((len(rows), n_frames), np.nan)                # max of the VAD ring's [-7:-4] window the gate compared (NaN: empty)
     for i, pcm in enumerate(rows):
         m = proto if i == 0 else _model(heads, emb, vad)
         for t in range(n_frames):
             p = m.predict(pcm[t * CHUNK:(t + 1) * CHUNK])
-            out[i, t] = [p[k] for k in head_names]
+            out[i, t] = [p[k] for k in labels]
             if vad:
                 window = list(m.vad.ring)[-7:-4]
                 if window:
@@ -140,19 +157,20 @@ def _run_pool(pcm: np.ndarray, head_names: List[str], workers: int, vad: bool = 
     else:
         with mp.get_context("fork").Pool(workers) as pool:      # forked from a fresh interpreter (see oracle_reference)
             res = pool.map(_worker, jobs)
-    scores = np.zeros((n, pcm.shape[1] // CHUNK, len(head_names)), np.float64)
+    scores = np.zeros((n, pcm.shape[1] // CHUNK, len(labels_of(head_names))), np.float64)
     feats = np.zeros((n, 16, 96), np.float32)
     gate = np.full((n, pcm.shape[1] // CHUNK), np.nan)
     for idx, (out, _, last, g) in zip(parts, res):
         scores[idx] = out
         feats[idx] = last
         gate[idx] = g
-    return {"scores": scores, "init_features": res[0][1], "features": feats, "heads": np.array(head_names), "vad_window_max": gate}
+    return {"scores": scores, "init_features": res[0][1], "features": feats, "heads": np.array(head_names),
+            "labels": np.array(labels_of(head_names)), "vad_window_max": gate}
 
 
 def oracle_reference(n_probe: int = N_PROBE, n_frames: int = N_FRAMES, head_names: Sequence[str] = HEADS3,
                      workers: int = 0, timeout_s: float = 1500.0, vad: bool = False) -> Dict[str, np.ndarray]:
-    """Oracle results for `probe_pcm(n_probe, n_frames)`: scores [n_probe, n_frames, n_heads] (float64), the feature-ring
+    """Oracle results for `probe_pcm(n_probe, n_frames)`: scores [n_probe, n_frames, n_labels] (float64; `labels`: labels_of), the feature-ring
     seed every stream starts from ([41, 96], oldest first) and each probe's last 16 feature rows.  With `vad` every model carries
     the voice-activity gate of BASELINE configs[4] (model.py:366-381; threshold VAD_THRESHOLD, the stand-in network with the seed-1234
     weights behind the reference's VAD wrapper) and `vad_window_max` [n_probe, n_frames] holds the value each gate decision compared

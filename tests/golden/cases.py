@@ -85,3 +85,33 @@ ONNX_VERIFIER = ("fver", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(ch
 # the argument only ever matters for single-output models, whose mapping predict() never reads), parent lookup (215-224) and
 # false-positive mining from a WAV file (428-479) on exported files
 ONNX_MAPPING = ("fmap", ["timer_custom", "alexa_custom"], "hey_jane", [{}, {"alexa_custom": {"0": "positive"}}], 0.25)
+
+# Model(enable_speex_noise_suppression=True) (model.py:201-205, 272-273, 481-504; the reference's own test: tests/test_models.py:179-215)
+# with oracle/fake_speex.py standing in for the absent `speexdsp_ns` package: cleaned audio to the preprocessor, the RAW call argument
+# to the voice-activity detector (model.py:370), predict_clip's chunking on top; (case id, heads, clip, predict_clip kwargs, vad_threshold)
+ONNX_SPEEX_CASES = [
+    ("fspeex", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=1280), 0.0),
+    ("fspeex2560", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=2560), 0.0),
+    ("fspeexvad", ["alexa_custom"], "hey_jane", dict(chunk_size=1280), 0.2),
+]
+
+# predict() calls LONGER than a handle's mel buffer (max_chunks): the reference runs melspectrogram.onnx once over the whole call
+# (utils.py:387-401), so its clamp floor "maximum - 80 dB" is the call's -- a call whose loudest frame sits in its LAST chunk clamps
+# the near-silent chunks before it.  (case id, heads, call sizes); the audio is long_call_pcm(alexa clip)
+ONNX_LONG = ("flong", ["alexa_custom", "mycroft_custom"], [1280] * 6 + [6400, 1280, 6400, 2560, 1280])
+
+
+def long_call_pcm(alexa_clip):
+    """int16 audio for ONNX_LONG: six loud warm-up chunks; a 5-chunk call = 4 chunks of +-3 LSB noise, then the loudest 80 ms of the
+    clip; a loud chunk; a 5-chunk call the other way round (loud first); a quiet 2-chunk call; a loud chunk."""
+    import numpy as np
+    r = np.random.default_rng(4242)
+    c = np.asarray(alexa_clip, np.int16)
+    c = np.resize(c, max(len(c), 1280 * 12))                              # (a short clip is tiled)
+    i = int(np.argmax(np.abs(c.astype(np.int32))))
+    lo = min(max(0, i - 640 - 1280 * 5), len(c) - 1280 * 10)
+    loud = c[lo: lo + 1280 * 10].reshape(10, 1280)
+    peak = loud[int(np.argmax(np.abs(loud.astype(np.int32)).max(axis=1)))]
+    quiet = lambda n: r.integers(-3, 4, 1280 * n).astype(np.int16)      # noqa: E731
+    parts = [loud[:6].reshape(-1), quiet(4), peak, loud[6], peak, quiet(4), quiet(2), loud[7]]
+    return np.concatenate(parts)

@@ -75,6 +75,24 @@ def main():
             out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
             out[f"{cid}/vad"] = np.array(list(mdl.vad.prediction_buffer), dtype=np.float64)
             out[f"{cid}/ring"] = np.array([list(mdl.prediction_buffer[k]) for k in labels], dtype=np.float64)
+        # Model(enable_speex_noise_suppression=True): `speexdsp_ns` is oracle/fake_speex.py (a deterministic stateful stand-in with the
+        # package's interface -- the real one is not in this image); what is pinned is the reference's ORDER of operations around it
+        from oracle import fake_speex
+        sys.modules["speexdsp_ns"] = fake_speex.as_module()
+        for cid, head_names, clip, kw, thr in cases.ONNX_SPEEX_CASES:
+            np.random.seed(cases.SEED_NP)
+            mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx", vad_threshold=thr,
+                                     enable_speex_noise_suppression=True,
+                                     melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+            assert type(mdl.speex_ns).__module__ == "oracle.fake_speex"
+            preds = mdl.predict_clip(clips[clip], **kw)
+            labels = sorted(preds[0].keys())
+            out[f"{cid}/labels"] = np.array(labels)
+            out[f"{cid}/scores"] = np.array([[float(p[k]) for k in labels] for p in preds], dtype=np.float64)
+            out[f"{cid}/features"] = mdl.preprocessor.feature_buffer.astype(np.float32)
+            out[f"{cid}/raw_mid"] = np.array(list(mdl.preprocessor.raw_data_buffer)[-24000:-16000], dtype=np.int16)   # what the preprocessor was fed (before the trailing second of padding)
+            if thr > 0:
+                out[f"{cid}/vad"] = np.array(list(mdl.vad.prediction_buffer), dtype=np.float64)
         # a custom verifier model re-scoring the frames the base model likes (model.py:320-328)
         import verifier_fixture
         cid, head_names, clip, kw, target, vthr = cases.ONNX_VERIFIER
@@ -132,6 +150,23 @@ def main():
             rows.append([float(p[k]) for k in labels])
         out[f"{cid}/labels"] = np.array(labels)
         out[f"{cid}/scores"] = np.array(rows, dtype=np.float64)
+        # calls longer than a HIP handle's mel buffer: one run of the melspectrogram graph per call = one clamp floor per call
+        cid, head_names, sizes = cases.ONNX_LONG
+        x = cases.long_call_pcm(clips["alexa_test"])
+        assert len(x) == sum(sizes)
+        np.random.seed(cases.SEED_NP)
+        mdl = openwakeword.Model(wakeword_models=[paths[n] for n in head_names], inference_framework="onnx",
+                                 melspec_model_path=paths["melspectrogram"], embedding_model_path=paths["embedding_model"])
+        rows, o = [], 0
+        for n in sizes:
+            p = mdl.predict(x[o:o + n])
+            o += n
+            labels = sorted(p.keys())
+            rows.append([float(p[k]) for k in labels])
+        out[f"{cid}/labels"] = np.array(labels)
+        out[f"{cid}/scores"] = np.array(rows, dtype=np.float64)
+        out[f"{cid}/features"] = mdl.preprocessor.feature_buffer.astype(np.float32)
+        out[f"{cid}/mel_tail"] = mdl.preprocessor.melspectrogram_buffer[-8 * 15:].astype(np.float32)
     path = os.path.join(os.path.dirname(__file__), "ref_onnx_files.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

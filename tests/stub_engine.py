@@ -51,7 +51,7 @@ class OracleEngine:
 
     def step_raw(self, pcm):
         pcm = np.asarray(pcm)
-        assert pcm.shape[0] == 1 and pcm.shape[1] % CHUNK == 0 and pcm.shape[1] // CHUNK <= self.max_chunks
+        assert pcm.shape[0] == 1 and pcm.shape[1] % CHUNK == 0        # (any number of chunks: oww_step slices longer calls itself)
         k = pcm.shape[1] // CHUNK
         assert self._oaf(pcm[0]) == pcm.shape[1]
         out = np.full(self.n_labels, -np.inf, np.float32)

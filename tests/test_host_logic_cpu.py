@@ -88,21 +88,31 @@ def test_predict_argument_errors_and_short_calls(stub, golden):
     assert set(clock["models"]) == {"preprocessor", "alexa"}
 
 
-def test_call_longer_than_max_chunks_is_fed_in_slices(stub, golden):
-    """An 11-chunk call through an engine that takes at most 4 chunks per step: three engine steps, raw scores max-combined like the
-    reference's multi-chunk rule (model.py:287-298); the stream carries on afterwards."""
-    m = M.Model(wakeword_models=["alexa"], weights=_weights(["alexa"]), max_chunks=4)
-    clip = np.resize(golden["pcm/alexa_test"], 1280 * 11)
-    for t in range(6):
-        m.predict(clip[:1280])
+def test_call_longer_than_max_chunks_keeps_the_calls_clamp_floor(stub, golden):
+    """cases.ONNX_LONG: 5-chunk predict() calls through a Model whose engine holds ONE chunk of mel rows, against the reference's own
+    run on the exporter-written files (one run of the melspectrogram graph per call = one clamp floor, utils.py:387-401): the whole
+    call goes to the engine in one step (oww_step slices it behind a maximum pass; here the oracle engine), the stream carries on."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, sizes = cases.ONNX_LONG
+    w = cases.onnx_file_weights()
+    x = cases.long_call_pcm(golden["pcm/alexa_test"])
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights={"embedding": w["embedding"], "heads": {n: w["heads"][n] for n in head_names}},
+                max_chunks=1)
     calls = []
     real = stub[-1].step_raw
     stub[-1].step_raw = lambda pcm: (calls.append(pcm.shape[1] // 1280), real(pcm))[1]
-    out = m.predict(clip)
-    assert calls == [4, 4, 3]
-    assert set(out) == {"alexa"} and 0.0 <= out["alexa"] <= 1.0 and m.preprocessor.accumulated_samples == 0
-    again = m.predict(clip[:1280])
-    assert 0.0 <= again["alexa"] <= 1.0 and len(m.prediction_buffer["alexa"]) == 8 and calls[-1] == 1
+    labels = list(ref[f"{cid}/labels"])
+    rows, o = [], 0
+    for n in sizes:
+        p = m.predict(x[o:o + n])
+        o += n
+        rows.append([float(p[k]) for k in labels])
+    assert calls == [n // 1280 for n in sizes] and m.preprocessor.accumulated_samples == 0
+    np.testing.assert_allclose(np.array(rows), ref[f"{cid}/scores"], rtol=0, atol=2e-5)
+    feats = ref[f"{cid}/features"]
+    np.testing.assert_allclose(m.preprocessor.get_features(len(feats))[0], feats, rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize("case", cases.VAD_CASES, ids=[c[0] for c in cases.VAD_CASES])
@@ -266,3 +276,50 @@ def test_mapping_parent_lookup_and_positive_frames_match_the_reference(stub, gol
         assert all(a.shape[1] == 64000 for a in audio.values())
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("case", cases.ONNX_SPEEX_CASES, ids=[c[0] for c in cases.ONNX_SPEEX_CASES])
+def test_speex_hook_of_the_host_shim_matches_the_reference_with_the_same_stand_in(stub, golden, tmp_path, monkeypatch, case):
+    """Model(enable_speex_noise_suppression=True) (model.py:201-205, 272-273, 481-504; the reference's own test: tests/test_models.py:
+    179-215).  `speexdsp_ns` is oracle/fake_speex.py on both sides (the package is not in this image): the reference's own Model ran
+    with it on the exporter-written files (tests/golden/make_golden_onnx.py).  Pinned: ONE filter object per Model fed 160-sample
+    frames in call order, the CLEANED audio is what the preprocessor buffers (bit for bit), the RAW call argument is what the
+    voice-activity detector scores (model.py:370), predict_clip's chunking on top (chunk_size 1280 and 2560)."""
+    pytest.importorskip("torch")
+    import os
+    import sys
+    import torch_export as TE
+    from oracle import fake_speex, mini_ort
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    cid, head_names, clip, kw, thr = case
+    monkeypatch.setitem(sys.modules, "speexdsp_ns", fake_speex.as_module())
+    fake_speex.NoiseSuppression.instances.clear()
+    vad_kw = {}
+    if thr > 0:
+        path = str(tmp_path / "silero_vad.onnx")
+        try:
+            TE.export_vad(W.synthetic_vad(cases.ONNX_VAD_SEED), path)
+        except Exception as e:                                  # noqa: BLE001
+            pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+        vad_kw = dict(vad_threshold=thr, vad_session=mini_ort.InferenceSession(path))
+    fed = []
+    real_call = M.AudioFeatures.__call__
+    monkeypatch.setattr(M.AudioFeatures, "__call__", lambda self, x: (fed.append(np.array(x)), real_call(self, x))[1])
+    w = cases.onnx_file_weights()
+    np.random.seed(cases.SEED_NP)
+    m = M.Model(wakeword_models=list(head_names), weights={"embedding": w["embedding"], "heads": {n: w["heads"][n] for n in head_names}},
+                enable_speex_noise_suppression=True, **vad_kw)
+    assert type(m.speex_ns).__module__ == "oracle.fake_speex"
+    preds = m.predict_clip(golden["pcm/" + clip], **kw)
+    labels = list(ref[f"{cid}/labels"])
+    got = np.array([[float(p[k]) for k in labels] for p in preds])
+    np.testing.assert_allclose(got, ref[f"{cid}/scores"], rtol=0, atol=2e-5)
+    feats = ref[f"{cid}/features"]
+    np.testing.assert_allclose(m.preprocessor.get_features(len(feats))[0], feats, rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(np.concatenate(fed)[-24000:-16000], ref[f"{cid}/raw_mid"])      # the preprocessor saw the cleaned audio
+    assert len(fake_speex.NoiseSuppression.instances) == 1 and fake_speex.NoiseSuppression.instances[0].n_frames * 160 == sum(len(f) for f in fed)
+    if thr > 0:
+        np.testing.assert_allclose(np.array(m.vad.prediction_buffer), ref[f"{cid}/vad"], rtol=0, atol=1e-6)   # ... and the VAD the raw audio
+        np.testing.assert_allclose(ref[f"{cid}/vad"], ref["fvad20/vad"], rtol=0, atol=0)        # (the reference's VAD ring with and without Speex: same clip)
+    assert np.abs(ref[f"{cid}/scores"] - (ref["f1280/scores"] if cid == "fspeex" else 0)).max() > 0.05    # the filter matters
+    m.close()

@@ -262,21 +262,46 @@ class _Verifier:
 
 
 @gpu
-def test_call_longer_than_max_chunks_is_fed_in_slices(golden):
-    """a predict() call longer than max_chunks x 1280 samples used to raise AFTER mutating the buffers and left
-    the stream stuck; it is now fed in slices (raw scores max-combined like the reference's multi-chunk rule) and the stream
-    carries on.  The reference takes any length (model.py:287-298)."""
+@pytest.mark.parametrize("max_chunks", [1, 2, 32])
+def test_call_longer_than_max_chunks_keeps_the_calls_clamp_floor(tmp_path, golden, max_chunks):
+    """cases.ONNX_LONG on the HIP Model, files loaded by path: 5-chunk predict() calls whose loudest frame sits in the LAST (or first)
+    chunk, through handles that hold 1, 2 or 32 chunks of mel rows.  The reference runs its melspectrogram graph once per call
+    (utils.py:387-401), so the clamp floor is the call's; oww_step evaluates a call longer than max_chunks in slices behind one pass
+    of the mel kernel that finds that maximum -- scores, the feature ring and the (clamped) mel rows of the last slice against the
+    reference's own run on the same files, 1e-4; and the three handle sizes agree with each other to fp32 round-off."""
+    pytest.importorskip("torch")
+    import os
+    import torch_export as TE
     from openwakeword_amd import Model
-    m = Model(wakeword_models=["alexa"], weights=_weights(["alexa"]), max_chunks=4)
+    cid, head_names, sizes = cases.ONNX_LONG
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
     try:
-        clip = np.resize(golden["pcm/alexa_test"], 1280 * 11)
-        for t in range(6):
-            m.predict(clip[:1280])
-        out = m.predict(clip)                           # 11 chunks > max_chunks = 4: three slices
-        assert set(out) == {"alexa"} and 0.0 <= out["alexa"] <= 1.0
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    x = cases.long_call_pcm(golden["pcm/alexa_test"])
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=[paths[n] for n in head_names], melspec_model_path=paths["melspectrogram"],
+              embedding_model_path=paths["embedding_model"], max_chunks=max_chunks)
+    try:
+        labels = list(ref[f"{cid}/labels"])
+        rows, o = [], 0
+        for n in sizes:
+            p = m.predict(x[o:o + n])
+            o += n
+            rows.append([float(p[k]) for k in labels])
+            k_last = 5 if max_chunks >= 5 else (5 % max_chunks or max_chunks)          # chunks of a 5-chunk call's last slice
+            if n == 6400 and o == 1280 * 6 + 6400 and k_last > 1:          # the call with the loud LAST chunk: its quiet rows sit on the call's floor
+                # (a one-chunk slice leaves no rows to read back: oww_get_mel refuses, the fused front end keeps them in registers)
+                got_mel = m._engine.get_mel(0, 8 * k_last)
+                want_mel = ref[f"{cid}/mel_tail"]           # rows of the last 15 chunks; this call ends 9 chunks before the end
+                want = want_mel[len(want_mel) - 8 * 9 - 8 * k_last: len(want_mel) - 8 * 9]
+                np.testing.assert_allclose(got_mel, want, rtol=0, atol=5e-4)
+        np.testing.assert_allclose(np.array(rows), ref[f"{cid}/scores"], rtol=0, atol=TOL_SCORE)
+        feats = ref[f"{cid}/features"]
+        n = min(len(feats), 120)
+        np.testing.assert_allclose(m.preprocessor.get_features(n)[0], feats[-n:], rtol=0, atol=2e-4)
         assert m.preprocessor.accumulated_samples == 0
-        again = m.predict(clip[:1280])                  # the stream is not stuck
-        assert 0.0 <= again["alexa"] <= 1.0 and len(m.prediction_buffer["alexa"]) == 8
     finally:
         m.close()
 
@@ -799,5 +824,53 @@ def test_mapping_parent_lookup_and_positive_frames_on_exported_files(tmp_path, g
             np.testing.assert_allclose(v, want, rtol=0, atol=2e-4)
         audio = m._get_positive_prediction_frames(wav, threshold=fthr, return_type="audio")
         assert all(a.shape[1] == 64000 for a in audio.values())
+    finally:
+        m.close()
+
+
+@gpu
+@pytest.mark.parametrize("case", cases.ONNX_SPEEX_CASES, ids=[c[0] for c in cases.ONNX_SPEEX_CASES])
+def test_hip_model_with_speex_matches_the_reference_with_the_same_stand_in(tmp_path, golden, monkeypatch, case):
+    """(f)4, the Speex hook on the HIP Model: files loaded by path, `speexdsp_ns` = oracle/fake_speex.py as in the reference's run
+    (tests/golden/make_golden_onnx.py; the real package is not in this image).  Cleaned audio to the device front end (bit for bit what
+    the reference's preprocessor buffered), raw audio to the voice-activity session (model.py:370), chunked by predict_clip."""
+    pytest.importorskip("torch")
+    import os
+    import sys
+    import torch_export as TE
+    from oracle import fake_speex, mini_ort
+    from openwakeword_amd import Model, model as M
+    cid, head_names, clip, kw, thr = case
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_onnx_files.npz"))
+    try:
+        paths = TE.export_reference_files(str(tmp_path), cases.onnx_file_weights(), head_opsets=cases.ONNX_HEAD_OPSETS)
+        vad_kw = {}
+        if thr > 0:
+            vpath = str(tmp_path / "silero_vad.onnx")
+            TE.export_vad(W.synthetic_vad(cases.ONNX_VAD_SEED), vpath)
+            vad_kw = dict(vad_threshold=thr, vad_session=mini_ort.InferenceSession(vpath))
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    monkeypatch.setitem(sys.modules, "speexdsp_ns", fake_speex.as_module())
+    fake_speex.NoiseSuppression.instances.clear()
+    fed = []
+    real_call = M.AudioFeatures.__call__
+    monkeypatch.setattr(M.AudioFeatures, "__call__", lambda self, x: (fed.append(np.array(x)), real_call(self, x))[1])
+    np.random.seed(cases.SEED_NP)
+    m = Model(wakeword_models=[paths[n] for n in head_names], melspec_model_path=paths["melspectrogram"],
+              embedding_model_path=paths["embedding_model"], enable_speex_noise_suppression=True, **vad_kw)
+    try:
+        preds = m.predict_clip(golden["pcm/" + clip], **kw)
+        labels = list(ref[f"{cid}/labels"])
+        assert sorted(preds[0].keys()) == labels
+        got = np.array([[float(p[k]) for k in labels] for p in preds])
+        np.testing.assert_allclose(got, ref[f"{cid}/scores"], rtol=0, atol=TOL_SCORE)
+        feats = ref[f"{cid}/features"]
+        n = min(len(feats), 120)
+        np.testing.assert_allclose(m.preprocessor.get_features(n)[0], feats[-n:], rtol=0, atol=2e-4)
+        np.testing.assert_array_equal(np.concatenate(fed)[-24000:-16000], ref[f"{cid}/raw_mid"])
+        assert len(fake_speex.NoiseSuppression.instances) == 1
+        if thr > 0:
+            np.testing.assert_allclose(np.array(m.vad.prediction_buffer), ref[f"{cid}/vad"], rtol=0, atol=1e-6)
     finally:
         m.close()

@@ -49,10 +49,14 @@ def test_oracle_reference_worker_matches_direct_call():
     (65536, PS.HEADS3, 3),                         # configs[2]
     (131072, PS.HEADS3, 3),                        # configs[3], one GPU's shard
     (131072, PS.HEADS3, 1),                        # the same on the exact-fp32 family
-], ids=["c1_4096x1", "c2_65536x3", "c3_131072x3", "c3_131072x3_fp32"])
+    (131072, PS.HEADS6, 3),                        # the reference's default Model(): six models, 12 score columns (model.py:84-87)
+], ids=["c1_4096x1", "c2_65536x3", "c3_131072x3", "c3_131072x3_fp32", "default6_131072x6"])
 def test_probe_streams_match_oracle_inside_a_full_size_batch(probe, n_streams, head_names, family):
     pcm, ref = probe
-    cols = [list(PS.HEADS3).index(h) for h in head_names]
+    if not set(head_names) <= set(PS.HEADS3):
+        ref = PS.oracle_reference(head_names=head_names)
+    ref_labels = [str(x) for x in ref["labels"]]
+    cols = [ref_labels.index(l) for l in PS.labels_of(head_names)]
     emb, heads = PS._weights(head_names)
     ids = PS.probe_stream_ids(n_streams)
     r = np.random.default_rng(n_streams)
