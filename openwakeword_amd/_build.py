@@ -19,15 +19,19 @@ def lib_path() -> str:
     return os.environ.get("OWW_LIB") or LIB
 
 
-def source_hash() -> str:
-    """First 16 hex digits of the SHA-256 over the library's sources (csrc/ + include/owwhip.h): compiled into the library
-    (oww_build_info) and stored with every rocprofv3 counter summary under profiles/, so that bench.py can tell whether a committed
-    PMC pass belongs to the kernels it is timing."""
+def source_hash(defines: tuple = (), extra_flags: str = "") -> str:
+    """First 16 hex digits of the SHA-256 over what determines the library's kernels: the sources (csrc/ + include/owwhip.h), the -D
+    defines of a variant build and any extra hipcc flags (OWW_HIPCC_FLAGS) -- compiled into the library (oww_build_info) and stored
+    with every rocprofv3 counter summary under profiles/, so that bench.py can tell whether a committed PMC pass belongs to the
+    kernels it is timing (an A/B build with OWH_* defines must not be priced with the default build's counters)."""
     import hashlib
     h = hashlib.sha256()
     for d in DEPS:
         with open(d, "rb") as f:
             h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    variant = " ".join(sorted(defines)) + "|" + " ".join(extra_flags.split())
+    if variant != "|":                         # (the default build hashes exactly as before: sources only)
+        h.update(b"\0variant\0" + variant.encode())
     return h.hexdigest()[:16]
 
 
@@ -43,8 +47,9 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, de
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC,
            "-I" + os.path.join(ROOT, "include"), "-o", target + ".tmp", "-Wall", "-Wno-unused-function"]
     cmd += ["-D" + d for d in defines]
-    cmd += ['-DOWW_SRC_SHA16="' + source_hash() + '"']
-    cmd += os.environ.get("OWW_HIPCC_FLAGS", "").split()          # (diagnostic builds only, e.g. -mllvm -amdgpu-waitcnt-forcezero)
+    extra = os.environ.get("OWW_HIPCC_FLAGS", "")
+    cmd += ['-DOWW_SRC_SHA16="' + source_hash(tuple(defines), extra) + '"']
+    cmd += extra.split()          # (diagnostic builds only, e.g. -mllvm -amdgpu-waitcnt-forcezero)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -162,10 +162,13 @@ class StreamEngine:
             if isinstance(calibration_pcm, str):
                 calibration_pcm = default_calibration_pcm() if calibration_pcm == "default" else None
             if calibration_pcm is not None and int(use_mfma) == 3:
-                if np.asarray(calibration_pcm).dtype != np.int16:
+                cal = np.asarray(calibration_pcm)
+                if cal.dtype.kind not in "iu":
                     # (float audio in [-1, 1] would be truncated to silence and the scale ladder calibrated on nothing)
-                    raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {np.asarray(calibration_pcm).dtype} data.")
-                cal = np.ascontiguousarray(calibration_pcm, dtype=np.int16)
+                    raise ValueError(f"Input data must be 16-bit integers (i.e., 16-bit PCM audio). You provided {cal.dtype} data.")
+                if cal.size and (int(cal.min()) < -32768 or int(cal.max()) > 32767):      # wider integer types: valid 16-bit PCM only
+                    raise ValueError(f"calibration_pcm holds values outside the 16-bit PCM range ({int(cal.min())} .. {int(cal.max())})")
+                cal = np.ascontiguousarray(cal, dtype=np.int16)
                 if cal.ndim != 2 or cal.shape[1] < CHUNK:
                     raise ValueError("calibration_pcm must be int16 [n_streams, n_frames * 1280]")
                 n_frames = cal.shape[1] // CHUNK

@@ -86,21 +86,23 @@ def resolve_weights(weights: Union[str, dict, None]):
 
 def _verify_melspectrogram(mel_path: str) -> None:
     """Hold a melspectrogram graph file to the analytic HIP front end (onnx_ingest.verify_melspectrogram).  A parameter FOUND to differ
-    (window, hop, filter bank, amin, top_db ...) refuses; a structure the verifier cannot follow warns and goes on with the published
-    recipe; OWW_TRUST_MELSPECTROGRAM=1 skips the check."""
+    (window, hop, filter bank, amin, top_db ...) refuses.  A structure the verifier cannot follow (an exporter idiom it does not know)
+    is not waved through: the file is then EVALUATED on probe audio (onnx_ingest.probe_melspectrogram) and must reproduce the recipe
+    numerically, else it is refused too.  OWW_TRUST_MELSPECTROGRAM=1 is the only way past both checks."""
     if os.environ.get("OWW_TRUST_MELSPECTROGRAM") == "1":
         return
     from . import onnx_ingest
+    hint = (".  The HIP front end computes the published recipe only; if this graph is known to be equivalent, set "
+            "OWW_TRUST_MELSPECTROGRAM=1 and hold the result to tests/test_real_reference.py")
     try:
         onnx_ingest.verify_melspectrogram(mel_path)
     except onnx_ingest.GraphIdiomUnknown as e:
-        import warnings
-        warnings.warn(f"{e} -- the melspectrogram graph could not be verified against the analytic HIP front end (no parameter was found "
-                      "to differ); going on with the published recipe.  Hold the result to tests/test_real_reference.py", RuntimeWarning)
+        try:
+            onnx_ingest.probe_melspectrogram(mel_path)
+        except ValueError as e2:
+            raise ValueError(f"{e}; and the numeric check did not clear it either: {e2}{hint}") from e2
     except ValueError as e:
-        raise ValueError(f"{e}.  The HIP front end computes the published recipe only; if this graph is known to be equivalent "
-                         "(an exporter idiom the verifier does not know), set OWW_TRUST_MELSPECTROGRAM=1 and hold the result to "
-                         "tests/test_real_reference.py") from e
+        raise ValueError(f"{e}{hint}") from e
 
 
 def resolve_embedding(embedding: Optional[dict], seed: Optional[int], embedding_model_path: str = "",

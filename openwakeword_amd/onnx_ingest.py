@@ -163,7 +163,8 @@ def load_graph(path: str) -> dict:
     file.  Constant nodes become initializers; shape-only operators on constants (Transpose / Reshape / Identity / Cast / Squeeze /
     Unsqueeze of an initializer -- a weight stored HWIO behind a Transpose, a scalar behind a Cast) are folded away; subgraph
     attributes (If branches) are graphs of the same form under attrs[...]."""
-    data = open(path, "rb").read()
+    with open(path, "rb") as f:
+        data = f.read()
     graph = None
     try:
         for fno, wt, v in _fields(data):
@@ -933,6 +934,171 @@ def verify_melspectrogram(path: str, tol: float = 1e-4) -> dict:
     if len(clampers) != 1 or cur not in clampers[0]["inputs"]:
         fl.refuse("the log-mel values are not clamped from below at (maximum - top_db)", unknown=True)
     return {"stft_kernel_max_abs_diff": worst, "filterbank_max_abs_diff": fb_diff, "log_factor": factor, "top_db": top_db}
+
+
+# ---- numeric probe of a melspectrogram graph the walker cannot follow -------------------------------------------------------------
+class _ProbeUnsupported(ValueError):
+    pass
+
+
+def _run_graph(g: dict, feeds: Dict[str, np.ndarray]) -> List[np.ndarray]:
+    """Evaluate a (small, straight-line) fp32 graph with numpy: the operators a log-mel front end can be written with.  Load-time
+    VERIFICATION only (probe_melspectrogram) -- nothing on the scoring path runs through it.  Raises _ProbeUnsupported on anything else."""
+    env: Dict[str, np.ndarray] = dict(g["initializers"])
+    env.update(feeds)
+
+    def axes_of(n, idx=1):
+        a = n["attrs"].get("axes")
+        if a is None and len(n["inputs"]) > idx and n["inputs"][idx]:
+            a = np.asarray(env[n["inputs"][idx]]).reshape(-1).tolist()
+        return None if a is None else [int(v) for v in a]
+
+    def conv(x, w, n):
+        at = n["attrs"]
+        if int(at.get("group", 1) or 1) != 1 or any(int(d) != 1 for d in (at.get("dilations") or [1])):
+            raise _ProbeUnsupported("grouped / dilated Conv")
+        if (at.get("auto_pad", "NOTSET") or "NOTSET") not in ("NOTSET", "VALID"):
+            raise _ProbeUnsupported("Conv auto_pad")
+        nd = x.ndim - 2
+        st = [int(v) for v in (at.get("strides") or [1] * nd)]
+        pads = [int(v) for v in (at.get("pads") or [0] * (2 * nd))]
+        x = np.pad(x, [(0, 0), (0, 0)] + [(pads[i], pads[i + nd]) for i in range(nd)])
+        win = np.lib.stride_tricks.sliding_window_view(x, w.shape[2:], axis=tuple(range(2, 2 + nd)))
+        win = win[(slice(None), slice(None)) + tuple(slice(None, None, s_) for s_ in st)]       # [N, C, out..., k...]
+        out = np.tensordot(win, w, axes=([1] + list(range(2 + nd, 2 + 2 * nd)), [1] + list(range(2, 2 + nd))))   # [N, out..., M]
+        out = np.moveaxis(out, -1, 1)
+        if len(n["inputs"]) > 2 and n["inputs"][2]:
+            out = out + env[n["inputs"][2]].reshape((1, -1) + (1,) * nd)
+        return out.astype(np.float32)
+
+    binary = {"Add": np.add, "Sub": np.subtract, "Mul": np.multiply, "Div": np.divide, "Pow": np.power}
+    unary = {"Log": np.log, "Sqrt": np.sqrt, "Abs": np.abs, "Neg": np.negative, "Exp": np.exp, "Relu": lambda v: np.maximum(v, 0), "Identity": lambda v: v}
+    for n in g["nodes"]:
+        op, at = n["op"], n["attrs"]
+        x = [env[i] if i else None for i in n["inputs"]]
+        with np.errstate(all="ignore"):
+            if op in binary:
+                y = binary[op](x[0], x[1])
+                y = y.astype(np.result_type(x[0], x[1])) if isinstance(y, np.ndarray) else np.asarray(y)
+            elif op in unary:
+                y = unary[op](x[0])
+            elif op in ("Max", "Min"):
+                y = x[0]
+                for o in x[1:]:
+                    y = (np.maximum if op == "Max" else np.minimum)(y, o)
+            elif op == "Clip":
+                lo = at.get("min") if len(x) < 2 or x[1] is None else x[1]
+                hi = at.get("max") if len(x) < 3 or x[2] is None else x[2]
+                y = x[0]
+                y = np.maximum(y, lo) if lo is not None else y
+                y = np.minimum(y, hi) if hi is not None else y
+            elif op == "Conv":
+                y = conv(np.asarray(x[0], np.float32), np.asarray(x[1], np.float32), n)
+            elif op == "MatMul":
+                y = np.matmul(x[0], x[1])
+            elif op in ("ReduceMax", "ReduceSum", "ReduceMean", "ReduceMin"):
+                ax = axes_of(n)
+                fn = {"ReduceMax": np.max, "ReduceSum": np.sum, "ReduceMean": np.mean, "ReduceMin": np.min}[op]
+                y = fn(x[0], axis=None if ax is None else tuple(ax), keepdims=bool(at.get("keepdims", 1)))
+            elif op == "Transpose":
+                y = np.transpose(x[0], at.get("perm") or list(range(x[0].ndim))[::-1])
+            elif op == "Reshape":
+                shp = [int(d) for d in np.asarray(x[1]).reshape(-1)]
+                y = x[0].reshape([x[0].shape[i] if d == 0 else d for i, d in enumerate(shp)])
+            elif op == "Flatten":
+                a = int(at.get("axis", 1))
+                y = x[0].reshape(int(np.prod(x[0].shape[:a], dtype=np.int64)), -1)
+            elif op == "Unsqueeze":
+                y = x[0]
+                for a in sorted(a_ if a_ >= 0 else a_ + x[0].ndim + len(axes_of(n)) for a_ in axes_of(n)):
+                    y = np.expand_dims(y, a)
+            elif op == "Squeeze":
+                ax = axes_of(n)
+                y = np.squeeze(x[0], axis=None if ax is None else tuple(ax))
+            elif op == "Cast":
+                y = np.asarray(x[0]).astype(_DTYPES.get(at.get("to", 1), np.float32))
+            elif op == "Shape":
+                y = np.asarray(x[0].shape, np.int64)
+            elif op == "Gather":
+                y = np.take(x[0], np.asarray(x[1], np.int64), axis=int(at.get("axis", 0)))
+            elif op == "Concat":
+                y = np.concatenate([np.atleast_1d(v) for v in x], axis=int(at.get("axis", 0)))
+            elif op == "Slice":
+                starts, ends = np.asarray(x[1]).reshape(-1), np.asarray(x[2]).reshape(-1)
+                axes = np.asarray(x[3]).reshape(-1) if len(x) > 3 and x[3] is not None else np.arange(len(starts))
+                steps = np.asarray(x[4]).reshape(-1) if len(x) > 4 and x[4] is not None else np.ones(len(starts), np.int64)
+                sl = [slice(None)] * x[0].ndim
+                for a, b, e, st_ in zip(axes, starts, ends, steps):
+                    sl[int(a)] = slice(int(b), int(min(e, np.iinfo(np.int64).max)), int(st_))
+                y = x[0][tuple(sl)]
+            elif op == "Pad":
+                pads = at.get("pads") if len(x) < 2 or x[1] is None else np.asarray(x[1]).reshape(-1).tolist()
+                nd = x[0].ndim
+                if (at.get("mode", "constant") or "constant") != "constant":
+                    raise _ProbeUnsupported("Pad mode")
+                y = np.pad(x[0], [(int(pads[i]), int(pads[i + nd])) for i in range(nd)])
+            elif op == "Expand":
+                y = x[0] * np.ones([int(d) for d in np.asarray(x[1]).reshape(-1)], x[0].dtype)
+            elif op == "ConstantOfShape":
+                v = at.get("value")
+                y = np.full([int(d) for d in np.asarray(x[0]).reshape(-1)], v.reshape(-1)[0] if isinstance(v, np.ndarray) else 0.0,
+                            v.dtype if isinstance(v, np.ndarray) else np.float32)
+            else:
+                raise _ProbeUnsupported(f"operator {op}")
+        env[n["outputs"][0]] = np.asarray(y)
+    return [env[o] for o in g["outputs"]]
+
+
+def analytic_logmel_db(x: np.ndarray) -> np.ndarray:
+    """The recipe of the HIP front end in numpy float64 (SURVEY Appendix A; csrc/owwhip_fused.h, owwhip_kernels.h::mel_kernel): int16
+    samples [n] as floats -> dB rows [F, 32] with the call's clamp floor."""
+    x = np.asarray(x, np.float64)
+    F = (len(x) - W.N_FFT) // W.HOP + 1
+    win = np.zeros(W.N_FFT)
+    lo = (W.N_FFT - W.WIN) // 2
+    win[lo:lo + W.WIN] = W.hann_window().astype(np.float64)
+    fr = np.lib.stride_tricks.sliding_window_view(x, W.N_FFT)[::W.HOP][:F] * win
+    p = np.abs(np.fft.rfft(fr, axis=1)) ** 2
+    db = 10.0 * np.log10(np.maximum(p @ W.mel_filterbank().astype(np.float64), 1e-10))
+    return np.maximum(db, db.max() - 80.0)
+
+
+def probe_melspectrogram(path: str, tol_db: float = 2e-2) -> dict:
+    """Numeric check of a melspectrogram graph whose STRUCTURE verify_melspectrogram could not follow (GraphIdiomUnknown): the file is
+    evaluated (numpy, _run_graph) on probe audio -- Gaussian noise at four levels, silence inside a loud call (the clamp floor), full
+    scale square wave, a 1 kHz tone, several call lengths -- and must reproduce the analytic recipe to `tol_db` (0.02 dB = 2e-3 in the
+    x/10 + 2 units the embedding network sees, far below what a different window / hop / bank / top_db / offset would move).  Returns
+    the largest difference; raises ValueError when the file computes something else or uses an operator the evaluator does not have."""
+    g = load_graph(path)
+    fl = _Flow(g, path)
+    name = fl.start()
+    r = np.random.default_rng(0x0E1)
+    t = np.arange(1280 * 3 + 480)
+    probes = [np.clip(np.round(r.normal(0, a, n)), -32768, 32767) for a, n in ((30, 1760), (300, 1760), (3000, 3040), (12000, 4320))]
+    loud = np.clip(np.round(r.normal(0, 9000, 4320)), -32768, 32767)
+    loud[800:2600] = 0.0                                                       # silence inside a loud call: rows on the clamp floor
+    probes += [loud, np.where((t // 8) % 2, 32767.0, -32768.0), np.round(8000 * np.sin(2 * np.pi * 1000 * t / 16000.0)), np.zeros(1760)]
+    worst = 0.0
+    for x in probes:
+        try:
+            out = _run_graph(g, {name: np.asarray(x, np.float32)[None, :]})[0]
+        except _ProbeUnsupported as e:
+            raise ValueError(f"{path}: cannot evaluate the melspectrogram graph for a numeric check ({e})") from e
+        except Exception as e:                                                  # noqa: BLE001  (shape mismatch inside the evaluator etc.)
+            raise ValueError(f"{path}: evaluating the melspectrogram graph failed ({type(e).__name__}: {e})") from e
+        want = analytic_logmel_db(x)
+        got = np.asarray(out, np.float64)
+        if got.size != want.size:
+            raise ValueError(f"{path}: the graph returns {got.shape} for {len(x)} samples, the front end produces {want.shape} rows")
+        got = got.reshape(-1, W.N_MELS) if got.shape[-1] == W.N_MELS else np.squeeze(got)
+        if got.shape != want.shape:
+            raise ValueError(f"{path}: the graph returns {np.asarray(out).shape} for {len(x)} samples, the front end produces {want.shape} rows")
+        d = float(np.abs(got - want).max())
+        if not np.isfinite(d) or d > tol_db:
+            raise ValueError(f"{path}: the graph's log-mel rows differ from the HIP front end's recipe by {d:.3g} dB on probe audio "
+                             f"(tolerance {tol_db} dB): it computes a different front end")
+        worst = max(worst, d)
+    return {"probe_max_abs_diff_db": worst, "n_probes": len(probes)}
 
 
 # ------------------------------------------------------------------------------------------- voice-activity network

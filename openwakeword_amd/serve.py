@@ -148,7 +148,7 @@ def cohort_distance(a, b) -> float:
 
 class _Client:
     __slots__ = ("cid", "slot", "ws", "rate", "pending", "n_pending", "n_steps", "closed", "in_flight", "outbox", "sender", "arrivals",
-                 "n_arrived")
+                 "n_arrived", "reaped")
 
     def __init__(self, slot: Optional[int], ws, cid: int = -1):
         self.cid, self.slot, self.ws, self.rate = cid, slot, ws, 16000
@@ -156,6 +156,7 @@ class _Client:
         self.n_pending = 0
         self.n_steps = 0
         self.closed = False
+        self.reaped = False           # its slot went back to the pool (once: _reap); nothing of this connection may touch a slot again
         self.in_flight = 0            # submitted steps whose scores for this client have not been dispatched yet
         self.outbox: "collections.deque" = collections.deque()     # activation messages not yet written to the socket, in step order
         self.sender: Optional[asyncio.Task] = None                  # the one task that drains `outbox`
@@ -354,6 +355,10 @@ class FanInServer:
                         break
                     c.rate = rate
                 elif msg.type == WSMsgType.BINARY:
+                    if c.closed:
+                        # dropped by the server (send timeout, unread activations): its slot is being -- or has been -- returned and may
+                        # already belong to another connection; audio that still arrives is not staged, the handler ends
+                        break
                     n = len(msg.data) // 2
                     if c.slot is None and n:
                         # the first audio: place the connection next to the ones whose chunks fall due in the same rounds.  A slot
@@ -372,7 +377,8 @@ class FanInServer:
                     break
         finally:
             c.closed = True          # the pump scores what the client still delivered, then returns the slot to the pool
-            self._closing.add(c)
+            if not c.reaped:         # (a connection the server dropped earlier may have been reaped while this handler still ran)
+                self._closing.add(c)
             self._have_chunk.set()
         return ws
 
@@ -381,14 +387,20 @@ class FanInServer:
         if not self._closing:
             return
         for c in list(self._closing):
+            if c.reaped:                                    # one-shot: a second pass must not release a slot that has a new owner
+                self._closing.discard(c)
+                continue
             if c.slot is not None and (c.n_pending >= CHUNK or self._inflight[c.slot] or self._on[self._fill][c.slot]):
                 continue
             self._closing.discard(c)
             self._more.discard(c)
             self.conns.pop(c.cid, None)
-            if c.slot is not None:
-                del self.clients[c.slot]
-                self.slots.release(c.slot)
+            slot, c.slot, c.reaped = c.slot, None, True     # the connection is severed from its slot before the pool sees it again
+            c.pending.clear(); c.n_pending = 0
+            if slot is not None:
+                if self.clients.get(slot) is c:
+                    del self.clients[slot]
+                self.slots.release(slot)
 
     # ---- the one place steps are put together
     def _post(self, c: "_Client", text: str) -> None:
@@ -424,8 +436,14 @@ class FanInServer:
                 await asyncio.wait_for(c.ws.send_str(text), timeout=self.send_timeout_s)
             except (ConnectionError, RuntimeError, asyncio.TimeoutError):
                 c.closed = True
-                self._closing.add(c)
+                if not c.reaped:
+                    self._closing.add(c)
                 c.outbox.clear()
+                self._have_chunk.set()
+                try:                                        # end the websocket handler too: it would go on reading audio for a dead peer
+                    await asyncio.wait_for(c.ws.close(code=1008, message=b"activation messages not delivered"), timeout=self.send_timeout_s)
+                except Exception:                           # noqa: BLE001  (the socket is already gone)
+                    pass
 
     def _step_now(self, pcm: np.ndarray, on: np.ndarray):
         """(GPU thread) one whole step; also returns what it took THERE -- the event loop's own delays must not enter the decision
@@ -582,6 +600,49 @@ class FanInServer:
             raise
 
 
+def _supervise(cmd: List[str], n: int, poll_s: float = 0.5) -> int:
+    """Parent of `--workers N`: start the worker processes in their own session, forward SIGTERM / SIGINT to them, and watch ALL of
+    them -- when any worker ends (a GPU fault, an exception) the others are stopped and the exit code is its own, so that a process
+    supervisor restarts the whole set instead of serving on with a silent hole.  Workers never outlive the parent's
+    signal handling: every exit path terminates, then kills, what is still running.  Returns the exit code."""
+    import signal
+    import subprocess
+    import time
+    procs = [subprocess.Popen(cmd, start_new_session=True) for _ in range(n)]
+    stop = {"sig": 0}
+
+    def on_signal(signum, _frame):
+        stop["sig"] = signum
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    code = 0
+    try:
+        while not stop["sig"]:
+            ended = [p for p in procs if p.poll() is not None]
+            if ended:
+                code = ended[0].returncode or 1 if any(p.returncode for p in ended) else 0
+                import logging
+                logging.getLogger(__name__).error("worker %d ended with code %s: stopping the other %d", ended[0].pid, ended[0].returncode, n - len(ended))
+                break
+            time.sleep(poll_s)
+        else:
+            code = 128 + stop["sig"]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        deadline = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    return code
+
+
 def main(argv=None) -> None:
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--streams", type=int, default=1024, help="client slots (= streams of the batched model) per worker process")
@@ -601,21 +662,12 @@ def main(argv=None) -> None:
     ap.add_argument("--reuse-port", action="store_true", help="(set for the worker processes of --workers)")
     a = ap.parse_args(argv)
     if a.workers > 1:
-        import subprocess
         import sys
         cmd = [sys.executable, "-m", "openwakeword_amd.serve", "--streams", str(a.streams), "--models", *a.models, "--threshold", str(a.threshold),
                "--host", a.host, "--port", str(a.port), "--device", str(a.device), "--workers", "1", "--reuse-port"]
         cmd += ["--weights", a.weights] if a.weights else []
         cmd += ["--use-mfma", str(a.use_mfma)] if a.use_mfma is not None else []
-        procs = [subprocess.Popen(cmd) for _ in range(a.workers)]
-        try:
-            for p in procs:
-                p.wait()
-        finally:
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-        return
+        raise SystemExit(_supervise(cmd, a.workers))
     from .model import BatchedModel
     model = BatchedModel(a.streams, a.models, weights=a.weights, device=a.device, use_mfma=a.use_mfma)
     web.run_app(FanInServer(model, threshold=a.threshold).app(), host=a.host, port=a.port, reuse_port=True if a.reuse_port else None)

@@ -644,18 +644,29 @@ def write_melspectrogram(path, win_len=400, n_fft=512, hop=160, top_db=80.0, ami
     g.save(path)
 
 
-def test_unknown_melspectrogram_idiom_warns_and_a_found_difference_refuses(tmp_path):
-    """a rendering of the recipe the verifier cannot follow must not make the default real-weights path unloadable -- a
-    GraphIdiomUnknown becomes a RuntimeWarning in model.resolve_embedding -- while a parameter that was FOUND to differ (hop, top_db,
-    filter bank ...) still refuses."""
+def test_unknown_melspectrogram_idiom_is_cleared_numerically_or_refused(tmp_path, monkeypatch):
+    """ADVICE r04 + r05: a rendering of the recipe the structural verifier cannot follow must not make the default real-weights path
+    unloadable -- but must not be waved through either: on GraphIdiomUnknown the file is EVALUATED on probe audio
+    (onnx_ingest.probe_melspectrogram) and accepted only when it reproduces the analytic front end; a graph of unknown structure that
+    computes something else (a reference offset through a second Log, another normalisation) is refused, as is any parameter FOUND to
+    differ.  OWW_TRUST_MELSPECTROGRAM=1 is the only way past."""
+    import warnings
     from openwakeword_amd.model import resolve_embedding
     path = os.path.join(tmp_path, "melspectrogram.onnx")
     emb = W.synthetic_embedding(5)
-    write_melspectrogram(path, idiom="abs")
+    write_melspectrogram(path, idiom="abs")                  # |re|^2 + |im|^2: unknown to the walker, the same numbers
     with pytest.raises(onnx_ingest.GraphIdiomUnknown, match="Abs"):
         onnx_ingest.verify_melspectrogram(path)
-    with pytest.warns(RuntimeWarning, match="could not be verified"):
+    assert onnx_ingest.probe_melspectrogram(path)["probe_max_abs_diff_db"] < 2e-2
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                        # cleared numerically: loads without a warning
         assert resolve_embedding(emb, None, melspec_model_path=path) is emb
+    write_melspectrogram(path, idiom="abs", log_factor=4.0)  # unknown structure AND another scale: the probe catches it
+    with pytest.raises(ValueError, match="numeric check did not clear it"):
+        resolve_embedding(emb, None, melspec_model_path=path)
+    monkeypatch.setenv("OWW_TRUST_MELSPECTROGRAM", "1")
+    assert resolve_embedding(emb, None, melspec_model_path=path) is emb
+    monkeypatch.delenv("OWW_TRUST_MELSPECTROGRAM")
     write_melspectrogram(path, hop=128)
     with pytest.raises(ValueError, match="stride") as ei:
         resolve_embedding(emb, None, melspec_model_path=path)
@@ -664,6 +675,16 @@ def test_unknown_melspectrogram_idiom_warns_and_a_found_difference_refuses(tmp_p
     with pytest.raises(ValueError, match="Sqrt") as ei:
         onnx_ingest.verify_melspectrogram(path)
     assert not isinstance(ei.value, onnx_ingest.GraphIdiomUnknown)
+
+
+def test_probe_of_a_plain_melspectrogram_file_matches_the_analytic_recipe(tmp_path):
+    path = os.path.join(tmp_path, "melspectrogram.onnx")
+    write_melspectrogram(path)
+    res = onnx_ingest.probe_melspectrogram(path)
+    assert res["n_probes"] >= 8 and res["probe_max_abs_diff_db"] < 2e-2
+    write_melspectrogram(path, top_db=60.0)
+    with pytest.raises(ValueError, match="different front end"):
+        onnx_ingest.probe_melspectrogram(path)
 
 
 def test_melspectrogram_file_is_verified_against_the_analytic_front_end(tmp_path):
@@ -849,6 +870,7 @@ def test_melspectrogram_written_by_pytorchs_own_exporter_is_verified(tmp_path):
         pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
     res = onnx_ingest.verify_melspectrogram(path)
     assert res["stft_kernel_max_abs_diff"] < 1e-6 and res["filterbank_max_abs_diff"] == 0.0 and res["top_db"] == 80.0
+    assert onnx_ingest.probe_melspectrogram(path)["probe_max_abs_diff_db"] < 2e-2       # ... and the numeric probe agrees on the exporter's rendering
     # the module itself computes what the oracle computes
     x = (np.random.default_rng(4).normal(0, 3000, (2, 1760))).astype(np.float32)
     with torch.no_grad():
@@ -858,6 +880,8 @@ def test_melspectrogram_written_by_pytorchs_own_exporter_is_verified(tmp_path):
         export(_torch_melspectrogram(**kw), path)
         with pytest.raises(ValueError, match=why):
             onnx_ingest.verify_melspectrogram(path)
+        with pytest.raises(ValueError, match="different front end|rows"):
+            onnx_ingest.probe_melspectrogram(path)
 
 
 @pytest.mark.parametrize("form,opset", [("where", 13), ("where", 17), ("if", 13)])

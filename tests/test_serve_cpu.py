@@ -93,3 +93,37 @@ def test_cohort_key_bins_by_period_and_phase():
     assert serve.cohort_key(0.080, 0.079) == (80, 7)
     assert serve.cohort_key(0.080, 8.0 + 0.045) == (80, 4)                  # the same phase ten periods later
     assert serve.cohort_key(4096 / 48000.0, 0.0)[0] == 85                   # the reference client's 4096-sample buffers at 48 kHz
+
+
+def test_workers_parent_forwards_signals_and_notices_a_dead_worker():
+    """the `--workers N` parent must not leave orphans on SIGTERM and must not sit blocked on worker 0 while another
+    worker has died.  `_supervise` with stand-in workers (sleepers): (a) one worker exits with code 3 -> the others are stopped, the
+    parent returns 3; (b) SIGTERM to the parent -> every worker is gone when it returns 128 + 15."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import threading
+    import time
+    flag = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"oww_supervise_{os.getpid()}")
+    if os.path.exists(flag):
+        os.remove(flag)
+    # the first worker to start claims the flag file and dies after 0.3 s; the others sleep "forever"
+    code = ("import os, sys, time\n"
+            f"p = {flag!r}\n"
+            "try:\n    fd = os.open(p, os.O_CREAT | os.O_EXCL | os.O_WRONLY); os.close(fd); time.sleep(0.3); sys.exit(3)\n"
+            "except FileExistsError:\n    time.sleep(600)\n")
+    t0 = time.monotonic()
+    assert serve._supervise([sys.executable, "-c", code], 3, poll_s=0.05) == 3
+    assert time.monotonic() - t0 < 20
+    os.remove(flag)
+    # (b) a signal to the parent reaches the children
+    pids = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"oww_supervise_pids_{os.getpid()}")
+    open(pids, "w").close()
+    code = f"import os, time\nopen({pids!r}, 'a').write(str(os.getpid()) + '\\n')\ntime.sleep(600)\n"
+    threading.Timer(1.0, lambda: os.kill(os.getpid(), signal.SIGTERM)).start()
+    assert serve._supervise([sys.executable, "-c", code], 2, poll_s=0.05) == 128 + signal.SIGTERM
+    for pid in [int(x) for x in open(pids).read().split()]:
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
+    os.remove(pids)

@@ -239,3 +239,62 @@ def test_load_driver_dry_run_on_two_server_processes():
     assert d["connections_accepted"] == 120 and sum(d["connections_per_server"]) == 120 and d["server_processes"] == 2
     assert d["chunks_sent"] > 500 and d["answers_received"] == d["chunks_sent"] == d["pump"]["stream_steps"]
     assert d["backlog_chunks_at_end"] == 0 and d["client_errors"] == 0 and d["server_latency_ms"]["p50"] < 200
+
+
+def test_a_dropped_connection_never_touches_its_slot_again():
+    """ADVICE r05 (high).  The server drops a connection on its own (send timeout, unread activations) while that connection's websocket
+    handler is still reading audio.  Its slot goes back to the pool ONCE; audio the old connection keeps sending is not staged into
+    the slot's row (which by then belongs to someone else), and the old handler's exit neither evicts the new owner nor releases the
+    slot a second time nor kills the pump."""
+    from aiohttp.test_utils import TestClient, TestServer
+    model = _Model(1)
+    tap = {}
+    srv = serve.FanInServer(model, threshold=2.0, window_s=0.002, on_scores=lambda cid, k, row: tap.setdefault(cid, []).append((k, row.copy())))
+    rng = np.random.default_rng(3)
+    a_audio = rng.integers(-20000, 20000, size=1280 * 12, dtype=np.int16)
+    b_audio = rng.integers(-20000, 20000, size=1280 * 8, dtype=np.int16)
+
+    async def wait_for(cond, what):
+        for _ in range(600):
+            if cond():
+                return
+            await asyncio.sleep(0.005)
+        raise AssertionError(what)
+
+    async def run():
+        async with TestClient(TestServer(srv.app())) as tc:
+            wa = await tc.ws_connect("/ws")
+            await wa.receive()
+            await wa.send_bytes(a_audio[:1280 * 2].tobytes())
+            await wait_for(lambda: len(tap.get(0, [])) == 2, "A's first chunks scored")
+            ca = srv.conns[0]
+            assert ca.slot == 0
+            # what _drain does when a send times out -- the peer's socket stays open and keeps sending
+            ca.closed = True
+            srv._closing.add(ca)
+            srv._have_chunk.set()
+            await wait_for(lambda: ca.reaped, "A reaped")
+            assert ca.slot is None and not srv.conns and not srv.clients
+            wb = await tc.ws_connect("/ws")
+            await wb.receive()
+            await wb.send_bytes(b_audio[:1280 * 3].tobytes())
+            await wait_for(lambda: len(tap.get(1, [])) == 3, "B's first chunks scored")
+            assert srv.conns[1].slot == 0                              # the slot was reused
+            await wa.send_bytes(a_audio[1280 * 2: 1280 * 7].tobytes())   # the stale connection goes on sending
+            await wa.send_bytes(a_audio[1280 * 7:].tobytes())
+            await asyncio.sleep(0.05)
+            await wb.send_bytes(b_audio[1280 * 3:].tobytes())
+            await wait_for(lambda: len(tap.get(1, [])) == 8, "B's remaining chunks scored")
+            await wa.close()
+            await asyncio.sleep(0.05)                                  # A's handler ends; the pump passes _reap again
+            assert srv.failed is None and srv.clients.get(0) is srv.conns[1] and srv.conns[1].slot == 0
+            await wb.close()
+            await wait_for(lambda: not srv.conns, "B reaped")
+    asyncio.run(asyncio.wait_for(run(), 60))
+    assert srv.failed is None
+    assert len(tap[0]) == 2                                            # nothing of A's later audio was scored ...
+    got = [row[0] for _, row in tap[1]]
+    want = [_checksum(b_audio[1280 * t: 1280 * (t + 1)]) for t in range(8)]
+    np.testing.assert_allclose(got, want, atol=1e-6)                   # ... and B's stream holds B's audio only, in order
+    assert [k for k, _ in tap[1]] == list(range(8))
+    assert sorted(srv.slots.free_slots()) == [0] if hasattr(srv.slots, "free_slots") else True
