@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 # executed algorithmic flops per stream-step of each CNN stage (2 x MACs of the incremental form)
 STAGE_FLOPS = {"stageA": 1_880_064, "stageB": 3_096_576, "stageC": 3_649_536, "stageD": 1_658_880, "stageE": 940_032}
+MFLOP_CNN_STEP = sum(STAGE_FLOPS.values()) / 1e6      # 11.225 MFLOP: one incremental step of the embedding CNN
 MEL_BYTES = 3584            # 2560 B new PCM + 1024 B mel rows per stream-step
 PEAK_FP32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 MFMA dense peak
 PEAK_F16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: f16 / bf16 MFMA dense peak
@@ -399,6 +400,102 @@ def leg_resident_1m(args):
                       "scores_valid": ok, "parity": parity}))
 
 
+def _embed_cpu_worker(a):
+    seed, budget_s, n = a
+    import torch
+    torch.set_num_threads(1)
+    from openwakeword_amd import weights as W
+    from oracle.oww_oracle_torch import TorchCpuPort
+    port = TorchCpuPort(W.synthetic_embedding(1234), {}, threads=1)
+    clip = W.synthetic_pcm(1, n, seed=seed)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        spec = port.mel(clip)[0]
+        port.embed(torch.stack([spec[i:i + 76] for i in range(0, spec.shape[0] - 75, 8)]))      # utils.py:354-385: every window, full CNN
+        done += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    return done, time.perf_counter() - t0
+
+
+def leg_embed_clips(args):
+    """Child-process leg, SURVEY §8(f)1: bulk clip embedding (AudioFeatures.embed_clips / compute_features_from_generator,
+    /root/reference/openwakeword/utils.py:354-385, 542-601) -- `--streams` clips of 2 s, PCM and embeddings resident in HBM, one
+    oww_embed_clips call per repetition.  Reports clips/s, the flops the incremental CNN EXECUTES (9 lead-in steps + one step per
+    window, 11.225 MFLOP each) against the f16 MFMA peak, the per-kernel times of one call, parity against the vectors the reference's
+    own AudioFeatures.embed_clips produced on the exporter-written files (tests/golden/ref_onnx_files.npz: embed/*), and the
+    reference's algorithm (torch-CPU port: mel per clip, every 76-row window through the full CNN) timed on the host cores."""
+    import multiprocessing as mp
+    n = 32000
+    cpu = None
+    if not args.no_cpu_baseline:                        # forked workers: before HIP is touched
+        from oracle.parity_sample import effective_cpus
+        cores = effective_cpus()
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.map(_embed_cpu_worker, [(50 + i, args.cpu_seconds, n) for i in range(cores)])
+        clips, wall = sum(r[0] for r in res), max(r[1] for r in res)
+        cpu = {"value": round(clips / wall, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+               "sample": f"{clips} clips of 2 s in {wall:.1f} s on {cores} single-threaded processes (the reference's form: full-window CNN per embedding, torch-CPU)"}
+    import torch
+    from openwakeword_amd import weights as W
+    from openwakeword_amd.engine import StreamEngine
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = args.streams
+    frames = (n - 512) // 160 + 1
+    n_out = (frames - 76) // 8 + 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    pcm = (torch.randn(B, n, device=dev, generator=gen) * 3000.0).round().clamp(-32768, 32767).to(torch.int16)
+    out = torch.empty(B, n_out, 96, device=dev, dtype=torch.float32)
+    eng = StreamEngine(B, {}, W.synthetic_embedding(1234), device=0, use_mfma=3)
+    try:
+        # parity: the reference's own embed_clips on the exporter-written files (4 clips of 2 s) through the same entry point
+        parity = None
+        try:
+            z = np.load(os.path.join(ROOT, "tests", "golden", "ref_onnx_files.npz"))
+            got = eng.embed_clips(np.ascontiguousarray(z["embed/pcm"]))
+            want = z["embed/embed_clips"]
+            err = float(np.abs(got - want).max())
+            parity = {"n_clips": int(want.shape[0]), "windows": int(want.shape[1]), "max_abs_err": err, "tolerance": 2e-4 * max(1.0, float(np.abs(want).max())),
+                      "ok": bool(err <= 2e-4 * max(1.0, float(np.abs(want).max()))),
+                      "checker": "tests/golden/ref_onnx_files.npz embed/*: /root/reference's AudioFeatures.embed_clips on model files written by "
+                                 "PyTorch's exporter from the same weights (tests/golden/make_golden_onnx.py)"}
+        except Exception as e:                          # noqa: BLE001
+            parity = {"error": repr(e)[:300], "ok": False}
+        eng.embed_clips_device(pcm.data_ptr(), B, n, out.data_ptr())                   # warm-up (the call synchronises)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.embed_clips_device(pcm.data_ptr(), B, n, out.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        ok = bool(torch.isfinite(out).all().item())
+        eng.enable_timing(True)
+        eng.embed_clips_device(pcm.data_ptr(), B, n, out.data_ptr())
+        kt = {k: round(v["ms"], 3) for k, v in eng.kernel_times().items() if v["launches"]}
+        eng.enable_timing(False)
+    finally:
+        eng.close()
+    steps = 9 + n_out
+    flops = B * steps * MFLOP_CNN_STEP * 1e6
+    tf = flops / dt / 1e12
+    cnn_ms = sum(v for k, v in kt.items() if k.startswith("stage"))
+    rec = {"metric": "clip embeddings (AudioFeatures.embed_clips), clips/s on 1 GPU", "value": round(B / dt, 1), "unit": "clips/s",
+           "clips": B, "clip_seconds": 2.0, "windows_per_clip": n_out, "ms_per_call": round(dt * 1e3, 2), "calls_timed": args.steps,
+           "audio_seconds_per_second": round(B * 2.0 / dt, 1), "embeddings_per_second": round(B * n_out / dt, 1),
+           "kernel_ms_per_call": kt,
+           "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_TFLOPS, 4),
+                        "cnn_kernels_only": round(flops / (cnn_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4) if cnn_ms else None,
+                        "flops_per_clip": round(steps * MFLOP_CNN_STEP * 1e6), "traffic": None,
+                        "note": f"executed flops only: {steps} incremental CNN steps of {MFLOP_CNN_STEP} MFLOP per clip (9 lead-in + one per window); "
+                                f"the reference's full-window form would execute {n_out} x 83.9 MFLOP for the same output"},
+           "finite": ok, "parity": parity, "data": "synthetic Gaussian int16 PCM (RMS 3000), synthetic weights seed 1234", "cpu_baseline": cpu}
+    if cpu:
+        rec["x_cpu_host"] = round(rec["value"] / cpu["value"], 1)
+    print(json.dumps(rec))
+
+
 def self_launch(n: int) -> None:
     """A bare `python bench.py --gpus N` (N > 1, no torchrun environment): re-execute this command line under
     torch.distributed.run -- one rank per GPU, rendezvous on 127.0.0.1 at a free port -- and pass the ranks' output through
@@ -513,7 +610,7 @@ def main():
                          "c_abi = the library's own grouped ncclSend / ncclRecv exchange (oww_comm_init / oww_gather_scores; also runs "
                          "with one rank, as a send-to-self through RCCL)")
     ap.add_argument("--vad", action="store_true", help="BASELINE configs[4]: the voice-activity stand-in network + gate fused into the step")
-    ap.add_argument("--leg", default="", help="(internal) run one extra record in this process and print its JSON: resident_1m")
+    ap.add_argument("--leg", default="", help="(internal) run one extra record in this process and print its JSON: resident_1m | embed_clips")
     ap.add_argument("--pcm-pool", type=int, default=4, help="distinct PCM buffers cycled through")
     ap.add_argument("--pcm", choices=("noise", "uniform", "wav"), default="noise",
                     help="synthetic input (SURVEY 8d): noise = Gaussian RMS 3000 (default); uniform = the reference tests' "
@@ -527,6 +624,8 @@ def main():
 
     if args.leg == "resident_1m":
         return leg_resident_1m(args)
+    if args.leg == "embed_clips":
+        return leg_embed_clips(args)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
@@ -545,10 +644,10 @@ def main():
         cpu_base = cpu_baseline.run(head_names, budget_s=args.cpu_seconds)
     parity_ref = None
     family_ok = not (args.valu or args.lds_mfma)
+    PS6 = ("alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather")        # (= oracle.parity_sample.HEADS6)
     want_parity = (not args.no_parity and family_ok and set(head_names) <= set(PS6)
                    and not (args.host_pcm or args.host_pcm_blocking))
     vad_parity_ref = default6_ref = None
-    PS6 = ("alexa", "hey_mycroft", "hey_jarvis", "hey_rhasspy", "timer", "weather")        # (= oracle.parity_sample.HEADS6)
     if want_parity and rank0:
         from oracle import parity_sample as PS
         # computed once by a child interpreter, cached under $TMPDIR (the three-head sample unless the run names other catalogue heads)
@@ -744,6 +843,15 @@ def main():
             except Exception as e:
                 extras["configs_error"] = repr(e)[:400]
             torch.cuda.empty_cache()
+        # ---- embed_clips: SURVEY §8(f)1, bulk clip embedding on the same kernels (child process: its CPU leg forks before HIP)
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--leg", "embed_clips", "--streams", "16384", "--steps", "5", "--cpu-seconds", "6"]
+            cmd += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            extras["embed_clips"] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:
+            extras["embed_clips"] = {"error": repr(e)[:400]}
         # ---- resident_1m: a million streams in ONE handle on this GPU, in a child process (own 73 GB of state)
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--leg", "resident_1m", "--streams", str(1 << 20), "--heads", args.heads,

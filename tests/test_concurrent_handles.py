@@ -81,7 +81,7 @@ def test_error_text_is_per_thread():
 
     def bad():
         try:
-            eng.step(np.zeros((4, 1280 * 99), np.int16))      # more chunks per call than the handle was created for
+            eng.step(np.zeros((4, 1280 * 4097), np.int16))    # more chunks per call than the ABI takes (OWW_MAX_CALL_CHUNKS = 4096)
         except Exception as e:           # noqa: BLE001
             seen["bad"] = str(e)
 
