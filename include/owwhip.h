@@ -82,6 +82,13 @@ int  oww_destroy(oww_ctx* h);
  *          extra_blocks = 0 is the network of every released model (train.py:27,67: n_blocks = 1); train.py's Net takes any
  *          n_blocks (train.py:73): extra_blocks = n_blocks - 1, from -1 (no hidden block) to OWW_MAX_HEAD_BLOCKS - 1.  Nets with
  *          other than one block are evaluated by the generic heads kernel (any kernel family), not by the MFMA head kernels.
+ *          In the default family (use_mfma = 3) one-block nets of up to 64 hidden units and one sigmoid output run on the f16-split
+ *          heads kernel, and ungated one-block nets of up to 128 hidden units / 8 outputs (the multiclass `timer` model,
+ *          docs/models/timers.md:9-27) on its wide form; everything else on the generic kernel.
+ *  head, recurrent (train.py:85-98, model_type "rnn"): hdr = {3, T (<= 64), 64, n_out, 0, 0, 0, 0}; then for LSTM layer 0 (input 96) and 1
+ *          (input 128), for direction forward and reverse: w[in + 64][256] (rows x ; h, columns i | f | g | o -- torch's gate order),
+ *          b[256] (= b_ih + b_hh); then w_out[128][n_out], b_out[n_out].  Output = Sigmoid (n_out = 1) or ReLU + softmax of the
+ *          linear layer on the last time step (out[:, -1]).
  */
 int  oww_load_mel(oww_ctx* h, const void* blob, size_t nbytes);
 int  oww_load_embedding(oww_ctx* h, const void* blob, size_t nbytes);

@@ -404,6 +404,8 @@ struct NetHost {
     int n_blocks;                     // hidden blocks behind the first layer (train.py:73: Net's n_blocks; 1 in every released model)
     const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // into the owning head blob (w2 .. ln2b: block 0)
     const float* blocks;              // the n_blocks blocks back to back: w[H][H] b[H] (g[H] be[H])
+    const float* rnn = nullptr;       // model_type "rnn" (kind 3): the head's blob (owk::heads_rnn_kernel); its size in rnn_floats
+    size_t rnn_floats = 0;
     int hx_e1 = 0, hx_e2 = 0, hx_e3 = 0;   // fp16-split heads: power-of-two scales of w1 / w2 (/ w3: wide form) (hx_weight_exp)
 };
 struct HeadHost {
@@ -472,6 +474,7 @@ struct oww_ctx {
     std::vector<NetDesc> host_descs;  // device pointers of every net's arrays (host copy of d_allnets)
     std::vector<FastGroup> groups;
     std::vector<int> generic_nets;    // indices into nets (with verifier right after its primary)
+    std::vector<int> rnn_nets;        // recurrent heads (train.py:85-98): owk::heads_rnn_kernel, one launch per head
     NetDesc* d_generic = nullptr;
     int generic_hmax = 0;
     int generic_spw = 0;              // OWW_GENERIC_SPW: 4 / 16 pins the generic heads kernel's shape, 0 = by launch size
@@ -523,6 +526,9 @@ struct oww_ctx {
     int hx_e[20] = {}, hx_ein[20] = {}, hx_xexp[5] = {};
     float hx_absmax[20] = {};        // largest |activation| of each layer in the calibration run (exact-fp32 kernels)
     std::vector<int16_t> cal_user;   // oww_set_calibration: caller's calibration audio as [n_seg][CAL_T * 1280] segments
+    // builds with -DOWH_DEEP_RING only (round 6 experiment, profiles/r06_deep_ring_c1.txt: bit-identical, no faster at 4,096 / 16,384 streams):
+    // launches of at most this many workgroups run a weight ring of NS = 4 / 5 slots, three / four chunks in flight; OWW_DEEP_WGS
+    int deep_wgs = 0;
     int small_wgs = kSmallLaunchWgs, small_wgs_heads = kSmallLaunchWgs;   // A/B aids: OWW_SMALL_WGS / OWW_SMALL_WGS_HEADS (0 = never the deep rings)
     bool ring3_always[4] = {};       // A/B aid (OWW_RING3_ALWAYS="BCDE"): the three-slot weight ring of stages B..E at any launch size
     int hx_efeat = 0;                // heads: the features enter the first GEMM multiplied by 2^hx_efeat (largest probe |embedding| at 2^9..2^10)
@@ -715,6 +721,9 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 2);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_B - 1) / OWH_WG_B;
+#ifdef OWH_DEEP_RING
+        if (HX && !DBG && nwg <= h->deep_wgs) { hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, false, OWH_WG_B, 4>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p); } else
+#endif
         if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[0])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, false, OWH_WG_B, 3>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HB, false, DBG, OWH_WG_B>), dim3(nwg), dim3(64 * OWH_WG_B), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RB, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
@@ -724,6 +733,9 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 3);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_C - 1) / OWH_WG_C;
+#ifdef OWH_DEEP_RING
+        if (HX && !DBG && nwg <= h->deep_wgs) { hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, false, OWH_WG_C, 5>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p); } else
+#endif
         if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[1])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, false, OWH_WG_C, 3>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HC, false, DBG, OWH_WG_C>), dim3(nwg), dim3(64 * OWH_WG_C), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RC, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
@@ -733,6 +745,9 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 4);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_D - 1) / OWH_WG_D;
+#ifdef OWH_DEEP_RING
+        if (HX && !DBG && nwg <= h->deep_wgs) { hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, false, OWH_WG_D, 5>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p); } else
+#endif
         if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[2])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, false, OWH_WG_D, 3>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HD, false, DBG, OWH_WG_D>), dim3(nwg), dim3(64 * OWH_WG_D), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RD, false, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
@@ -744,6 +759,9 @@ int run_cnn_rr(oww_ctx* h, int n_active, int mel_stride, int mel_off) {
         Timed t(h, 5);
         // a launch whose workgroups are (nearly) alone on their CUs runs the three-slot weight ring (owwhip_hx.h WRing): same results
         const int nwg = (p.n_groups + OWH_WG_E - 1) / OWH_WG_E;
+#ifdef OWH_DEEP_RING
+        if (HX && !DBG && nwg <= h->deep_wgs) { hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, false, OWH_WG_E, 5>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p); } else
+#endif
         if (HX && !DBG && (nwg <= h->small_wgs || h->ring3_always[3])) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, false, OWH_WG_E, 3>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
         else if (HX) hipLaunchKernelGGL((owh::hstage_kernel<owh::HE, true, DBG, OWH_WG_E>), dim3(nwg), dim3(64 * OWH_WG_E), 0, st, p);
         else hipLaunchKernelGGL((rstage_kernel<RE, true, DBG>), dim3((p.n_groups + 3) / 4), dim3(256), 0, st, p);
@@ -862,6 +880,13 @@ int run_heads(oww_ctx* h, int n_active, bool accumulate_max, const float* ext, i
             p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
             launch_generic_heads(h, p, n_active, nb, ne, st);
         }
+    }
+    // recurrent heads (model_type "rnn"): the same kernel in every family
+    for (int ni : h->rnn_nets) {
+        if (only_head >= 0 && h->nets[ni].head != only_head) continue;
+        HeadParams p = base;
+        p.nets = h->d_allnets; p.n_nets = (int)h->nets.size();
+        hipLaunchKernelGGL((heads_rnn_kernel<RNN_SPW>), dim3((n_active + RNN_SPW - 1) / RNN_SPW), dim3(64), rnn_lds_bytes(h->nets[ni].T), st, p, ni);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1058,7 +1083,7 @@ int build_active_lists(oww_ctx* h, const uint8_t* on) {
     int n_act = 0;
     for (int s = 0; s < S; ++s) n_act += on[s] != 0;          // (vectorised by the compiler)
     if (n_act == 0) return 0;
-    if (!h->hx || !h->fuse || !h->generic_nets.empty()) return -1;       // the group lists are read by the default family's launches only
+    if (!h->hx || !h->fuse || !h->generic_nets.empty() || !h->rnn_nets.empty()) return -1;       // the group lists are read by the default family's launches only
     if ((long long)n_act * 8 > (long long)S * 7) return -1;
     const size_t need = (size_t)S + S / 2 + S / 4 + S / 8 + S / 16 + 64;       // (regions of the five lists, see below)
     if (need > h->lists_cap) {
@@ -1563,6 +1588,18 @@ int oww_add_head(oww_ctx* h, const void* blob, size_t nbytes) {
     HeadHost hh{};
     hh.kind = hdr[0]; hh.T = hdr[1]; hh.hidden = hdr[2]; hh.n_out = hdr[3]; hh.has_ln = hdr[4];
     hh.n_blocks = 1 + hdr[5];                  // (hdr[5] = hidden blocks beyond the one every released model has; -1 = none)
+    if (hh.kind == 3) {                        // train.py:85-98: 2-layer bidirectional LSTM(64) + Linear(128, n_out)
+        if (hh.T < 1 || hh.T > RNN_TMAX || hh.hidden != RNN_H || hh.n_out < 1 || hh.n_out > 8 || hh.has_ln || hdr[5] != 0)
+            return fail(OWW_EINVAL, "oww_add_head: bad rnn header T=%d (<= %d) hidden=%d (= %d) n_out=%d", hh.T, RNN_TMAX, hh.hidden, RNN_H, hh.n_out);
+        const size_t want = 2 * ((size_t)(96 + RNN_H) * 256 + 256) + 2 * ((size_t)(128 + RNN_H) * 256 + 256) + (size_t)128 * hh.n_out + hh.n_out;
+        if (nbytes != 32 + want * 4) return fail(OWW_EINVAL, "oww_add_head: rnn blob is %zu bytes, expected %zu", nbytes, 32 + want * 4);
+        hh.n_blocks = 1;
+        hh.blob.assign((const float*)((const char*)blob + 32), (const float*)((const char*)blob + nbytes));
+        for (size_t i = 0; i < hh.blob.size(); ++i)
+            if (!std::isfinite(hh.blob[i])) return fail(OWW_EINVAL, "oww_add_head: head weights are not finite (float %zu of the blob)", i);
+        h->heads.push_back(std::move(hh));
+        return (int)h->heads.size() - 1;
+    }
     if (hh.kind < 0 || hh.kind > 2 || hh.T < 1 || hh.T > 120 || hh.hidden < 1 || hh.hidden > 512 || hh.n_out < 1 || hh.n_out > 8 ||
         hh.n_blocks < 0 || hh.n_blocks > OWW_MAX_HEAD_BLOCKS)
         return fail(OWW_EINVAL, "oww_add_head: bad header kind=%d T=%d hidden=%d n_out=%d blocks=%d", hh.kind, hh.T, hh.hidden, hh.n_out, hh.n_blocks);
@@ -1653,7 +1690,14 @@ int oww_commit(oww_ctx* h) {
         const size_t in = (size_t)hh.T * 96, H = hh.hidden, O = hh.n_out;
         const float* q = hh.blob.data();
         const int begin = (int)h->nets.size();
-        for (int r = 0; r < (hh.kind == 1 ? 2 : 1); ++r) {
+        if (hh.kind == 3) {                                                  // recurrent head: one net, its blob as a whole
+            NetHost n{};
+            n.hidden = hh.hidden; n.n_out = hh.n_out; n.has_ln = 0; n.T = hh.T; n.final_act = hh.n_out == 1 ? 0 : 1;
+            n.head = (int)hi; n.role = 0; n.out_col = col; n.n_blocks = 0;
+            n.rnn = q; n.rnn_floats = hh.blob.size();
+            h->nets.push_back(n);
+        }
+        for (int r = 0; r < (hh.kind == 3 ? 0 : hh.kind == 1 ? 2 : 1); ++r) {
             NetHost n{};
             n.hidden = hh.hidden; n.n_out = hh.n_out; n.has_ln = hh.has_ln; n.T = hh.T;
             n.final_act = hh.kind == 2 ? 1 : 0; n.head = (int)hi; n.role = r; n.out_col = col;
@@ -1812,10 +1856,11 @@ int oww_commit(oww_ctx* h) {
         }
     }
     // heads: natural arrays for every net (+ packed w2 for hidden==64), fast groups
-    struct NetOff { size_t w1, b1, ln1g, ln1b, w2, b2, ln2g, ln2b, w3, b3, w2pk, blocks; };
+    struct NetOff { size_t w1, b1, ln1g, ln1b, w2, b2, ln2g, ln2b, w3, b3, w2pk, blocks, rnn; };
     std::vector<NetOff> noff(h->nets.size());
     for (size_t ni = 0; ni < h->nets.size(); ++ni) {
         const NetHost& n = h->nets[ni];
+        if (n.rnn) { noff[ni] = NetOff{}; noff[ni].rnn = hb.add(n.rnn, n.rnn_floats); continue; }
         const size_t in = (size_t)n.T * 96, H = n.hidden, O = n.n_out;
         NetOff& o = noff[ni];
         o.w1 = hb.add(n.w1, in * H); o.b1 = hb.add(n.b1, H);
@@ -1832,11 +1877,12 @@ int oww_commit(oww_ctx* h) {
         if (n.hidden == 64 && n.n_blocks == 1) { std::vector<float> pk; pack_mfma(n.w2, 1, 64, 64, pk); o.w2pk = hb.add(pk); }
     }
     // grouping: heads whose nets are all (hidden 64, n_out 1, sigmoid) share a fast group per T (<= 8 nets each)
-    h->groups.clear(); h->generic_nets.clear();
+    h->groups.clear(); h->generic_nets.clear(); h->rnn_nets.clear();
     struct GOff { size_t w1pk, b1cat, w1hx; std::vector<size_t> w2hx, pad, w3hx; };
     std::vector<GOff> goff;
     for (size_t hi = 0; hi < h->heads.size(); ++hi) {
         const auto [nb, ne] = h->head_nets[hi];
+        if (h->nets[nb].rnn) { h->rnn_nets.push_back(nb); continue; }       // recurrent heads have their own kernel in every family
         bool fast = h->mfma;
         // the MFMA head kernels: sigmoid nets of one output and one hidden block; exactly 64 hidden units in the fp32 family
         // (heads64_kernel), up to 64 in the fp16-split family (zero-padded, see FastGroup::d_pad)
@@ -1992,6 +2038,7 @@ int oww_commit(oww_ctx* h) {
         NetDesc d{};
         d.hidden = n.hidden; d.n_out = n.n_out; d.has_ln = n.has_ln; d.final_act = n.final_act; d.T = n.T;
         d.head = n.head; d.role = n.role; d.out_col = n.out_col; d.hid_off = hid_off;
+        if (n.rnn) { d.rnn = h->d_w + o.rnn; return d; }
         d.w1 = h->d_w + o.w1; d.b1 = h->d_w + o.b1;
         d.ln1g = n.has_ln ? h->d_w + o.ln1g : nullptr; d.ln1b = n.has_ln ? h->d_w + o.ln1b : nullptr;
         d.n_blocks = n.n_blocks;
@@ -2024,6 +2071,7 @@ int oww_commit(oww_ctx* h) {
         }
         if (g.ht == 4) if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
     }
+    for (int ni : h->rnn_nets) if (int rc = set_lds(heads_rnn_kernel<RNN_SPW>, (int)rnn_lds_bytes(RNN_TMAX))) return rc;
 
     // ---- sticky range flag of the f16-split kernels: page-locked + device-mapped, so the host reads it without a copy ----
     {
@@ -2090,11 +2138,12 @@ int oww_commit(oww_ctx* h) {
         }
     }
     h->fuse = h->hx && !getenv("OWW_NO_FUSE");
+    if (const char* e = getenv("OWW_DEEP_WGS")) h->deep_wgs = atoi(e);
     if (const char* e = getenv("OWW_SMALL_WGS")) h->small_wgs = atoi(e);
     if (const char* e = getenv("OWW_SMALL_WGS_HEADS")) h->small_wgs_heads = atoi(e);
     if (const char* e = getenv("OWW_GENERIC_SPW")) { const int v = atoi(e); h->generic_spw = v == 4 || v == 16 ? v : 0; }
     if (const char* e = getenv("OWW_RING3_ALWAYS")) for (int i = 0; i < 4; ++i) h->ring3_always[i] = strchr(e, "BCDE"[i]) != nullptr;
-    h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->groups[0].ht == 4 && h->generic_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
+    h->post_in_heads = h->hx && !getenv("OWW_NO_FUSE") && h->groups.size() == 1 && h->groups[0].ht == 4 && h->generic_nets.empty() && h->rnn_nets.empty() && h->NL > 0;                  // (A/B switch: OWW_NO_FUSE=1 keeps the separate mel kernel)
     if (int rc = set_lds(owf::hmelA_kernel<false>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(owf::hmelA_kernel<true>, owf::FA_LDS_BYTES)) return rc;
     if (int rc = set_lds(stageA_kernel<true>, CfgA::LDS_BYTES)) return rc;

@@ -321,6 +321,15 @@ using HE = owr::RCfg<96, 96, 2, 2, 2, 2, 2, OWH_WPS_E>;
 
 #define OWH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
+// PRICING BUILDS ONLY (tools/price_handover.sh; results are garbage): what would a fused A -> B launch save at most?  Bit 0 folds
+// stage A's hand-over STORES onto 512 streams' rows (4 MB), bit 1 stage B's hand-over LOADS -- the rows then live in L2 and the 8 KB written
+// and 8 KB read per stream-step never reach HBM, while every instruction of both kernels still executes.  The time such a build
+// saves is the upper bound of a fusion's gain from the hand-over traffic (the launch boundary itself is priced by the 4,096-stream run).
+#ifndef OWH_PRICE_HANDOVER
+#define OWH_PRICE_HANDOVER 0
+#endif
+template <bool ON> __device__ __forceinline__ int price_alias(int i) { return ON ? (i & 511) : i; }
+
 // ---- weight-chunk ring of the stage kernels ----------------------------------------------------------------------------------------
 // A layer's weights arrive as NCTO chunks (one output-channel tile each: 6..18 KB), L2 -> LDS by global_load_lds, shared by the
 // workgroup's waves.  NS slots, P = NS - 1 chunks in flight ahead of the one being consumed; chunks past a layer's end are the first
@@ -343,7 +352,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
     asm volatile("" ::: "memory");
 }
-template <int NS> struct WRing { float* s[3]; };
+template <int NS> struct WRing { float* s[5]; };
+// s_waitcnt vmcnt(n) for an n that is a compile-time value only AFTER unrolling (a sum over the chunks that may stay in flight): the
+// builtin wants an integer constant expression, so the value is matched against 0 .. MAX and the dead branches fold away
+template <int MAX> __device__ __forceinline__ void wait_vmcnt_of(int n) {
+    if (n >= MAX) wait_vmcnt<MAX>();
+    else if constexpr (MAX > 0) wait_vmcnt_of<MAX - 1>(n);
+}
 // a chunk with the SAME number of DMA instructions in every wave (no branch on the wave index): blocks past the end re-load the last
 // block (same source, same destination, same data).  Straight-line issue keeps the compiler's wait counts exact -- behind a branch it
 // falls back to vmcnt(0) in front of the next read of that slot -- and makes the counted wait below exact for every wave.
@@ -378,11 +393,14 @@ __device__ __forceinline__ void ring_end(int oct) {
     if (!(oct + 1 < NCTO || NEXT_NBLK > 0)) return;          // no chunk oct + 1 in this launch
     if constexpr (NS == 2) owr::chunk_sync();
     else {
-        constexpr int P = NS - 1;
-        const int c = oct + P;
-        if (c < NCTO) wait_vmcnt<(NBLK + WG - 1) / WG>();
-        else if (NEXT_NBLK > 0 && c - NCTO < P) wait_vmcnt<(NEXT_NBLK + WG - 1) / WG>();
-        else wait_vmcnt<0>();
+        // chunk oct + 1 must have landed; chunks oct + 2 .. oct + P (issued after it: VMEM returns in order) may stay in flight.  NS = 3:
+        // that is the chunk issued in this step; deeper rings (NS = 4, 5: launches of at most ONE workgroup per CU, where nothing else
+        // covers the L2 -> LDS round trip and the per-CU DMA rate is what a chunk step costs) leave P - 1 = 2, 3 chunks in flight
+        constexpr int P = NS - 1, A = (NBLK + WG - 1) / WG, B = NEXT_NBLK > 0 ? ((NEXT_NBLK > 0 ? NEXT_NBLK : 1) + WG - 1) / WG : 0;
+        int n = 0;
+#pragma unroll
+        for (int c = oct + 2; c <= oct + P; ++c) n += c < NCTO ? A : ((NEXT_NBLK > 0 && c - NCTO < P) ? B : 0);
+        wait_vmcnt_of<(P - 1) * (A > B ? A : B)>(n);
         // lgkmcnt(0): this wave's LDS reads of chunk oct have RETURNED before the barrier lets another wave restage that slot in the
         // next step (the MFMAs that consume them -- and the waits in front of those -- may be scheduled behind the bare barrier)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -817,13 +835,14 @@ __device__ __forceinline__ void load_tile_lds(f32x4 (&t)[NCT], const float* base
 }
 
 template <class C, bool LAST, bool DBG, int WG = OWH_WG, int NS = 2>
-__global__ __launch_bounds__(64 * WG, (DBG ? 1 : (NS == 3 && C::WPS > 2 ? 2 : C::WPS))) void hstage_kernel(owr::RStageParams p) {
+__global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 2 ? 2 : C::WPS))) void hstage_kernel(owr::RStageParams p) {
     using namespace owr;
     constexpr int NCTI = C::NCTI, NCT = C::NCT, R = C::RP, F = C::F;   // R = rows per pass (see owr::RCfg::RP)
     static_assert(!LAST || C::NPASS == 1, "the last stage runs in one pass");
     // every pass starts at ring phase CH0 = 0 (conv a) and advances the ring by 4 * NCT chunks: with more than one pass the slot the
     // chunk prefetched by conv d lands in is the one conv a of the next pass reads only if that advance is a multiple of the ring length
     static_assert(NS == 2 || C::NPASS == 1 || (4 * NCT) % NS == 0, "multi-pass stages need a ring phase that returns to 0 after each pass");
+    static_assert(NS >= 2 && NS <= 5 && NS - 1 <= NCT, "the chunks in flight at a layer boundary belong to at most the next layer");
     constexpr int KSA = (NCTI + 1) / 2, KS = (NCT + 1) / 2;          // k-steps per tap: first layer / other layers
     constexpr int NBA = 3 * KSA * 2, NB = 3 * KS * 2;                // 1 KB blocks per chunk
     using TK = TimeK<NCT, C::HOUT>;
@@ -856,8 +875,10 @@ __global__ __launch_bounds__(64 * WG, (DBG ? 1 : (NS == 3 && C::WPS > 2 ? 2 : C:
     // the slots of the weight ring are DISTINCT LDS objects (see WRing above)
     __shared__ __attribute__((aligned(16))) float wbuf[WBS];
     __shared__ __attribute__((aligned(16))) float wbuf1[WBS];
-    __shared__ __attribute__((aligned(16))) float wbuf2[NS == 3 ? WBS : 4];
-    const WRing<NS> ring{{wbuf, wbuf1, wbuf2}};
+    __shared__ __attribute__((aligned(16))) float wbuf2[NS >= 3 ? WBS : 4];
+    __shared__ __attribute__((aligned(16))) float wbuf3[NS >= 4 ? WBS : 4];
+    __shared__ __attribute__((aligned(16))) float wbuf4[NS >= 5 ? WBS : 4];
+    const WRing<NS> ring{{wbuf, wbuf1, wbuf2, wbuf3, wbuf4}};
     __shared__ __attribute__((aligned(16))) float sbn[4][NCT * 16];      // per layer: K * BatchNorm shift in tile row order = accumulator start values
     __shared__ __attribute__((aligned(16))) float hlds[HLDS ? WG * 2 * HROW : 4];
     float* const hl = hlds + (HLDS ? wave * 2 * HROW : 0);
@@ -867,7 +888,9 @@ __global__ __launch_bounds__(64 * WG, (DBG ? 1 : (NS == 3 && C::WPS > 2 ? 2 : C:
     else g += p.g_base;                   // block-pipelined step: this launch covers groups g_base .. g_base + n_groups - 1
     lanemask_t bad = 0;
     ring_issue<NS, NBAM, WG>(p.w[0], wbuf, wave, lane);
-    if (NS == 3) ring_issue<NS, NBAM, WG>(p.w[0] + (size_t)NBAM * 256, wbuf1, wave, lane);   // (two chunks in flight from the start)
+    if (NS >= 3) ring_issue<NS, NBAM, WG>(p.w[0] + (size_t)NBAM * 256, wbuf1, wave, lane);   // (NS - 1 chunks in flight from the start)
+    if (NS >= 4) ring_issue<NS, NBAM, WG>(p.w[0] + (size_t)2 * NBAM * 256, wbuf2, wave, lane);
+    if (NS >= 5) ring_issue<NS, NBAM, WG>(p.w[0] + (size_t)3 * NBAM * 256, wbuf3, wave, lane);
     for (int i = threadIdx.x; i < 4 * NCT * 16; i += 64 * WG) {
         const int l = i / (NCT * 16), c = i % (NCT * 16);
         sbn[l][c] = p.shift[l][c];
@@ -887,7 +910,7 @@ __global__ __launch_bounds__(64 * WG, (DBG ? 1 : (NS == 3 && C::WPS > 2 ? 2 : C:
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         f32x4 X[NCTI];
-        load_tile_h<NCTI, C::HIN>(X, p.xin + ((size_t)g * C::R + pass * R + r) * (NCTI * 4 * 64), lane);
+        load_tile_h<NCTI, C::HIN>(X, p.xin + ((size_t)price_alias<(OWH_PRICE_HANDOVER & 2) != 0 && C::CIN == 24>(g) * C::R + pass * R + r) * (NCTI * 4 * 64), lane);
         to_ops<NCTI, C::HIN>(X, Xo[r]);
     }
     if (pass == 0) chunk_sync();
@@ -1384,7 +1407,7 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
 #pragma unroll
         for (int h = 0; h < 2; ++h) { Yh[0][h] = Y1o[h][0]; Yh[1][h] = Y1o[2 + h][0]; }
         // ---- stage B input row q: the 16 pooled bins are the 16 positions of one tile
-        float* xo = p.xout + ((size_t)s * 4 + q) * (8 * 64) + lane;
+        float* xo = p.xout + ((size_t)price_alias<(OWH_PRICE_HANDOVER & 1) != 0>(s) * 4 + q) * (8 * 64) + lane;
 #pragma unroll
         for (int e = 0; e < 4; ++e) xo[e * 64] = PA[0][e];
         xo[4 * 64] = PA[1][0];

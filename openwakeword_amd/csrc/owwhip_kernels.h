@@ -915,6 +915,8 @@ struct NetDesc {
     const float *w1, *b1, *ln1g, *ln1b, *w2, *b2, *ln2g, *ln2b, *w3, *b3;   // natural layouts (w2 .. ln2b: hidden block 0)
     int n_blocks;                            // hidden blocks (train.py:73); the MFMA head kernels take nets with exactly one
     const float* blocks;                     // all of them back to back, w[H][H] b[H] (g[H] be[H]) each: heads_generic_kernel
+    const float* rnn;                        // model_type "rnn" (train.py:85-98; heads_rnn_kernel): the head's whole blob -- per layer, per
+                                             // direction w [in + 64][256], b [256]; then w_out [128][n_out], b_out [n_out]; nullptr = an MLP net
     const float *w2pk;                       // MFMA-packed [hidden/16][hidden/4][64] (fast path)
 };
 
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(64 * WAVES, SPW >= 16 ? 2 : 1) void heads_generic_k
     for (int s = 0; s < SPW; ++s) sid[s] = min(s0 + s, p.S - 1);
     for (int ni = net_begin; ni < net_end; ++ni) {
         const NetDesc& n = p.nets[ni];
-        if (n.role != 0) continue;
+        if (n.role != 0 || n.rnn != nullptr) continue;       // (recurrent heads: heads_rnn_kernel)
         float result[8];                                     // lane s < SPW: the scores of stream s0 + s
         float gate_score = 0.f;
 #pragma unroll
@@ -1145,6 +1147,152 @@ __global__ __launch_bounds__(64 * WAVES, SPW >= 16 ? 2 : 1) void heads_generic_k
             for (int o = 0; o < 8; ++o)
                 if (o < n.n_out) store_raw(p, s0 + lane, n.out_col + o, result[o]);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's other model_type, "rnn" (train.py:85-98): x [T, 96] -> 2-layer bidirectional LSTM(64) -> Linear(128, n_out) on the
+// LAST time step's output -> Sigmoid (one class) | ReLU + softmax (train.py:152-165).  No released model is recurrent; this kernel is the
+// plain form for any kernel family: ONE WAVE per SPW streams, lane = hidden unit (its four gates, its cell and hidden state in
+// registers), the step's input vector and the previous hidden vector broadcast from the wave's LDS, weight rows read coalesced from L2
+// (torch's gate order i | f | g | o in 64-column blocks).  Layer 0 runs both directions over all T rows; layer 1 runs forward over all
+// of them and backward for ONE step only -- out[:, -1] of the reverse direction is its first step, from a zero state.
+// LDS (dynamic): [SPW] x (T x 96 features + T x 128 layer-0 outputs + 64 hidden + 128 last + 8 outputs).
+// ------------------------------------------------------------------------------------------------
+constexpr int RNN_H = 64, RNN_SPW = 2, RNN_TMAX = 64;
+inline size_t rnn_lds_bytes(int T) { return (size_t)RNN_SPW * ((size_t)T * (96 + 128) + 64 + 128 + 8) * sizeof(float); }
+
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// one LSTM step of one direction for the wave's streams: x = xin[s] (n_in floats, LDS), hp[s] (64 floats, LDS; skipped when `first`)
+template <int SPW>
+__device__ __forceinline__ void rnn_step(const float* __restrict__ w, const float* __restrict__ b, int n_in, const float* const (&xin)[SPW],
+                                         float* hp, bool first, float (&c)[SPW], float (&hcur)[SPW], int lane) {
+    float acc[SPW][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float bb = b[g * RNN_H + lane];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) acc[s][g] = bb;
+    }
+#pragma unroll 4
+    for (int k = 0; k < n_in; ++k) {
+        float wv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wv[g] = w[(size_t)k * 256 + g * RNN_H + lane];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const float xv = xin[s][k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[s][g] = fmaf(xv, wv[g], acc[s][g]);
+        }
+    }
+    if (!first) {
+        const float* wh = w + (size_t)n_in * 256;
+#pragma unroll 4
+        for (int k = 0; k < RNN_H; ++k) {
+            float wv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[g] = wh[(size_t)k * 256 + g * RNN_H + lane];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const float hv = hp[s * RNN_H + k];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[s][g] = fmaf(hv, wv[g], acc[s][g]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const float i = sigm(acc[s][0]), f = sigm(acc[s][1]), gg = tanhf(acc[s][2]), o = sigm(acc[s][3]);
+        c[s] = first ? i * gg : fmaf(f, c[s], i * gg);
+        hcur[s] = o * tanhf(c[s]);
+    }
+}
+
+template <int SPW>
+__global__ __launch_bounds__(64) void heads_rnn_kernel(HeadParams p, int ni) {
+    extern __shared__ __attribute__((aligned(16))) float rnn_lds[];
+    const NetDesc& n = p.nets[ni];
+    const int lane = threadIdx.x, T = n.T, O = n.n_out;
+    const int s0 = blockIdx.x * SPW;
+    float* xs = rnn_lds;                                 // [SPW][T][96]
+    float* y0 = xs + (size_t)SPW * T * 96;               // [SPW][T][128]  layer-0 outputs (forward | backward)
+    float* hp = y0 + (size_t)SPW * T * 128;              // [SPW][64]      previous hidden vector of the running direction
+    float* last = hp + SPW * RNN_H;                      // [SPW][128]     out[:, -1] of layer 1
+    float* sz = last + SPW * 128;                        // [SPW][8]
+    int sid[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) sid[s] = min(s0 + s, p.S - 1);
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const float* row = feat_row(p, sid[s], T, t);
+            xs[((size_t)s * T + t) * 96 + lane] = row[lane];
+            if (lane < 32) xs[((size_t)s * T + t) * 96 + 64 + lane] = row[64 + lane];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float* q = n.rnn;
+    for (int layer = 0; layer < 2; ++layer) {
+        const int n_in = layer == 0 ? 96 : 128;
+        const float* src = layer == 0 ? xs : y0;
+        for (int dir = 0; dir < 2; ++dir) {
+            const float* w = q;
+            const float* b = q + (size_t)(n_in + RNN_H) * 256;
+            q = b + 256;
+            float c[SPW], hc[SPW];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) { c[s] = 0.f; hc[s] = 0.f; }
+            const int n_steps = (layer == 1 && dir == 1) ? 1 : T;          // out[:, -1] of the reverse direction = its first step
+            for (int it = 0; it < n_steps; ++it) {
+                const int t = dir == 0 ? it : T - 1 - it;
+                const float* xin[SPW];
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) xin[s] = src + ((size_t)s * T + t) * n_in;
+                rnn_step<SPW>(w, b, n_in, xin, hp, it == 0, c, hc, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane has read the previous hidden vector
+#pragma unroll
+                for (int s = 0; s < SPW; ++s) {
+                    hp[s * RNN_H + lane] = hc[s];
+                    if (layer == 0) y0[((size_t)s * T + t) * 128 + dir * RNN_H + lane] = hc[s];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) if (layer == 1) last[s * 128 + dir * RNN_H + lane] = hc[s];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    const float* w_out = q;
+    const float* b_out = q + (size_t)128 * O;
+    if (lane < O) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            float a = b_out[lane];
+            for (int k = 0; k < 128; ++k) a = fmaf(last[s * 128 + k], w_out[k * O + lane], a);
+            sz[s * 8 + lane] = a;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < SPW && s0 + lane < p.S) {
+        float z[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) z[o] = o < O ? sz[lane * 8 + o] : 0.f;
+        if (n.final_act == 1) {
+            float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < O) { z[o] = fmaxf(z[o], 0.f); mx = fmaxf(mx, z[o]); }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < O) { z[o] = expf(z[o] - mx); sum += z[o]; }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < O) z[o] /= sum;
+        } else {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < O) z[o] = sigm(z[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < O) store_raw(p, s0 + lane, n.out_col + o, z[o]);
     }
 }
 

@@ -21,7 +21,7 @@ from . import _lib, weights as W
 
 CHUNK = 1280
 EMB_DIM = 96
-_KIND = {"binary": 0, "gated": 1, "multiclass": 2}
+_KIND = {"binary": 0, "gated": 1, "multiclass": 2, "rnn": 3}
 # rows x mel-width x channels that each CNN layer produces per 80 ms step (incremental form)
 LAYER_NEW_SHAPES = ([(8, 32, 24)] * 3 + [(4, 16, 48)] * 4 + [(4, 8, 72)] * 4 + [(2, 4, 96)] * 4 +
                     [(2, 2, 96)] * 4 + [(1, 1, 96)])
@@ -51,6 +51,22 @@ def pack_embedding_blob(emb: dict) -> np.ndarray:
 
 def pack_head_blob(head: dict) -> np.ndarray:
     T, H, O = int(head["T"]), int(head["hidden"]), int(head["n_out"])
+    if head["kind"] == "rnn":
+        # train.py:85-98: hdr = {3, T, 64, n_out, 0, 0, 0, 0}; per layer, per direction: w [in + 64][256] (rows x ; h, columns i | f | g | o),
+        # b [256]; then w_out [128][n_out], b_out [n_out]
+        if H != W.RNN_HID or len(head["lstm"]) != 2 or any(len(layer) != 2 for layer in head["lstm"]):
+            raise ValueError("an rnn head is a 2-layer bidirectional LSTM(64) (train.py:88)")
+        parts = [np.array([3, T, H, O, 0, 0, 0, 0], dtype=np.int32).view(np.float32)]
+        for li, layer in enumerate(head["lstm"]):
+            n_in = EMB_DIM if li == 0 else 2 * H
+            for w, b in layer:
+                if w.shape != (n_in + H, 4 * H) or b.shape != (4 * H,):
+                    raise ValueError("rnn head weight shapes do not match train.py:85-98")
+                parts += [w.ravel(), b]
+        if head["w_out"].shape != (2 * H, O) or head["b_out"].shape != (O,):
+            raise ValueError("rnn head output layer shape")
+        parts += [head["w_out"].ravel(), head["b_out"]]
+        return np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in parts])
     has_ln = head["net"].get("ln1") is not None
     n_blocks = len(W.net_blocks(head["net"]))             # train.py:73; hdr[5] counts the blocks beyond the released models' one
     hdr = np.array([_KIND[head["kind"]], T, H, O, int(has_ln), n_blocks - 1, 0, 0], dtype=np.int32)

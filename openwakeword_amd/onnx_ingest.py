@@ -128,15 +128,31 @@ def _graph(buf: bytes) -> dict:
     """One GraphProto (the model's, or an If branch): initializers (Constant nodes included), nodes, input / output names."""
     inits: Dict[str, np.ndarray] = {}
     nodes, inputs, outputs = [], [], []
+    shapes: Dict[str, list] = {}
     for fno, wt, v in _fields(buf):
         if fno == 5:
             name, arr = _tensor(v)
             if arr is not None:
                 inits[name] = arr
-        elif fno in (11, 12):                                   # ValueInfoProto: name = field 1
+        elif fno in (11, 12):                                   # ValueInfoProto: name = field 1, type = field 2
+            vname = ""
             for f2, _w2, v2 in _fields(v):
                 if f2 == 1:
-                    (inputs if fno == 11 else outputs).append(v2.decode())
+                    vname = v2.decode()
+                    (inputs if fno == 11 else outputs).append(vname)
+                elif f2 == 2:                                   # TypeProto.tensor_type (1) . shape (2) . dim (1) . dim_value (1)
+                    dims = []
+                    for f3, _w3, v3 in _fields(v2):
+                        if f3 != 1:
+                            continue
+                        for f4, _w4, v4 in _fields(v3):
+                            if f4 != 2:
+                                continue
+                            for f5, _w5, v5 in _fields(v4):
+                                if f5 == 1:
+                                    dv = [x for f6, _w6, x in _fields(v5) if f6 == 1]
+                                    dims.append(int(dv[0]) if dv else None)        # (a symbolic dimension: None)
+                    shapes[vname] = dims
         elif fno == 1:
             node = {"op": "", "name": "", "inputs": [], "outputs": [], "attrs": {}}
             for f2, w2, v2 in _fields(v):
@@ -155,7 +171,7 @@ def _graph(buf: bytes) -> dict:
                 inits[node["outputs"][0]] = node["attrs"]["value"]
                 continue
             nodes.append(node)
-    return {"initializers": inits, "nodes": nodes, "inputs": [i for i in inputs if i not in inits], "outputs": outputs}
+    return {"initializers": inits, "nodes": nodes, "inputs": [i for i in inputs if i not in inits], "outputs": outputs, "shapes": shapes}
 
 
 def load_graph(path: str) -> dict:
@@ -448,10 +464,11 @@ def load_head(path: str) -> dict:
     lin = [c for c in cons if c["op"] in ("Gemm", "MatMul")]
     ifs = [n for n in g["nodes"] if n["op"] == "If"]
     rec = sorted({n["op"] for n in g["nodes"] if n["op"] in ("LSTM", "GRU", "RNN")})
+    if rec == ["LSTM"]:
+        return _load_rnn_head(fl, g, x)                         # train.py:85-98: model_type = "rnn"
     if rec:
-        # train.py:85-98: model_type = "rnn" (two bidirectional LSTM layers over the T feature rows, then a linear layer)
-        fl.refuse(f"a recurrent network ({', '.join(rec)}: train.py's model_type 'rnn'); the head kernels evaluate the fully connected "
-                  "form (model_type 'dnn', train.py:56-83) only")
+        fl.refuse(f"a recurrent network of {', '.join(rec)} nodes; of the recurrent forms only train.py's model_type 'rnn' (two "
+                  "bidirectional LSTM(64) layers, train.py:85-98) has a kernel")
     if not lin:
         fl.refuse(f"no linear layer consumes the (flattened) input; found {[c['op'] for c in cons]}")
     if len(lin) > 2 or len(lin) + len(ifs) > 2:
@@ -490,6 +507,113 @@ def load_head(path: str) -> dict:
     if net2 is not None:
         head["net2"] = net2
     return head
+
+
+def _load_rnn_head(fl: _Flow, g: dict, x: str) -> dict:
+    """train.py:85-98 (model_type "rnn") as torch.onnx.export writes it: input [B, T, 96] -> Transpose to time-major -> LSTM
+    (bidirectional, hidden 64, zero initial state) -> Transpose + Reshape to [T, B, 128] -> LSTM (the same) -> back to batch-first ->
+    Gather of the LAST time step -> Gemm(128 -> n_out) -> Sigmoid | Relu -> Softmax.  Returns the layout of weights.synthetic_rnn_head.
+    Everything the kernel fixes is checked: two layers, both directions, hidden size, default activations, no peepholes / sequence
+    lengths / input_forget, zero initial state, the last-step selection, the output activation."""
+    nodes, inits = g["nodes"], g["initializers"]
+    H = W.RNN_HID
+    allowed = {"LSTM", "Transpose", "Reshape", "Shape", "Gather", "Unsqueeze", "Squeeze", "Concat", "Expand", "Slice", "Cast", "Identity",
+               "ConstantOfShape", "Gemm", "MatMul", "Add", "Sigmoid", "Relu", "Softmax", "Flatten"}
+    odd = sorted({n["op"] for n in nodes} - allowed)
+    if odd:
+        fl.refuse(f"a recurrent head with {odd}: not the graph of train.py's model_type 'rnn'")
+    lstms = [n for n in nodes if n["op"] == "LSTM"]
+    if len(lstms) != 2:
+        fl.refuse(f"{len(lstms)} LSTM nodes, expected the two layers of nn.LSTM(96, 64, num_layers=2, bidirectional=True) (train.py:88)")
+
+    def upstream(t: str) -> str:                                  # through shape-only operators to the tensor that carries the data
+        seen = 0
+        while t in fl.producer and fl.producer[t]["op"] in ("Transpose", "Reshape", "Squeeze", "Unsqueeze", "Identity", "Cast", "Flatten") and seen < 16:
+            t = fl.producer[t]["inputs"][0]
+            seen += 1
+        return t
+
+    if upstream(lstms[0]["inputs"][0]) != x:
+        lstms.reverse()
+    if upstream(lstms[0]["inputs"][0]) != x or upstream(lstms[1]["inputs"][0]) != lstms[0]["outputs"][0]:
+        fl.refuse("the two LSTM layers are not chained input -> layer 0 -> Y -> layer 1")
+    layers = []
+    for li, n in enumerate(lstms):
+        a = n["attrs"]
+        n_in = W.EMB_DIM if li == 0 else 2 * H
+        if (a.get("hidden_size") or 0) != H or (a.get("direction") or "forward") != "bidirectional":
+            fl.refuse(f"LSTM layer {li}: hidden_size {a.get('hidden_size')} / direction {a.get('direction')}, expected {H} / bidirectional")
+        if a.get("activations") or a.get("input_forget") or a.get("layout") or a.get("clip") is not None:
+            fl.refuse(f"LSTM layer {li} sets activations / input_forget / layout / clip: only the defaults have a kernel")
+        ins = n["inputs"] + [""] * (8 - len(n["inputs"]))
+        if ins[4] or ins[7]:
+            fl.refuse(f"LSTM layer {li} uses sequence_lens / peepholes")
+        for k in (5, 6):                                          # initial_h / initial_c: absent, or zeros (Expand of a zero constant)
+            t = ins[k]
+            if not t:
+                continue
+            while t in fl.producer and fl.producer[t]["op"] in ("Expand", "Identity", "Reshape", "Cast"):
+                t = fl.producer[t]["inputs"][0]
+            v = inits.get(t)
+            if v is None and t in fl.producer and fl.producer[t]["op"] == "ConstantOfShape":
+                cv = fl.producer[t]["attrs"].get("value")
+                v = np.zeros(1) if cv is None else np.asarray(cv)
+            if v is None or np.any(np.asarray(v) != 0):
+                fl.refuse(f"LSTM layer {li} starts from a non-zero (or computed) state; nn.LSTM called without (h0, c0) starts from zeros")
+        try:
+            wi, wr = inits[ins[1]], inits[ins[2]]                 # [2, 4H, in], [2, 4H, H]; ONNX gate order i, o, f, c
+            bb = inits[ins[3]] if ins[3] else np.zeros((2, 8 * H), np.float32)
+        except KeyError:
+            fl.refuse(f"LSTM layer {li}: weights are not initializers")
+        if wi.shape != (2, 4 * H, n_in) or wr.shape != (2, 4 * H, H) or bb.shape != (2, 8 * H):
+            fl.refuse(f"LSTM layer {li} weights {tuple(wi.shape)} / {tuple(wr.shape)} / {tuple(bb.shape)}, expected (2, {4 * H}, {n_in}), (2, {4 * H}, {H}), (2, {8 * H})")
+        order = [0, 2, 3, 1]                                      # ours (torch's): i | f | g | o  <-  ONNX blocks i(0) o(1) f(2) c(3)
+        dirs = []
+        for d in range(2):
+            rows = np.concatenate([wi[d], wr[d]], axis=1)         # [4H, in + H]: columns x ; h
+            rows = np.concatenate([rows[k * H:(k + 1) * H] for k in order], axis=0)
+            bias = bb[d, :4 * H] + bb[d, 4 * H:]
+            bias = np.concatenate([bias[k * H:(k + 1) * H] for k in order])
+            dirs.append((np.ascontiguousarray(rows.T, np.float32), np.ascontiguousarray(bias, np.float32)))
+        layers.append(dirs)
+    # ---- out[:, -1] -> Linear -> activation
+    lin = [n for n in nodes if n["op"] in ("Gemm", "MatMul") and any(i in inits and inits[i].ndim == 2 and 2 * H in inits[i].shape for i in n["inputs"])]
+    if len(lin) != 1:
+        fl.refuse(f"{len(lin)} linear layers of {2 * H} inputs behind the LSTM, expected one (train.py:90)")
+    gsrc = fl.data_input(lin[0])
+    sel = fl.producer.get(gsrc)
+    while sel is not None and sel["op"] in ("Reshape", "Squeeze", "Unsqueeze", "Identity", "Flatten"):
+        sel = fl.producer.get(sel["inputs"][0])
+    shape_in = (g.get("shapes") or {}).get(x) or []
+    T = shape_in[1] if len(shape_in) == 3 and shape_in[1] else None
+    if sel is None or sel["op"] != "Gather" or upstream(sel["inputs"][0]) != lstms[1]["outputs"][0]:
+        fl.refuse("the linear layer does not read ONE time step of the second LSTM layer's output (out[:, -1], train.py:94)")
+    idx = inits.get(sel["inputs"][1])
+    tr = fl.producer.get(sel["inputs"][0])
+    batch_first = tr is not None and tr["op"] == "Transpose" and list(tr["attrs"].get("perm") or []) == [1, 0, 2]
+    want_axis = 1 if batch_first else 0
+    if idx is None or np.asarray(idx).size != 1 or int(sel["attrs"].get("axis", 0)) != want_axis or \
+            int(np.asarray(idx).reshape(-1)[0]) not in ((-1,) if T is None else (-1, T - 1)):
+        fl.refuse(f"the time step selected (Gather axis {sel['attrs'].get('axis', 0)}, index {None if idx is None else np.asarray(idx).reshape(-1).tolist()}) "
+                  "is not the last one (out[:, -1])")
+    w, b, cur = _walk_linear(fl, lin[0], "output layer")
+    tail = []
+    while True:
+        cons = fl.consumers.get(cur, [])
+        if len(cons) != 1 or cons[0]["op"] not in ("Sigmoid", "Relu", "Softmax"):
+            break
+        tail.append(cons[0]["op"])
+        cur = cons[0]["outputs"][0]
+    n_out = int(w.shape[1])
+    if not ((tail == ["Sigmoid"] and n_out == 1) or (tail == ["Relu", "Softmax"] and n_out > 1)):
+        fl.refuse(f"unsupported output activation {tail} for {n_out} output(s) (supported: Sigmoid for one class, Relu -> Softmax -- the "
+                  "wrapper train.py:152-165 exports multiclass models under)")
+    if T is None:
+        fl.refuse("the input's time dimension is not declared in the file (the reference reads it from there: model.py:156)")
+    if w.shape[0] != 2 * H or cur not in g["outputs"]:
+        fl.refuse("the output layer does not end the graph")
+    return {"kind": "rnn", "T": int(T), "hidden": H, "n_out": n_out, "lstm": layers,
+            "w_out": np.ascontiguousarray(w, np.float32), "b_out": np.ascontiguousarray(b, np.float32)}
 
 
 def _pick_zero(fl: _Flow, n: dict) -> bool:

@@ -200,6 +200,8 @@ def synthetic_head(name: str, seed: int = 1234, kind: Optional[str] = None, T: O
     n_out = n_out or cat[3]
     layernorm = cat[4] if layernorm is None else layernorm
     r = _rng(seed, f"head:{base}")
+    if kind == "rnn":
+        return synthetic_rnn_head(r, int(T), int(n_out))
     head = {"kind": kind, "T": int(T), "hidden": int(hidden), "n_out": int(n_out),
             "net": _synthetic_mlp(r, T * EMB_DIM, hidden, n_out, layernorm,
                                   out_gain=0.5 if kind == "multiclass" else 8.0, n_blocks=n_blocks)}
@@ -217,7 +219,34 @@ def synthetic_head(name: str, seed: int = 1234, kind: Optional[str] = None, T: O
     return head
 
 
+RNN_HID = 64         # train.py:88: nn.LSTM(input_shape[-1], 64, num_layers=2, bidirectional=True)
+
+
+def synthetic_rnn_head(r: np.random.Generator, T: int = 16, n_out: int = 1) -> dict:
+    """Random-init head of the reference's other model_type, "rnn" (train.py:85-98): a 2-layer bidirectional LSTM(64) over the T feature
+    rows, Linear(128 -> n_out) on the LAST time step's output, Sigmoid (one class) or ReLU (+ the softmax train.py:152-165 adds at
+    export).  'lstm': [layer][direction] = (w [in + 64, 256]: rows (x ; h), columns (i | f | g | o) -- torch's gate order --,
+    b [256] = b_ih + b_hh), in = 96 for layer 0 and 128 for layer 1; 'w_out' [128, n_out], 'b_out' [n_out]."""
+    H = RNN_HID
+    lstm = []
+    for layer in range(2):
+        n_in = EMB_DIM if layer == 0 else 2 * H
+        dirs = []
+        for _d in range(2):
+            # (the synthetic embeddings are of order 10: layer-0 input weights small enough that the gates are not all saturated)
+            w = np.concatenate([r.normal(0, (0.35 if layer == 0 else 1.2) / np.sqrt(n_in), (n_in, 4 * H)),
+                                r.normal(0, 0.8 / np.sqrt(H), (H, 4 * H))], axis=0).astype(np.float32)
+            b = r.normal(0, 0.3, 4 * H).astype(np.float32)
+            dirs.append((w, b))
+        lstm.append(dirs)
+    return {"kind": "rnn", "T": int(T), "hidden": H, "n_out": int(n_out), "lstm": lstm,
+            "w_out": r.normal(0, 12.0 / np.sqrt(2 * H), (2 * H, n_out)).astype(np.float32),
+            "b_out": r.normal(0, 0.3, n_out).astype(np.float32)}
+
+
 def head_param_count(head: dict) -> int:
+    if head["kind"] == "rnn":
+        return sum(w.size + b.size for layer in head["lstm"] for w, b in layer) + head["w_out"].size + head["b_out"].size
     def cnt(net):
         n = 0
         for k, v in net.items():

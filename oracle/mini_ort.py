@@ -253,29 +253,36 @@ def _maxpool(x, a):
 
 
 def _lstm(x, a):
-    """ONNX LSTM, forward direction, default activations: X [T, B, in] (layout 0), W [1, 4H, in], R [1, 4H, H], B [1, 8H], gate order
-    i o f c, optional sequence_lens (unsupported), initial_h / initial_c [1, B, H] -> Y [T, 1, B, H], Y_h, Y_c [1, B, H]."""
-    if a.get("direction", "forward") != "forward" or a.get("layout", 0) != 0 or a.get("input_forget", 0):
-        raise NotImplementedError("mini_ort: LSTM direction / layout / input_forget")
-    X, Wm, R = x[0], x[1][0], x[2][0]
+    """ONNX LSTM, default activations: X [T, B, in] (layout 0), W [D, 4H, in], R [D, 4H, H], B [D, 8H] (D = 1: forward | reverse, 2:
+    bidirectional), gate order i o f c, optional sequence_lens (unsupported), initial_h / initial_c [D, B, H] -> Y [T, D, B, H] (the
+    reverse direction's rows at the positions of their inputs), Y_h, Y_c [D, B, H]."""
+    direction = a.get("direction", "forward")
+    if direction not in ("forward", "reverse", "bidirectional") or a.get("layout", 0) != 0 or a.get("input_forget", 0) or a.get("activations"):
+        raise NotImplementedError("mini_ort: LSTM direction / layout / input_forget / activations")
+    X = x[0]
     H = int(a["hidden_size"])
-    Bv = x[3][0] if len(x) > 3 and x[3] is not None else np.zeros(8 * H, X.dtype)
+    D = 2 if direction == "bidirectional" else 1
     if len(x) > 4 and x[4] is not None:
         raise NotImplementedError("mini_ort: LSTM sequence_lens")
-    h = x[5][0] if len(x) > 5 and x[5] is not None else np.zeros((X.shape[1], H), X.dtype)
-    c = x[6][0] if len(x) > 6 and x[6] is not None else np.zeros((X.shape[1], H), X.dtype)
     if len(x) > 7 and x[7] is not None:
         raise NotImplementedError("mini_ort: LSTM peepholes")
     sig = lambda z: 1.0 / (1.0 + np.exp(-z))
-    ys = []
-    for t in range(X.shape[0]):
-        z = X[t] @ Wm.T + h @ R.T + Bv[:4 * H] + Bv[4 * H:]
-        i, o, f, g = (z[:, k * H:(k + 1) * H] for k in range(4))
-        c = sig(f) * c + sig(i) * np.tanh(g)
-        h = sig(o) * np.tanh(c)
-        ys.append(h)
-    Y = np.stack(ys)[:, None].astype(X.dtype)
-    return Y, h[None].astype(X.dtype), c[None].astype(X.dtype)
+    Y = np.zeros((X.shape[0], D, X.shape[1], H), X.dtype)
+    Yh, Yc = [], []
+    for d in range(D):
+        Wm, R = x[1][d], x[2][d]
+        Bv = x[3][d] if len(x) > 3 and x[3] is not None else np.zeros(8 * H, X.dtype)
+        h = x[5][d] if len(x) > 5 and x[5] is not None else np.zeros((X.shape[1], H), X.dtype)
+        c = x[6][d] if len(x) > 6 and x[6] is not None else np.zeros((X.shape[1], H), X.dtype)
+        rev = direction == "reverse" or d == 1
+        for t in (range(X.shape[0] - 1, -1, -1) if rev else range(X.shape[0])):
+            z = X[t] @ Wm.T + h @ R.T + Bv[:4 * H] + Bv[4 * H:]
+            i, o, f, g = (z[:, k * H:(k + 1) * H] for k in range(4))
+            c = sig(f) * c + sig(i) * np.tanh(g)
+            h = sig(o) * np.tanh(c)
+            Y[t, d] = h
+        Yh.append(h); Yc.append(c)
+    return Y, np.stack(Yh).astype(X.dtype), np.stack(Yc).astype(X.dtype)
 
 
 def _axes(node, inputs, opset_from_input: int, opset: int):

@@ -312,6 +312,8 @@ def head_stage(x: np.ndarray, head: dict, dtype=np.float32) -> np.ndarray:
     if x.ndim == 2:
         x = x[None]
     kind = head["kind"]
+    if kind == "rnn":
+        return _rnn_head(x, head, dtype)
     if kind == "multiclass":
         z = np.maximum(_mlp(x, head["net"], dtype), dtype(0))
         z = z - z.max(axis=1, keepdims=True)
@@ -322,6 +324,39 @@ def head_stage(x: np.ndarray, head: dict, dtype=np.float32) -> np.ndarray:
         s2 = 1.0 / (1.0 + np.exp(-_mlp(x, head["net2"], dtype)))
         s = np.where(s > 0.5, s2, s)
     return s.astype(dtype)
+
+
+def _lstm_direction(x: np.ndarray, w: np.ndarray, b: np.ndarray, reverse: bool, dtype) -> np.ndarray:
+    """One direction of one torch.nn.LSTM layer from a zero state: x [B, T, in] -> h [B, T, H]; w [in + H, 4H] rows (x ; h), columns
+    (i | f | g | o), b = b_ih + b_hh.  (torch's equations: i, f, o = sigmoid, g = tanh; c' = f c + i g; h' = o tanh(c').)"""
+    B, T, _ = x.shape
+    H = w.shape[1] // 4
+    w, b = w.astype(dtype), b.astype(dtype)
+    h, c = np.zeros((B, H), dtype), np.zeros((B, H), dtype)
+    out = np.zeros((B, T, H), dtype)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))        # noqa: E731
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        z = np.concatenate([x[:, t], h], axis=1) @ w + b
+        i, f, g, o = sig(z[:, :H]), sig(z[:, H:2 * H]), np.tanh(z[:, 2 * H:3 * H]), sig(z[:, 3 * H:])
+        c = f * c + i * g
+        h = o * np.tanh(c)
+        out[:, t] = h
+    return out.astype(dtype)
+
+
+def _rnn_head(x: np.ndarray, head: dict, dtype) -> np.ndarray:
+    """train.py:85-98, model_type "rnn": `out, h = LSTM(96, 64, num_layers=2, bidirectional=True)(x)`, then
+    `Sigmoid | ReLU (Linear(128, n_classes)(out[:, -1]))`; multiclass files carry the softmax train.py:152-165 wraps around the model."""
+    a = x.astype(dtype)
+    for layer in head["lstm"]:
+        a = np.concatenate([_lstm_direction(a, layer[0][0], layer[0][1], False, dtype),
+                            _lstm_direction(a, layer[1][0], layer[1][1], True, dtype)], axis=2)
+    z = a[:, -1] @ head["w_out"].astype(dtype) + head["b_out"].astype(dtype)
+    if int(head["n_out"]) == 1:
+        return (1.0 / (1.0 + np.exp(-z))).astype(dtype)
+    z = np.maximum(z, dtype(0))
+    e = np.exp(z - z.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True)).astype(dtype)
 
 
 # --------------------------------------------------------------------------------------

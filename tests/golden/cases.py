@@ -36,9 +36,10 @@ VAD_CASES = [
 
 # The reference on real model FILES (tests/golden/make_golden_onnx.py): heads written by PyTorch's exporter under these names and
 # opsets (13 and older: decomposed LayerNorm; 17: the fused operator), loaded BY PATH; multiclass = the catalogue's timer shape.
-ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom", "jarvis_custom", "jarvis_custom_if", "deep2_custom", "flat0_custom"]
+ONNX_HEADS = ["alexa_custom", "mycroft_custom", "timer_custom", "jarvis_custom", "jarvis_custom_if", "deep2_custom", "flat0_custom",
+              "rnn_custom", "rnn3_custom"]
 ONNX_HEAD_OPSETS = {"alexa_custom": 13, "mycroft_custom": 17, "timer_custom": 12, "jarvis_custom": 13, "jarvis_custom_if": 13,
-                    "deep2_custom": 17, "flat0_custom": 13}
+                    "deep2_custom": 17, "flat0_custom": 13, "rnn_custom": 13, "rnn3_custom": 17}
 ONNX_FILE_CASES = [
     ("f1280", ["alexa_custom", "mycroft_custom"], "alexa_test", dict(chunk_size=1280)),
     ("f1280j", ["alexa_custom", "mycroft_custom"], "hey_jane", dict(chunk_size=1280)),
@@ -52,6 +53,9 @@ ONNX_FILE_CASES = [
     ("fjarvisif", ["jarvis_custom_if"], "hey_jane", dict(chunk_size=1280)),
     # train.py:67-73: Net(n_blocks) -- two hidden blocks of 32 units (the training pipeline's width) and none at all
     ("fdeep", ["deep2_custom", "flat0_custom", "alexa_custom"], "hey_jane", dict(chunk_size=1280)),
+    # train.py:85-98: model_type "rnn" -- 2-layer bidirectional LSTM(64) + Linear on the last step; one class (Sigmoid) and three (softmax wrapper)
+    ("frnn", ["rnn_custom", "alexa_custom"], "hey_jane", dict(chunk_size=1280)),
+    ("frnn3", ["rnn3_custom"], "alexa_test", dict(chunk_size=2560)),
 ]
 
 
@@ -63,6 +67,8 @@ def onnx_file_weights():
     heads = {n: W.synthetic_head(b, SEED_WEIGHTS) for n, b in base.items()}
     heads["deep2_custom"] = W.synthetic_head("deep2", SEED_WEIGHTS, hidden=32, n_blocks=2)
     heads["flat0_custom"] = W.synthetic_head("flat0", SEED_WEIGHTS, n_blocks=0)
+    heads["rnn_custom"] = W.synthetic_head("rnn", SEED_WEIGHTS, kind="rnn", n_out=1)
+    heads["rnn3_custom"] = W.synthetic_head("rnn3", SEED_WEIGHTS, kind="rnn", n_out=3)
     return {"embedding": W.synthetic_embedding(SEED_WEIGHTS), "heads": heads}
 
 # direct predict() calls of ragged sizes, empty calls included (model.py:232-386 on whatever the caller hands over)

@@ -409,6 +409,36 @@ def test_large_batch_properties(emb, heads):
         small.close()
 
 
+@pytest.mark.parametrize("S", [40, 2500])
+def test_weight_ring_depth_never_changes_a_bit(emb, heads, monkeypatch, S):
+    """The stage kernels stream their weights through an LDS ring of 2 slots (large launches) or 3 (at most two workgroups per CU) --
+    and of 4 / 5 in builds with -DOWH_DEEP_RING (OWW_DEEP_WGS; measured no faster, not in the default build, where the variable is
+    ignored) -- same arithmetic in the same order, only what is in flight differs.  Scores AND feature rings of a handle pinned to
+    the deepest ring built, to the three-slot ring and to the two-slot ring must be bit-identical."""
+    pcm = W.synthetic_pcm(S, 1280 * 8, seed=91)
+
+    def run(deep, small):
+        monkeypatch.setenv("OWW_DEEP_WGS", str(deep))
+        monkeypatch.setenv("OWW_SMALL_WGS", str(small))
+        e = StreamEngine(S, heads, emb)
+        try:
+            out = np.stack([e.step(pcm[:, 1280 * t: 1280 * (t + 1)]) for t in range(8)])
+            feats = np.stack([e.get_features(s, 16) for s in (0, S // 2, S - 1)])
+            assert not e.range_status()
+            return out, feats
+        finally:
+            e.close()
+
+    a = run(1 << 20, 1 << 20)          # every stage on its deepest ring
+    b = run(0, 1 << 20)                # three slots
+    c = run(0, 0)                      # two slots
+    monkeypatch.delenv("OWW_DEEP_WGS"); monkeypatch.delenv("OWW_SMALL_WGS")
+    for x, y in ((a, b), (a, c)):
+        np.testing.assert_array_equal(x[0], y[0])
+        np.testing.assert_array_equal(x[1], y[1])
+    assert a[0][-1].max() > 0
+
+
 def test_block_pipelined_step_is_bit_identical(emb, heads, monkeypatch):
     """OWW_BLOCKS=3: the fused one-chunk step launched as three stream blocks on internal HIP streams (off by default: measured no
     faster) must give exactly the scores of the single-launch step, also through a masked step.  Since round 4 this is also the

@@ -794,27 +794,72 @@ def test_torch_exported_heads_of_any_depth_load_to_the_same_network(tmp_path, na
     assert blob.size == 8 + T * 96 * H + H + ln_n + n_blocks * (H * H + H + ln_n) + H * O_ + O_
 
 
-def test_the_recurrent_model_type_is_refused_by_name(tmp_path):
-    """train.py:85-98: model_type = 'rnn' is a two-layer bidirectional LSTM over the feature rows -- not a network the head kernels run."""
+@pytest.mark.parametrize("n_out,opset", [(1, 11), (1, 17), (4, 13)])
+def test_the_recurrent_model_type_written_by_pytorchs_exporter(tmp_path, n_out, opset):
+    """train.py:85-98: model_type = 'rnn' -- nn.LSTM(96, 64, num_layers=2, bidirectional=True) over the feature rows, Linear(128, n) on
+    out[:, -1], Sigmoid | ReLU (+ the softmax wrapper of train.py:152-165).  The file PyTorch's exporter writes for that module loads
+    to the weights it was built from (ONNX gate order i o f c -> torch's i f g o, b_ih + b_hh summed), the oracle on the loaded head
+    equals the torch module, and the blob the C ABI takes has the documented size."""
+    torch = pytest.importorskip("torch")
+    import torch_export as TE
+    from openwakeword_amd import engine
+    head = W.synthetic_head("anrnn", 9, kind="rnn", n_out=n_out, T=16)
+    module = TE.torch_rnn_head(head)
+    path = os.path.join(tmp_path, "rnn.onnx")
+    try:
+        TE.torch_export_head(module, 16, path, opset)
+    except Exception as e:                                  # noqa: BLE001
+        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+    got = onnx_ingest.load_head(path)
+    assert (got["kind"], got["T"], got["hidden"], got["n_out"]) == ("rnn", 16, 64, n_out)
+    for li in range(2):
+        for d in range(2):
+            np.testing.assert_array_equal(got["lstm"][li][d][0], head["lstm"][li][d][0])
+            np.testing.assert_allclose(got["lstm"][li][d][1], head["lstm"][li][d][1], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(got["w_out"], head["w_out"])
+    x = np.random.default_rng(1).normal(0, 3.0, (5, 16, 96)).astype(np.float32)
+    with torch.no_grad():
+        want = module(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(O.head_stage(x, got, np.float32), want, rtol=0, atol=2e-6)
+    assert engine.pack_head_blob(got).size == 8 + 2 * (160 * 256 + 256) + 2 * (192 * 256 + 256) + 128 * n_out + n_out
+
+
+def test_recurrent_heads_other_than_train_pys_are_refused_by_name(tmp_path):
+    """What heads_rnn_kernel fixes is checked in the file: both directions, 64 hidden units, two layers, the LAST time step."""
     torch = pytest.importorskip("torch")
 
     class Rnn(torch.nn.Module):
-        def __init__(self):
+        def __init__(self, hidden=64, layers=2, bi=True, step=-1):
             super().__init__()
-            self.layer1 = torch.nn.LSTM(96, 64, num_layers=2, bidirectional=True, batch_first=True, dropout=0.0)
-            self.layer2 = torch.nn.Linear(128, 1)
+            self.step = step
+            self.layer1 = torch.nn.LSTM(96, hidden, num_layers=layers, bidirectional=bi, batch_first=True, dropout=0.0)
+            self.layer2 = torch.nn.Linear(hidden * (2 if bi else 1), 1)
             self.layer3 = torch.nn.Sigmoid()
 
         def forward(self, x):
             out, _h = self.layer1(x)
-            return self.layer3(self.layer2(out[:, -1]))
+            return self.layer3(self.layer2(out[:, self.step]))
 
     path = os.path.join(tmp_path, "rnn.onnx")
-    try:
-        _torch_export(Rnn().eval(), 16, path, 13)
-    except Exception as e:                                  # noqa: BLE001
-        pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
-    with pytest.raises(ValueError, match="recurrent network"):
+    for kw, why in ((dict(bi=False), "direction"), (dict(hidden=32), "hidden_size"), (dict(layers=1), "LSTM nodes"), (dict(step=0), "not the last one")):
+        try:
+            _torch_export(Rnn(**kw).eval(), 16, path, 13)
+        except Exception as e:                                  # noqa: BLE001
+            pytest.skip(f"torch.onnx.export is not usable in this environment: {type(e).__name__}: {e}")
+        with pytest.raises(ValueError, match=why):
+            onnx_ingest.load_head(path)
+
+    class Gru(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer1 = torch.nn.GRU(96, 64, batch_first=True)
+            self.layer2 = torch.nn.Linear(64, 1)
+
+        def forward(self, x):
+            return torch.sigmoid(self.layer2(self.layer1(x)[0][:, -1]))
+
+    _torch_export(Gru().eval(), 16, path, 13)
+    with pytest.raises(ValueError, match="recurrent network of GRU"):
         onnx_ingest.load_head(path)
 
 

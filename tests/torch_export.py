@@ -96,6 +96,52 @@ def torch_head(net, T, n_out, n_blocks=None):
     return Wrapped()
 
 
+def torch_rnn_head(head):
+    """The reference's model_type "rnn" (train.py:85-98), with the given weights: `out, h = nn.LSTM(96, 64, num_layers=2,
+    bidirectional=True, batch_first=True)(x)`; `Sigmoid | ReLU (Linear(128, n_classes)(out[:, -1]))`; a multiclass model is exported
+    under the softmax wrapper of train.py:152-165."""
+    import torch
+    import torch.nn as nn
+    n_out, H = int(head["n_out"]), W.RNN_HID
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer1 = nn.LSTM(W.EMB_DIM, H, num_layers=2, bidirectional=True, batch_first=True, dropout=0.0)
+            self.layer2 = nn.Linear(H * 2, n_out)
+            self.layer3 = nn.Sigmoid() if n_out == 1 else nn.ReLU()
+
+        def forward(self, x):
+            out, h = self.layer1(x)
+            return self.layer3(self.layer2(out[:, -1]))
+
+    m = Net()
+    with torch.no_grad():
+        for li in range(2):
+            n_in = W.EMB_DIM if li == 0 else 2 * H
+            for d in range(2):
+                w, b = head["lstm"][li][d]
+                sfx = f"_l{li}" + ("_reverse" if d else "")
+                getattr(m.layer1, "weight_ih" + sfx).copy_(torch.from_numpy(np.ascontiguousarray(w[:n_in].T)))
+                getattr(m.layer1, "weight_hh" + sfx).copy_(torch.from_numpy(np.ascontiguousarray(w[n_in:].T)))
+                getattr(m.layer1, "bias_ih" + sfx).copy_(torch.from_numpy(b * np.float32(0.25)))       # (b = b_ih + b_hh: split unevenly on purpose)
+                getattr(m.layer1, "bias_hh" + sfx).copy_(torch.from_numpy(b - b * np.float32(0.25)))
+        m.layer2.weight.copy_(torch.from_numpy(np.ascontiguousarray(head["w_out"].T)))
+        m.layer2.bias.copy_(torch.from_numpy(head["b_out"]))
+    if n_out == 1:
+        return m
+
+    class M(nn.Module):                                 # train.py:152-165
+        def __init__(self):
+            super().__init__()
+            self.model = m
+
+        def forward(self, x):
+            return torch.nn.functional.softmax(self.model(x), dim=1)
+
+    return M()
+
+
 def torch_embedding(emb, act="leakyclamp"):
     """The speech-embedding CNN (notebook cell 18, restated in oracle/oww_oracle.py: CNN_LAYERS) as a torch module in NCHW, input
     [B, 76, 32, 1] permuted once -- for PyTorch's exporter, which folds eval-mode BatchNorm into a preceding convolution."""
@@ -263,7 +309,9 @@ def export_reference_files(directory, weights, head_opsets=None, embedding_opset
     paths = {}
     for name, head in weights["heads"].items():
         paths[name] = os.path.join(directory, f"{name}.onnx")
-        if head["kind"] == "gated":                         # hey_jarvis-style routing: "<name>_if" = the scripted branch (an ONNX If)
+        if head["kind"] == "rnn":                           # train.py's model_type "rnn" (train.py:85-98)
+            module = torch_rnn_head(head)
+        elif head["kind"] == "gated":                       # hey_jarvis-style routing: "<name>_if" = the scripted branch (an ONNX If)
             module = torch_gated(head, "if" if name.endswith("_if") else "where")
         else:
             module = torch_head(head["net"], head["T"], head["n_out"])

@@ -13,7 +13,8 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_TC_INST_REQ" \
            "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-           "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+           "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           ${PMC_EXTRA:+"$PMC_EXTRA"} ${PMC_EXTRA2:+"$PMC_EXTRA2"}; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -- $BENCH > $out/pmc$i.log 2>&1
 done
