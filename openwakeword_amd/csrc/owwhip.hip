@@ -2071,7 +2071,7 @@ int oww_commit(oww_ctx* h) {
         }
         if (g.ht == 4) if (int rc = set_lds(heads64_kernel, heads_lds_bytes(g.NH))) return rc;
     }
-    for (int ni : h->rnn_nets) if (int rc = set_lds(heads_rnn_kernel<RNN_SPW>, (int)rnn_lds_bytes(RNN_TMAX))) return rc;
+    if (!h->rnn_nets.empty()) if (int rc = set_lds(heads_rnn_kernel<RNN_SPW>, (int)rnn_lds_bytes(RNN_TMAX))) return rc;
 
     // ---- sticky range flag of the f16-split kernels: page-locked + device-mapped, so the host reads it without a copy ----
     {

@@ -407,9 +407,47 @@ __device__ __forceinline__ void ring_end(int oct) {
     }
 }
 
+// ---- A operands one k-group ahead (OWH_APIPE) ---------------------------------------------------------------------------------------
+// A k-group = the (hi, lo) weight blocks of one (tap, k-step): two ds_read_b128 feeding 3 x NT MFMAs (NT = 2 or 4 position tiles).  Left
+// alone the compiler issues a group's reads right in front of the s_waitcnt lgkmcnt(0) that precedes its MFMAs -- in stage D the
+// schedule reads  r [wait] MM r [wait] MMMM  : every LDS round trip (~100 cycles) in the open behind 32-64 cycles of MFMA work, at two
+// waves per SIMD.  With OWH_APIPE the reads of group g + 1 are issued before the MFMAs of group g: `apipe_step` first makes the CURRENT
+// operands a use (an empty asm: the compiler's wait for them lands here), then loads the next pair, and a scheduling barrier keeps both
+// in front of the group's MFMAs.  Same MFMAs, same order: bit-identical results.  8 more VGPRs per wave.
+// Per stage: bit 0 = the 1x3 (mel) layers, bit 1 = the 3x1 (time) layers.  Same-box alternating runs at 131,072 streams
+// (profiles/r06_apipe_ab.txt): stage C with both 1.387 -> 1.351 ms (-2.6 %); everywhere (B, D, E: time layers too) B +5 %, D +7 %, E +9 %
+// -- their time layers lose the MFMA : VALU interleave of OWH_PIPE behind the scheduling barriers, D loses its third wave per SIMD
+// (172 registers), B and E spill; mel layers only: B, D unchanged (off), E -1.5 % (on).
+#ifndef OWH_APIPE_B
+#define OWH_APIPE_B 0
+#endif
+#ifndef OWH_APIPE_C
+#define OWH_APIPE_C 3
+#endif
+#ifndef OWH_APIPE_D
+#define OWH_APIPE_D 0
+#endif
+#ifndef OWH_APIPE_E
+#define OWH_APIPE_E 1
+#endif
+struct APair { f16x8 h, l; };
+__device__ __forceinline__ APair apair_load(const float* cur, int blk, int lane) { return APair{lds_h(cur, blk, lane), lds_h(cur, blk + 1, lane)}; }
+__device__ __forceinline__ void apair_pin(APair& a) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 x = __builtin_bit_cast(u32x4, a.h), y = __builtin_bit_cast(u32x4, a.l);
+    asm volatile("" : "+v"(x), "+v"(y));
+    a.h = __builtin_bit_cast(f16x8, x); a.l = __builtin_bit_cast(f16x8, y);
+}
+// current pair ready, next pair (block `next_blk`, < 0: none) on its way, both ahead of what follows
+__device__ __forceinline__ void apipe_step(APair& curp, APair& nextp, const float* cur, int next_blk, int lane) {
+    apair_pin(curp);
+    if (next_blk >= 0) nextp = apair_load(cur, next_blk, lane);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // chunk of one output-channel tile: [tap 3][ks KSI][part 2] blocks of 1 KB
 // 1x3 (mel) layer: NT tiles in operand form -> NT fp32 D tiles (BatchNorm + activation applied)
-template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, bool REM2 = false, int NS = 2>
+template <int KSI, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, bool REM2 = false, int NS = 2, bool AP = false>
 __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out)[NT][NCTO], const WRing<NS>& ring,
                                             const float* __restrict__ w, const float* __restrict__ w_next,
                                             const float* __restrict__ init, float cl, int wave, int lane,
@@ -425,6 +463,8 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
     for (int oct = 0; oct < NCTO; ++oct) {
         const float* cur = ring_begin<NS, CH0, NBLK, NCTO, NEXT_NBLK, WG>(ring, oct, w, w_next, wave, lane);
         f32x4 res[NT], accs[2][NT];
+        APair ap[2];
+        if constexpr (AP) ap[0] = apair_load(cur, 0, lane);           // (group 0: tap 0, k-step 0)
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
             const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
@@ -446,8 +486,16 @@ __device__ __forceinline__ void conv_mel_hx(const Op (&in)[NT][KSI], f32x4 (&out
             }
 #pragma unroll
             for (int ks = 0; ks < KSI; ++ks) {
-                const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
-                const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                f16x8 ah, al;
+                if constexpr (AP) {
+                    const int g = ti * KSI + ks;                  // position in the issue order (taps 0, 2, 1)
+                    const int ntap = ks + 1 < KSI ? tap : (ti == 0 ? 2 : 1), nks = ks + 1 < KSI ? ks + 1 : 0;
+                    apipe_step(ap[g & 1], ap[(g + 1) & 1], cur, g + 1 < 3 * KSI ? (ntap * KSI + nks) * 2 : -1, lane);
+                    ah = ap[g & 1].h; al = ap[g & 1].l;
+                } else {
+                    ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
+                    al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                }
                 if (REM2 && ks == KSI - 1) {                      // blocks (wh | wh), (wl | 0) against (xh | xl), (xh | 0): see split_dup
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, in[t][ks].l, acc[t]);
@@ -528,7 +576,7 @@ __device__ __forceinline__ void merge_mel_rems(const Op (&in)[NT][KSI], Op (&M)[
         }
     }
 }
-template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, int NS = 2>
+template <int KSI, int NMK, int NCTO, int NT, int F, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, int NS = 2, bool AP = false>
 __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (&M)[NT][NMK], f32x4 (&out)[NT][NCTO], const WRing<NS>& ring,
                                              const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
@@ -541,6 +589,9 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
     for (int oct = 0; oct < NCTO; ++oct) {
         const float* cur = ring_begin<NS, CH0, NBLK, NCTO, NEXT_NBLK, WG>(ring, oct, w, w_next, wave, lane);
         f32x4 res[NT], accs[2][NT];
+        APair ap[2];
+        if constexpr (AP) ap[0] = apair_load(cur, 0, lane);
+        int g = 0;                                                        // (a compile-time value after unrolling)
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {                                  // tap order 0, 2, 1 (see conv_mel_lds)
             const int tap = ti == 0 ? 0 : (ti == 1 ? 2 : 1);
@@ -562,8 +613,21 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
             for (int ks = 0; ks < KSF + (ti == 2 ? NMK : 0); ++ks) {
                 const int mk = ks < KSF ? 0 : ks - KSF;
                 const int blk = ks < KSF ? (tap * KSF + ks) * 2 : (3 * KSF + mk) * 2;
-                const f16x8 ah = lds_h(cur, blk + 0, lane);
-                const f16x8 al = lds_h(cur, blk + 1, lane);
+                f16x8 ah, al;
+                if constexpr (AP) {
+                    // next group in issue order: the next k-step of this tap, else k-step 0 of the next tap (2 after 0, 1 after 2);
+                    // behind the centre tap's full k-steps come its NMK merged ones
+                    const int nsteps = KSF + (ti == 2 ? NMK : 0);
+                    int nblk = -1;
+                    if (ks + 1 < nsteps) nblk = ks + 1 < KSF ? (tap * KSF + ks + 1) * 2 : (3 * KSF + (ks + 1 - KSF)) * 2;
+                    else if (ti < 2) nblk = KSF > 0 ? ((ti == 0 ? 2 : 1) * KSF) * 2 : (3 * KSF) * 2;
+                    apipe_step(ap[g & 1], ap[(g + 1) & 1], cur, nblk, lane);
+                    ah = ap[g & 1].h; al = ap[g & 1].l;
+                    ++g;
+                } else {
+                    ah = lds_h(cur, blk + 0, lane);
+                    al = lds_h(cur, blk + 1, lane);
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = OWH_MFMA(ah, ks < KSF ? in[t][ks].h : M[t][mk].h, acc[t]);
 #pragma unroll
@@ -609,7 +673,7 @@ __device__ __forceinline__ void conv_mel_hxm(const Op (&in)[NT][KSI], const Op (
 #ifndef OWH_PIPE_M
 #define OWH_PIPE_M 0       // the same interleave hint in the K-merged time layers (stage C): same-box A/B 1.555 -> 1.525 ms WITHOUT it
 #endif
-template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0, bool REM2 = false, int NS = 2>
+template <int KSI, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool GUARD = true, bool HOUT = false, bool PIPE = OWH_PIPE != 0, bool REM2 = false, int NS = 2, bool AP = false>
 __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)[KSI], const Op (&in)[NR][KSI], f32x4 (&out)[NR][NCTO],
                                              const WRing<NS>& ring, const float* __restrict__ w, const float* __restrict__ w_next,
                                              const float* __restrict__ init, float cl, int wave, int lane,
@@ -626,12 +690,21 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);           // folded BatchNorm shift = the chain's start value
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = I;
+            APair ap[2];
+            if constexpr (AP) ap[0] = apair_load(cur, 0, lane);
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
                 for (int ks = 0; ks < KSI; ++ks) {
-                    const f16x8 ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
-                    const f16x8 al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                    f16x8 ah, al;
+                    if constexpr (AP) {
+                        const int g = tap * KSI + ks;
+                        apipe_step(ap[g & 1], ap[(g + 1) & 1], cur, g + 1 < 3 * KSI ? (g + 1) * 2 : -1, lane);
+                        ah = ap[g & 1].h; al = ap[g & 1].l;
+                    } else {
+                        ah = lds_h(cur, (tap * KSI + ks) * 2 + 0, lane);
+                        al = lds_h(cur, (tap * KSI + ks) * 2 + 1, lane);
+                    }
                     const bool rem = REM2 && ks == KSI - 1;       // two MFMAs: (wh | wh) x (xh | xl), (wl | 0) x (xh | 0)
 #pragma unroll
                     for (int part = 0; part < (rem ? 2 : 3); ++part)
@@ -656,7 +729,7 @@ __device__ __forceinline__ void conv_time_hx(const Op (&h0)[KSI], const Op (&h1)
                 else { out[r][oct - 1] = act_t<BN, false>(prev[r], cl); pin_t<false>(out[r][oct - 1]); }
             }
         }
-        if (PIPE && oct > 0 && oct < NCTO) {
+        if (PIPE && !AP && oct > 0 && oct < NCTO) {                // (the A-operand pipeline's scheduling barriers fix the order themselves)
 #pragma unroll
             for (int i = 0; i < (9 * KSI - (REM2 ? 3 : 0)) * NR; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -731,7 +804,7 @@ __device__ __forceinline__ void merge_rems(const RemPairs (&rem)[NR + 2], Op (&M
     }
 }
 
-template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, int NS = 2>
+template <int KSF, int NMK, int NCTO, int NR, bool BN, int CH0, int NEXT_NBLK, int WG = OWH_WG, bool HOUT = false, int NS = 2, bool AP = false>
 __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1)[KSF], const Op (&in)[NR][KSF], const Op (&M)[NR][NMK],
                                               f32x4 (&out)[NR][NCTO], const WRing<NS>& ring, const float* __restrict__ w, const float* __restrict__ w_next,
                                               const float* __restrict__ init, float cl, int wave, int lane,
@@ -748,12 +821,21 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
             const f32x4 I = acc_init(BN ? init : nullptr, oct, j);
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] = I;
+            APair ap[2];
+            if constexpr (AP) ap[0] = apair_load(cur, 0, lane);  // groups in block order: 3 KSF full k-steps, then NMK merged ones
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
                 for (int ks = 0; ks < KSF; ++ks) {
-                    const f16x8 ah = lds_h(cur, (tap * KSF + ks) * 2 + 0, lane);
-                    const f16x8 al = lds_h(cur, (tap * KSF + ks) * 2 + 1, lane);
+                    f16x8 ah, al;
+                    if constexpr (AP) {
+                        const int g = tap * KSF + ks;
+                        apipe_step(ap[g & 1], ap[(g + 1) & 1], cur, g + 1 < 3 * KSF + NMK ? (g + 1) * 2 : -1, lane);
+                        ah = ap[g & 1].h; al = ap[g & 1].l;
+                    } else {
+                        ah = lds_h(cur, (tap * KSF + ks) * 2 + 0, lane);
+                        al = lds_h(cur, (tap * KSF + ks) * 2 + 1, lane);
+                    }
 #pragma unroll
                     for (int part = 0; part < 3; ++part)
 #pragma unroll
@@ -766,8 +848,15 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
                 }
 #pragma unroll
             for (int mk = 0; mk < NMK; ++mk) {
-                const f16x8 ah = lds_h(cur, (3 * KSF + mk) * 2 + 0, lane);
-                const f16x8 al = lds_h(cur, (3 * KSF + mk) * 2 + 1, lane);
+                f16x8 ah, al;
+                if constexpr (AP) {
+                    const int g = 3 * KSF + mk;
+                    apipe_step(ap[g & 1], ap[(g + 1) & 1], cur, g + 1 < 3 * KSF + NMK ? (g + 1) * 2 : -1, lane);
+                    ah = ap[g & 1].h; al = ap[g & 1].l;
+                } else {
+                    ah = lds_h(cur, (3 * KSF + mk) * 2 + 0, lane);
+                    al = lds_h(cur, (3 * KSF + mk) * 2 + 1, lane);
+                }
 #pragma unroll
                 for (int part = 0; part < 3; ++part)
 #pragma unroll
@@ -849,6 +938,8 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
     constexpr bool MERGE = OWH_KMERGE && (NCT % 2 == 1) && !LAST && (C::HOUT || OWH_KMERGE_B);   // time layers in the K-merged form
     constexpr int NBT = MERGE ? TK::NBLK : NB;                       // blocks per chunk of the 3x1 layers
     constexpr bool PIPE = OWH_PIPE != 0;
+    constexpr int APCFG = NCT == 3 ? OWH_APIPE_B : NCT == 5 ? OWH_APIPE_C : LAST ? OWH_APIPE_E : OWH_APIPE_D;
+    constexpr bool APM = (APCFG & 1) != 0, APT = (APCFG & 2) != 0;       // A operands one k-group ahead (apipe_step): mel / time layers
     // a full odd last channel tile (stage B: 48 = 32 + 16) in the two-MFMA remainder form of split_dup
     constexpr bool REM2 = OWH_REM2 && NCT % 2 == 1 && !C::HOUT && !LAST && !(OWH_KMERGE && OWH_KMERGE_B) && !(OWH_KMERGE_MEL && OWH_KMERGE_MEL2B);
     // 1x3 layers whose 72-channel input leaves a half remainder tile, in the K-merged form (conv_mel_hxm): layer a of stage D, c of C
@@ -919,9 +1010,9 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
     if constexpr (MMA) {
         Op Mx[R][NMKA];
         merge_mel_rems<KSA, R, F, NPRA>(Xo, Mx);
-        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT, NS>(Xo, Mx, Y, ring, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
+        conv_mel_hxm<KSA, NMKA, NCT, R, F, true, 0, NBT, WG, C::HOUT, NS, APM>(Xo, Mx, Y, ring, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
     } else
-    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT, false, NS>(Xo, Y, ring, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
+    conv_mel_hx<KSA, NCT, R, F, true, 0, NBT, WG, C::HOUT, false, NS, APM>(Xo, Y, ring, p.w[0], p.w[1], sbn[0], p.clampv[0], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane, p.dbg_mul[0]);
@@ -947,7 +1038,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT, NS>(H0F, H1F, AoF, M, Y, ring, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, NCT, NBCM, WG, C::HOUT, NS, APT>(H0F, H1F, AoF, M, Y, ring, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -965,7 +1056,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv b: 3x1 over [hist_b(2) ; Ya]
-    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2, NS>(H0, H1, Ao, Y, ring, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, NCT, NBCM, WG, true, C::HOUT, PIPE, REM2, NS, APT>(H0, H1, Ao, Y, ring, p.w[1], p.w[2], sbn[1], p.clampv[1], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -978,9 +1069,9 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
     if constexpr (MMC) {
         Op Mc[R][NMKC];
         merge_mel_rems<KS, R, F, NPRC>(Ao, Mc);
-        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, NS>(Ao, Mc, Y, ring, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
+        conv_mel_hxm<KS, NMKC, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, NS, APM>(Ao, Mc, Y, ring, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     } else
-    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2, NS>(Ao, Y, ring, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
+    conv_mel_hx<KS, NCT, R, F, true, 2 * NCT, NBT, WG, C::HOUT, REM2, NS, APM>(Ao, Y, ring, p.w[2], p.w[3], sbn[2], p.clampv[2], wave, lane, bad);
     if (DBG && p.dbg && active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
@@ -1004,7 +1095,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
         for (int r = 0; r < R; ++r) to_ops_time<NCT, C::HOUT>(Y[r], AoF[r], rem[2 + r]);
         merge_rems<R, TK::NPR, TK::NMK>(rem, M);
         __builtin_amdgcn_sched_barrier(0);
-        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT, NS>(H0F, H1F, AoF, M, Y, ring, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
+        conv_time_hxm<TK::KSF, TK::NMK, NCT, R, true, 3 * NCT, (C::NPASS > 1 ? NBAM : 0), WG, C::HOUT, NS, APT>(H0F, H1F, AoF, M, Y, ring, p.w[3], p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     } else {
     {
         f32x4 T0[NCT], T1[NCT];
@@ -1021,7 +1112,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
     // conv d: 3x1 over [hist_d(2) ; Yc]
-    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2, NS>(H0, H1, Ao, Y, ring, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
+    conv_time_hx<KS, NCT, R, true, 3 * NCT, (LAST ? NB : (C::NPASS > 1 ? NBAM : 0)), WG, true, C::HOUT, PIPE, REM2, NS, APT>(H0, H1, Ao, Y, ring, p.w[3], LAST ? p.w19 : p.w[0], sbn[3], p.clampv[3], wave, lane, bad);
     }
     if (DBG && p.dbg && active) {
 #pragma unroll
@@ -1735,6 +1826,9 @@ __device__ __forceinline__ void heads_wide_tail(const HeadHxParams& p, f32x4 (&a
 #ifndef OWH_HEADS_NBUF
 #define OWH_HEADS_NBUF 2
 #endif
+#ifndef OWH_HEADS_APIPE
+#define OWH_HEADS_APIPE 1      // A operands one pair of hidden tiles ahead of their MFMAs: heads launch 0.374 -> 0.340 ms (profiles/r06_apipe_ab.txt)
+#endif
 constexpr int HX_WG = OWH_HEADS_WG, HX_NBUF = OWH_HEADS_NBUF;
 // NBUF = slots of the weight ring in LDS (and of the feature ring in registers); D = NBUF - 1 k-steps are in flight ahead of the one
 // being consumed: the weight chunk of k-step i + D (L2 -> LDS, global_load_lds) and, issued right AFTER it, the feature rows of the
@@ -1831,6 +1925,32 @@ __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(H
             asm volatile("" ::: "memory");
             load_raw(ks + D, raw[un]);
         }
+#if OWH_HEADS_APIPE
+        // A operands (four 1 KB weight blocks per pair of hidden tiles) one pair AHEAD of the MFMAs that consume them: left alone the
+        // compiler issues a pair's four ds_read_b128 next to the last MFMA of the pair before and waits lgkmcnt(0) in front of the next
+        // twelve -- ~100 cycles of LDS latency in the open per 192 MFMA cycles.  LDS reads return in order, so the wait in front of a
+        // pair is lgkmcnt(4): its own reads done, the next pair's in flight.  Same MFMAs in the same order: bit-identical.
+        f16x8 A[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) A[0][b] = lds_h(cur, b, lane);
+#pragma unroll
+        for (int c2 = 0; c2 < NCT; c2 += 2) {
+            const int pc = (c2 / 2) & 1;
+            if (c2 + 2 < NCT) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) A[pc ^ 1][b] = lds_h(cur, (c2 + 2) * 2 + b, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // (the reads stay in front of this pair's MFMAs)
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[c2][t] = OWH_MFMA(part == 2 ? A[pc][1] : A[pc][0], part == 1 ? bcur[t].l : bcur[t].h, acc[c2][t]);
+                    acc[c2 + 1][t] = OWH_MFMA(part == 2 ? A[pc][3] : A[pc][2], part == 1 ? bcur[t].l : bcur[t].h, acc[c2 + 1][t]);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int c2 = 0; c2 < NCT; c2 += 2) {
             const f16x8 ah0 = lds_h(cur, c2 * 2 + 0, lane), al0 = lds_h(cur, c2 * 2 + 1, lane);
@@ -1844,6 +1964,7 @@ __global__ __launch_bounds__(64 * WG, (NBUF > 2 ? 1 : 2)) void heads_hx_kernel(H
                 }
             }
         }
+#endif
         if (ALWAYS || ks + 1 < KST) {
             // k-step ks+1: its features are younger than its weight chunk, so the split's wait covers this wave's part of the chunk;
             // the barrier covers the other waves' parts.  Everything issued for k-steps ks+2 .. ks+D stays in flight.
