@@ -323,3 +323,16 @@ def test_speex_hook_of_the_host_shim_matches_the_reference_with_the_same_stand_i
         np.testing.assert_allclose(ref[f"{cid}/vad"], ref["fvad20/vad"], rtol=0, atol=0)        # (the reference's VAD ring with and without Speex: same clip)
     assert np.abs(ref[f"{cid}/scores"] - (ref["f1280/scores"] if cid == "fspeex" else 0)).max() > 0.05    # the filter matters
     m.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequences_through_the_host_shim_match_the_oracle_model(stub, seed):
+    """tools/fuzz_model_vs_oracle.py with the host shim served by the oracle engine: the shim's alignment / carry-over, multi-chunk
+    maxima, first-five zeroing, patience / debounce and reset must reproduce OracleModel (model.py:232-386 restated) EXACTLY."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_model_vs_oracle", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_model_vs_oracle.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rec = fz.one_seed(seed)
+    assert rec["worst"] == 0.0 and rec["borderline"] == 0 and rec["scores"] > 0

@@ -874,3 +874,18 @@ def test_hip_model_with_speex_matches_the_reference_with_the_same_stand_in(tmp_p
             np.testing.assert_allclose(np.array(m.vad.prediction_buffer), ref[f"{cid}/vad"], rtol=0, atol=1e-6)
     finally:
         m.close()
+
+
+@gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13, 21, 34])
+def test_random_call_sequences_match_the_oracle_model(seed):
+    """tools/fuzz_model_vs_oracle.py: Model.predict on the HIP library against OracleModel over random call sequences (calls of
+    0 ... 6000 samples, silence ... full scale, random head sets, patience / debounce, calls longer than max_chunks, a reset in
+    mid-sequence); 150 seeds of it ran clean on the GPU in round 6 (profiles/r06_fuzz_model_vs_oracle.txt)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_model_vs_oracle", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_model_vs_oracle.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rec = fz.one_seed(seed)
+    assert rec["worst"] <= fz.TOL and rec["scores"] > 0
