@@ -200,6 +200,35 @@ def test_mel_stage_matches_an_independent_stft(golden):
     np.testing.assert_allclose(O.mel_stage(x[None], np.float32)[0, 0], db, rtol=0, atol=2e-3)     # fp32 DFT of int16-scale audio
 
 
+def test_mel_recipe_matches_a_third_party_port_of_librosa(golden):
+    """The [3P] part of the mel front end -- librosa's Slaney mel scale with slaney area normalisation, its periodic Hann window,
+    power_to_db with amin 1e-10 / ref 1 / top_db 80 (what torchlibrosa's Spectrogram + LogmelFilterBank compute in the notebook's
+    cell 15) -- against code that is neither the builder's nor the reference's: Hugging Face `transformers.audio_utils`
+    (`mel_filter_bank(..., norm="slaney", mel_scale="slaney")`, `window_function`, `spectrogram(..., log_mel="dB", db_range=80)`),
+    that library's own port of librosa's recipe.  Filter bank and window agree to float64 round-off (229 non-zero taps, FFT bins
+    2 ... 121), the whole log-mel of real audio to 1e-6 dB."""
+    au = pytest.importorskip("transformers.audio_utils")
+    fb = au.mel_filter_bank(257, 32, 60.0, 3800.0, 16000, norm="slaney", mel_scale="slaney")
+    np.testing.assert_allclose(O.mel_filterbank(np.float64), fb, rtol=0, atol=1e-15)
+    assert int((fb != 0).sum()) == 229 and list(np.nonzero(fb.sum(1))[0][[0, -1]]) == [2, 121]       # SURVEY Appendix A
+    win = np.zeros(512)
+    win[56:456] = au.window_function(400, "hann", periodic=True)
+    np.testing.assert_allclose(O.hann_window_padded(np.float64), win, rtol=0, atol=1e-15)
+    for name in ("alexa_test", "hey_mycroft_test", "hey_jane"):
+        clip = golden["pcm/" + name].astype(np.float64)
+        x = clip[len(clip) // 3: len(clip) // 3 + 1280 * 3 + 480]
+        want = au.spectrogram(x, win, frame_length=512, hop_length=160, fft_length=512, power=2.0, center=False, mel_filters=fb,
+                              mel_floor=1e-10, log_mel="dB", reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64).T
+        got = O.mel_stage(x[None], np.float64)[0, 0]
+        assert got.shape == want.shape == ((len(x) - 512) // 160 + 1, 32)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    # digital silence: every band at amin -> -100 dB, i.e. mel = -8 after the host transform (SURVEY Appendix A step 6)
+    z = au.spectrogram(np.zeros(1760), win, frame_length=512, hop_length=160, fft_length=512, power=2.0, center=False, mel_filters=fb,
+                       mel_floor=1e-10, log_mel="dB", reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64).T
+    np.testing.assert_allclose(O.mel_stage(np.zeros((1, 1760)), np.float64)[0, 0], z, rtol=0, atol=0)
+    assert float(O.mel_transform(z).max()) == -8.0
+
+
 def test_cnn_and_head_stages_match_torch_nn_in_float64():
     """The oracle's embedding CNN and head restatements against an independent implementation of the same published architecture:
     torch.nn.Conv2d / BatchNorm2d(eps 1e-3) / leaky_relu(0.2) + clamp(-0.4) / MaxPool2d in NCHW, and nn.Linear / LayerNorm / ReLU /
