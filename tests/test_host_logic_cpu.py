@@ -336,3 +336,6 @@ def test_random_call_sequences_through_the_host_shim_match_the_oracle_model(stub
     spec.loader.exec_module(fz)
     rec = fz.one_seed(seed)
     assert rec["worst"] == 0.0 and rec["borderline"] == 0 and rec["scores"] > 0
+    if seed == 1:          # and one long sequence with the debounce rule (the reference's ZeroDivisionError on frame-less calls included)
+        rec = fz.one_seed(5, 300, [1280, 1280, 1280, 1280, 640, 2560, 1000, 0])
+        assert rec["worst"] == 0.0 and rec["raised"] > 0

@@ -889,3 +889,6 @@ def test_random_call_sequences_match_the_oracle_model(seed):
     spec.loader.exec_module(fz)
     rec = fz.one_seed(seed)
     assert rec["worst"] <= fz.TOL and rec["scores"] > 0
+    if seed == 1:          # one LONG sequence: 320 calls, every device ring (features 120, mel 970 rows, scores 30, VAD 125) wraps
+        rec = fz.one_seed(2003, 320, [1280, 1280, 1280, 1280, 640, 2560, 1000, 0])
+        assert rec["worst"] <= fz.TOL and rec["scores"] > 1000
