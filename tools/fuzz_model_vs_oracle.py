@@ -39,9 +39,9 @@ def one_seed(seed: int, n_calls: int = 0, sizes=None) -> dict:
     mode = int(r.integers(0, 3))                     # 0 plain, 1 patience, 2 debounce
     kw = {}
     if mode == 1:
-        kw = dict(patience={n: int(r.integers(1, 4)) for n in names}, threshold={n: float(r.choice([0.1, 0.3, 0.5])) for n in names})
+        kw = dict(patience={n: int(r.integers(1, 4)) for n in names}, threshold={n: float(r.choice([1e-4, 0.003, 0.03, 0.1, 0.3, 0.5])) for n in names})
     elif mode == 2:
-        kw = dict(debounce_time=float(r.choice([0.25, 1.0])), threshold={n: float(r.choice([0.1, 0.3, 0.5])) for n in names})
+        kw = dict(debounce_time=float(r.choice([0.25, 1.0])), threshold={n: float(r.choice([1e-4, 0.003, 0.03, 0.1, 0.3, 0.5])) for n in names})
     vad_thr = float(r.choice([0.0, 0.0, 0.3, 0.6]))     # > 0: the VAD gate (model.py:366-381) with the same pseudo network either side
     vkw_h, vkw_o = {}, {}
     if vad_thr > 0:
