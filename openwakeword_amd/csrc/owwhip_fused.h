@@ -27,6 +27,19 @@ using owr::f32x4;
 #ifndef OWF_COMPACT_TAPS
 #define OWF_COMPACT_TAPS 1 // the sparse mel taps read conflict-free compact power tables (0: the plain power rows, three bins per bank)
 #endif
+// Wave priority by phase.  The three waves of a SIMD run the same program on equal shares of the streams, and left alone they stay in step:
+// three log-mel phases compete for VALU issue, then three matrix phases for the matrix pipe.  `s_setprio` around the matrix phase takes them
+// apart -- a wave in its matrix phase wins VALU arbitration (its dependent epilogues keep the MFMAs coming), the others' butterflies fill the
+// gaps -- and they stay apart: front-end launch -4.8 ... -5.4 % on three boxes, the step -1.0 ... -1.5 %, bit-identical
+// (profiles/r06_prio_ab.txt).  The level does not matter (1, 2, 3), the inverse (2) and a rotation of three levels by stream (4) do the same
+// within 1 %; three STATIC levels do nothing (3, removed), and drawing streams from a ticket counter instead of the static partition is
+// slower (+3 %: the waves were never unequal, only in step).  0 = off.
+#ifndef OWF_PRIO
+#define OWF_PRIO 1
+#endif
+#ifndef OWF_PRIO_HI
+#define OWF_PRIO_HI 2
+#endif
 #ifndef OWF_WG
 #define OWF_WG 12          // waves per workgroup (one workgroup per CU: 3 waves per SIMD)
 #endif
@@ -127,6 +140,14 @@ __global__ __launch_bounds__(64 * FA_WG, (FA_WG + 3) / 4) void hmelA_kernel(MelA
         // strength-reduced 64-bit per-lane pointers that would stay alive (and spill) across the whole loop body
         int s = __builtin_amdgcn_readfirstlane(s0 + q.a.s_base);
         asm volatile("" : "+s"(s));
+#if OWF_PRIO == 4
+        {   // (variant: the three waves of a SIMD take turns at the top priority, one stream each)
+            const int turn = __builtin_amdgcn_readfirstlane(((s0 - gw) / nw + (wave >> 2)) % 3);
+            if (turn == 0) __builtin_amdgcn_s_setprio(0);
+            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+#endif
         if (q.a.stream_on && !q.a.stream_on[s]) continue;        // masked step (oww_step_masked): no sample is consumed, no state touched
 
         // an opaque zero added to every LDS base of the mel phase: its per-lane addresses are then recomputed in each iteration
@@ -270,7 +291,17 @@ __global__ __launch_bounds__(64 * FA_WG, (FA_WG + 3) / 4) void hmelA_kernel(MelA
                            *reinterpret_cast<const int4*>(q.pcm + (size_t)s * 1280 + 800 + lane * 8);
         wave_sync();
         __builtin_amdgcn_sched_barrier(0);       // the mel phase ends here: none of its values stays live into stage A
+#if OWF_PRIO == 1
+        __builtin_amdgcn_s_setprio(OWF_PRIO_HI); // the matrix phase outranks the other waves' log-mel phases on this SIMD
+#elif OWF_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         owh::hstageA_stream<DBG, true>(q.a, s, sP, sW0, sW1, sW2, sbn, gtab, bad, lane_all);
+#if OWF_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif OWF_PRIO == 2
+        __builtin_amdgcn_s_setprio(OWF_PRIO_HI); // (variant, inverse: the log-mel phase outranks)
+#endif
         if (bad) { owh::raise_range_flag(bad, q.a.range_flag, s, 1); bad = 0; }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -903,6 +903,29 @@ __device__ __forceinline__ void conv_time_hxm(const Op (&h0)[KSF], const Op (&h1
 #ifndef OWH_HIST_LDS_C
 #define OWH_HIST_LDS_C 0       // stage C too: measured +1.5 % on C (same box: 1.496 -> 1.520 ms) against -2.5 % on B (1.378 -> 1.345)
 #endif
+// Wave priority by layer inside the stage kernels (s_setprio; profiles/r06_prio_ab.txt).  A code of four digits = the levels of conv a, b, c, d
+// (0 = off; the prologue's loads and the pooled store run at level 0).  The two or three workgroups of a CU are at different layers at any
+// time; with FALLING levels (3210) a workgroup that has just started -- the youngest wave of its SIMD, served last by the age-ordered arbiter
+// -- gets through its first layers ahead of the others and the SIMD's waves spread over the layers instead of bunching behind the oldest.
+// Same-box alternating runs, bit-identical: C -1 %, D -2 % with 3210; B -0.6 %, E -1 % with one level above the load / store phases (1111);
+// falling levels in B cost it +9 %, a high prologue costs everywhere.  Together -0.4 % of the step (5.59-5.61 -> 5.57-5.58 ms).
+#ifndef OWH_SPRIO_B
+#define OWH_SPRIO_B 1111
+#endif
+#ifndef OWH_SPRIO_C
+#define OWH_SPRIO_C 3210
+#endif
+#ifndef OWH_SPRIO_D
+#define OWH_SPRIO_D 3210
+#endif
+#ifndef OWH_SPRIO_E
+#define OWH_SPRIO_E 1111
+#endif
+template <int CODE, int LAYER> __device__ __forceinline__ void sprio() {
+    constexpr int div = LAYER == 0 ? 1000 : LAYER == 1 ? 100 : LAYER == 2 ? 10 : 1;
+    if constexpr (CODE != 0 && LAYER >= 0) __builtin_amdgcn_s_setprio((CODE / div) % 10);
+    if constexpr (CODE != 0 && LAYER < 0) __builtin_amdgcn_s_setprio(0);
+}
 // NBLK KB of a wave's own history block, HBM -> LDS (linear image: register-dump rows of 256 B, four rows per DMA instruction)
 template <int NBLK>
 __device__ __forceinline__ void issue_hist(const float* __restrict__ gsrc, float* ldst, int lane) {
@@ -940,6 +963,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
     constexpr bool PIPE = OWH_PIPE != 0;
     constexpr int APCFG = NCT == 3 ? OWH_APIPE_B : NCT == 5 ? OWH_APIPE_C : LAST ? OWH_APIPE_E : OWH_APIPE_D;
     constexpr bool APM = (APCFG & 1) != 0, APT = (APCFG & 2) != 0;       // A operands one k-group ahead (apipe_step): mel / time layers
+    constexpr int SPCODE = NCT == 3 ? OWH_SPRIO_B : NCT == 5 ? OWH_SPRIO_C : LAST ? OWH_SPRIO_E : OWH_SPRIO_D;   // wave priority by layer (sprio)
     // a full odd last channel tile (stage B: 48 = 32 + 16) in the two-MFMA remainder form of split_dup
     constexpr bool REM2 = OWH_REM2 && NCT % 2 == 1 && !C::HOUT && !LAST && !(OWH_KMERGE && OWH_KMERGE_B) && !(OWH_KMERGE_MEL && OWH_KMERGE_MEL2B);
     // 1x3 layers whose 72-channel input leaves a half remainder tile, in the K-merged form (conv_mel_hxm): layer a of stage D, c of C
@@ -1005,6 +1029,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
         to_ops<NCTI, C::HIN>(X, Xo[r]);
     }
     if (pass == 0) chunk_sync();
+    sprio<SPCODE, 0>();
 
     // conv a: 1x3, CIN -> C
     if constexpr (MMA) {
@@ -1018,6 +1043,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[0], s_first, pass * R + r, p.S, lane, p.dbg_mul[0]);
     }
     Op Ao[R][KS], H0[KS], H1[KS];
+    sprio<SPCODE, 1>();
     if constexpr (MERGE) {
         // conv b: 3x1 over [hist_b(2) ; Ya], K-merged form
         Op AoF[R][TK::KSF], H0F[TK::KSF], H1F[TK::KSF], M[R][TK::NMK];
@@ -1065,6 +1091,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
 #pragma unroll
     for (int r = 0; r < R; ++r) to_ops<NCT, C::HOUT, REM2>(Y[r], Ao[r]);
     __builtin_amdgcn_sched_barrier(0);
+    sprio<SPCODE, 2>();
     // conv c: 1x3
     if constexpr (MMC) {
         Op Mc[R][NMKC];
@@ -1076,6 +1103,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
 #pragma unroll
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[2], s_first, pass * R + r, p.S, lane, p.dbg_mul[2]);
     }
+    sprio<SPCODE, 3>();
     if constexpr (MERGE) {
         // conv d: 3x1 over [hist_d(2) ; Yc], K-merged form
         Op AoF[R][TK::KSF], H0F[TK::KSF], H1F[TK::KSF], M[R][TK::NMK];
@@ -1119,6 +1147,7 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
         for (int r = 0; r < R; ++r) dump_tile_ht<NCT, F, C::C>(Y[r], p.dbg, p.dbg_stride, p.dbg_off[3], s_first, pass * R + r, p.S, lane, p.dbg_mul[3]);
     }
 
+    sprio<SPCODE, -1>();
     if (!LAST && lane_on) {
         constexpr int FO = C::FO, RO = C::RO;
         constexpr int SPTN = 16 / FO;
