@@ -27,18 +27,22 @@ using owr::f32x4;
 #ifndef OWF_COMPACT_TAPS
 #define OWF_COMPACT_TAPS 1 // the sparse mel taps read conflict-free compact power tables (0: the plain power rows, three bins per bank)
 #endif
-// Wave priority by phase.  The three waves of a SIMD run the same program on equal shares of the streams, and left alone they stay in step:
-// three log-mel phases compete for VALU issue, then three matrix phases for the matrix pipe.  `s_setprio` around the matrix phase takes them
-// apart -- a wave in its matrix phase wins VALU arbitration (its dependent epilogues keep the MFMAs coming), the others' butterflies fill the
-// gaps -- and they stay apart: front-end launch -4.8 ... -5.4 % on three boxes, the step -1.0 ... -1.5 %, bit-identical
-// (profiles/r06_prio_ab.txt).  The level does not matter (1, 2, 3), the inverse (2) and a rotation of three levels by stream (4) do the same
-// within 1 %; three STATIC levels do nothing (3, removed), and drawing streams from a ticket counter instead of the static partition is
-// slower (+3 %: the waves were never unequal, only in step).  0 = off.
+// Wave priority by progress.  The three waves of a SIMD run the same program on equal shares of the streams, and left alone they stay in step:
+// three log-mel phases compete for VALU issue, then three matrix phases for the matrix pipe.  `s_setprio` takes them apart and keeps them
+// apart.  Default (6): the level RISES with the stream-step's progress -- FFT passes 0, 0, 1, 1 (OWF_MPRIO), row pairs of the matrix phase
+// 2, 2, 3, 3 (OWF_QPRIO, owwhip_hx.h) -- so the wave nearest to handing its stream over wins VALU arbitration (its dependent epilogues keep
+// the MFMAs coming) and the others' butterflies fill the gaps: front-end launch -9 ... -10 % against no priorities (1.55 -> 1.40 ms class),
+// the step -2.5 ... -3 %, bit-identical (profiles/r06_prio_ab.txt).  Flat forms: 1 = one level for the whole matrix phase (-5 %), 2 = the
+// inverse (-4 %), 4 = three levels rotating by stream (-5 %); three STATIC levels do nothing, and drawing streams from a ticket counter
+// instead of the static partition is slower (+3 %: the waves were never unequal, only in step).  0 = off.
 #ifndef OWF_PRIO
-#define OWF_PRIO 1
+#define OWF_PRIO 6
 #endif
 #ifndef OWF_PRIO_HI
 #define OWF_PRIO_HI 2
+#endif
+#ifndef OWF_MPRIO
+#define OWF_MPRIO 11       // levels of FFT passes 0..3 as digits (0011)
 #endif
 #ifndef OWF_WG
 #define OWF_WG 12          // waves per workgroup (one workgroup per CU: 3 waves per SIMD)
@@ -179,6 +183,15 @@ __global__ __launch_bounds__(64 * FA_WG, (FA_WG + 3) / 4) void hmelA_kernel(MelA
         fetch_pass(tail_row, pcm_row, 0, lane, raw);
 #pragma unroll
         for (int f2 = 0; f2 < 4; ++f2) {
+#if OWF_PRIO == 6
+            {   // the level rises with the stream-step's progress: FFT passes here, row pairs of the matrix phase in hstageA_stream
+                constexpr int code = OWF_MPRIO;
+                if (f2 == 0) __builtin_amdgcn_s_setprio((code / 1000) % 10);
+                else if (f2 == 1) __builtin_amdgcn_s_setprio((code / 100) % 10);
+                else if (f2 == 2) __builtin_amdgcn_s_setprio((code / 10) % 10);
+                else __builtin_amdgcn_s_setprio(code % 10);
+            }
+#endif
             wave_sync();                         // the previous pass's readers of the planes / power rows are done (same wave)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

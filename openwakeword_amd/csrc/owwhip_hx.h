@@ -1247,6 +1247,14 @@ __global__ __launch_bounds__(64 * WG, (DBG || NS > 3 ? 1 : (NS == 3 && C::WPS > 
 // The conv1 outputs of the last two rows (conv2's history) and the last two mel rows live in HBM in operand form -- (hi, lo) f16
 // pairs, the same 4 bytes per value as fp32 -- so nothing is split again when a step starts.
 // ------------------------------------------------------------------------------------------------
+// levels of the four row pairs of the fused front end's matrix phase (see owwhip_fused.h: OWF_PRIO 6; 0 = leave the priority alone)
+#ifndef OWF_QPRIO
+#if !defined(OWF_PRIO) || OWF_PRIO == 6
+#define OWF_QPRIO 2233
+#else
+#define OWF_QPRIO 0
+#endif
+#endif
 namespace sa {
 constexpr int RS = 34;                 // halves per mel row in a plane: 32 bins + a zero column either side
 constexpr int PLANE = 344;             // 10 rows (2 history + 8 new) x 34, rounded up to a multiple of 8 halves
@@ -1336,6 +1344,13 @@ __device__ __forceinline__ void hstageA_stream(const owr::RAParams& p, int s, _F
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                 // conv rows 2q, 2q+1; tile t = 2 * (row & 1) + parity
         OWR_SB();
+        if (MEL_IN_LDS && OWF_QPRIO != 0) {       // the fused front end's wave priority rises with the stream-step's progress (owwhip_fused.h: OWF_PRIO)
+            constexpr int code = OWF_QPRIO;
+            if (q == 0) __builtin_amdgcn_s_setprio((code / 1000) % 10);
+            else if (q == 1) __builtin_amdgcn_s_setprio((code / 100) % 10);
+            else if (q == 2) __builtin_amdgcn_s_setprio((code / 10) % 10);
+            else __builtin_amdgcn_s_setprio(code % 10);
+        }
         // ---- conv0: one K-folded MFMA per output tile
         Op Y0o[4][1];
         {
