@@ -27,14 +27,17 @@ using owr::f32x4;
 #ifndef OWF_COMPACT_TAPS
 #define OWF_COMPACT_TAPS 1 // the sparse mel taps read conflict-free compact power tables (0: the plain power rows, three bins per bank)
 #endif
-// Wave priority by progress.  The three waves of a SIMD run the same program on equal shares of the streams, and left alone they stay in step:
-// three log-mel phases compete for VALU issue, then three matrix phases for the matrix pipe.  `s_setprio` takes them apart and keeps them
-// apart.  Default (6): the level RISES with the stream-step's progress -- FFT passes 0, 0, 1, 1 (OWF_MPRIO), row pairs of the matrix phase
-// 2, 2, 3, 3 (OWF_QPRIO, owwhip_hx.h) -- so the wave nearest to handing its stream over wins VALU arbitration (its dependent epilogues keep
-// the MFMAs coming) and the others' butterflies fill the gaps: front-end launch -9 ... -10 % against no priorities (1.55 -> 1.40 ms class),
-// the step -2.5 ... -3 %, bit-identical (profiles/r06_prio_ab.txt).  Flat forms: 1 = one level for the whole matrix phase (-5 %), 2 = the
-// inverse (-4 %), 4 = three levels rotating by stream (-5 %); three STATIC levels do nothing, and drawing streams from a ticket counter
-// instead of the static partition is slower (+3 %: the waves were never unequal, only in step).  0 = off.
+// Wave priority by progress.  The three waves of a SIMD run the same program on equal shares of the streams, but the SIMD's arbiter serves the
+// oldest wave first -- for the whole life of this persistent launch.  Left alone, the favoured wave finishes its share early and the launch
+// ends on the youngest wave's tail (PMC: the launch's cycles fall by 11 % with the priorities at an unchanged sum of wave cycles and unchanged
+// instruction counts).  Default (6): the level RISES with the stream-step's progress -- FFT passes 0, 0, 1, 1 (OWF_MPRIO), row pairs of the
+// matrix phase 2, 2, 3, 3 (OWF_QPRIO, owwhip_hx.h) -- so no wave is the favourite for long, and the wave nearest to handing its stream over
+// wins VALU arbitration (its dependent epilogues keep the MFMAs coming) while the others' butterflies fill the gaps: front-end launch -10 %
+// against no priorities (1.54-1.57 -> 1.38-1.41 ms), the step -2 ... -2.6 %, bit-identical (profiles/r06_prio_ab.txt).  Flat forms: 1 = one
+// level for the whole matrix phase (-5 %), 2 = the inverse (-4 %), 4 = three levels rotating by stream (-5 %); three STATIC levels only move
+// the favour to another wave (nothing).  Handing the workgroup's streams to its waves from a counter in LDS instead of the static
+// partition evens the waves out as well (-7.5 % alone) and adds nothing beside the priorities; a device-wide ticket counter costs more in
+// atomic round trips than it evens out (+3 %).  0 = off.
 #ifndef OWF_PRIO
 #define OWF_PRIO 6
 #endif
